@@ -1,0 +1,138 @@
+/*
+ * vattn.h — C ABI of the MI355X-native vAttention page manager (libvattn_amd.so).
+ *
+ * Drop-in boundary for the reference's `vattention` Python module
+ * (/root/reference/vattention/vattention.cu:614-637, apis.h:1-63).  Each entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; no torch types, no exceptions:
+ * every call returns a VATTN_* code (or a value whose negative range is the code) and
+ * vattn_last_error() holds the message the Python layer turns into the reference's exception.
+ *
+ * Execution model (differs from the reference by design, observable bookkeeping is identical):
+ *   - integer bookkeeping (slots, mapped page counts, pool) is updated synchronously inside the
+ *     call, so num_free_kvblocks / alloc_new_batch_idx never race with background work;
+ *   - the driver calls a step needs NOW are executed before the call returns;
+ *   - look-ahead mapping / reclamation planned by step_async is executed by ONE mapper thread
+ *     while the GPU runs the forward pass; the next step()/step_async()/cleanup() joins it first
+ *     (HIP has no stream-ordered VMM call: hipMemMapArrayAsync returns hipErrorNotSupported,
+ *     /opt/rocm/include/hip/hip_runtime_api.h:9409-9420).
+ */
+#ifndef VATTN_H_
+#define VATTN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VATTN_OK 0
+#define VATTN_ERR_INVALID (-1)     /* bad argument / bad state                                  */
+#define VATTN_ERR_OOM (-2)         /* "OOM on demand" — vattention.cu:295                        */
+#define VATTN_ERR_DRIVER (-3)      /* a HIP VMM call failed (reference: exit(1), cudaInternal.h:1-13) */
+#define VATTN_ERR_POOL_EMPTY (-4)  /* "page pool is empty" — mux.h:2-3                           */
+
+/* vattn_config.flags */
+#define VATTN_FLAG_EAGER_CREATE 1u      /* create every physical handle inside reserve (reference behaviour) */
+#define VATTN_FLAG_NO_ACCESS_MERGE 2u   /* one set-access call per page instead of one per contiguous run   */
+#define VATTN_FLAG_NO_MAPPER_THREAD 4u  /* run "background" work inline (deterministic tests)               */
+
+typedef struct vattn_config {
+    uint32_t num_layers;          /* init_kvcache(num_layers, ...)   apis.h:3-13 */
+    uint32_t num_kv_heads;
+    uint32_t head_size;
+    uint32_t max_batch_size;
+    uint64_t max_context_length;
+    uint32_t itemsize;            /* dtype.itemsize (vattention.cu:122) */
+    int32_t device;
+    uint64_t page_size;           /* bytes; any multiple of the HIP VMM minimum granularity */
+    uint32_t megacache;
+    uint32_t flags;
+} vattn_config;
+
+/* Pluggable physical backend.  NULL selects the HIP VMM backend (the product path).  A custom
+ * table exists so the bookkeeping core can be driven on a CPU-only box by tests (tests/native/)
+ * and under ThreadSanitizer; it is never selected implicitly. All functions return 0 on success. */
+typedef struct vattn_backend_ops {
+    void* ctx;
+    int (*granularity)(void* ctx, uint64_t* min_gran, uint64_t* rec_gran);
+    int (*reserve_va)(void* ctx, uint64_t bytes, uint64_t align, uint64_t* base_out);
+    int (*free_va)(void* ctx, uint64_t base, uint64_t bytes);
+    int (*create)(void* ctx, uint64_t bytes, uint64_t* handle_out);
+    int (*release)(void* ctx, uint64_t handle);
+    int (*map)(void* ctx, uint64_t va, uint64_t bytes, uint64_t handle);
+    int (*set_access)(void* ctx, uint64_t va, uint64_t bytes);
+    int (*unmap)(void* ctx, uint64_t va, uint64_t bytes);
+    int (*thread_init)(void* ctx);          /* called once on the mapper thread (may be NULL) */
+} vattn_backend_ops;
+
+typedef struct vattn_layout {       /* element-unit description of every returned tensor */
+    uint32_t ndim;                  /* 4, or 5 for megacache */
+    uint64_t shape[5];              /* [B, max_ctx, kvh, D] or [B, max_ctx, L, kvh, D]  (vattention.cu:142-153) */
+    uint64_t stride[5];             /* batch stride = virt_bytes_per_req / itemsize (explicit padding) */
+    uint64_t virt_bytes_per_req;    /* ROUND_UP(max_ctx*row_bytes, page)  vattention.cu:57-58 */
+    uint64_t virt_bytes_total;
+    uint64_t tokens_per_page;       /* vattention.cu:38-47 */
+    uint64_t max_pages_per_req;
+    uint64_t page_size;
+} vattn_layout;
+
+typedef struct vattn_stats {
+    uint64_t handles_created, handles_released;
+    uint64_t map_calls, access_calls, unmap_calls;
+    uint64_t sync_batches, async_batches;
+    uint64_t sync_ns, async_ns;           /* wall time inside driver calls, per class */
+    uint64_t join_wait_ns;                /* time step()/step_async() spent waiting for the mapper */
+    uint64_t create_ns;
+    uint64_t pages_mapped_now;            /* currently mapped physical pages */
+} vattn_stats;
+
+typedef struct vattn_handle vattn_t;
+
+/* init_kvcache (apis.h:3-13; vattention.cu:97-128,142-187): validates the configuration, reserves
+ * 2*L (or 2) virtual ranges.  Tensor i: K_l -> l, V_l -> L+l (megacache: K -> 0, V -> 1). */
+int vattn_create(const vattn_config* cfg, const vattn_backend_ops* backend_or_null, vattn_t** out);
+int vattn_num_tensors(const vattn_t* m);
+uint64_t vattn_tensor_base(const vattn_t* m, int i);          /* device VA of tensor i */
+int vattn_get_layout(const vattn_t* m, vattn_layout* out);
+
+/* reserve_physical_pages (apis.h:23-25; cudaInternal.h:45-59; utils.h:221-228): returns the pool
+ * size in pages (rounded down to a multiple of 2*L), negative VATTN_ERR_* on failure. */
+int64_t vattn_reserve_physical_pages(vattn_t* m, uint64_t free_memory);
+
+/* step (apis.h:27-29; vattention.cu:395-409) and step_async (apis.h:31-35; vattention.cu:549-558).
+ * n must equal max_batch_size (the reference indexes unchecked). */
+int vattn_step(vattn_t* m, const uint64_t* seq_lens, uint32_t n, int eager_reclaim);
+int vattn_step_async(vattn_t* m, const uint64_t* seq_lens, uint32_t n);
+int vattn_wait(vattn_t* m);                                    /* join outstanding background mapping */
+
+/* alloc_new_batch_idx / free_batch_idx / num_free_kvblocks (apis.h:53-63; vattention.cu:189-217,564-594) */
+int vattn_alloc_new_batch_idx(vattn_t* m, uint64_t seqlen);    /* slot, or -1 if none is free */
+int vattn_free_batch_idx(vattn_t* m, int slot);
+uint64_t vattn_num_free_kvblocks(vattn_t* m);                  /* u64 wrap-around kept (utils.h:177-183) */
+
+/* set_deferred_reclamation / set_verbose / map_common_pages / show_* (apis.h:15-21,37-51) */
+int vattn_set_deferred_reclamation(vattn_t* m, int on);
+int vattn_set_verbose(vattn_t* m, int on);
+int vattn_map_common_pages(vattn_t* m, uint64_t num_tokens);
+int vattn_show_kvcache_config(vattn_t* m);
+int vattn_show_allocator_state(vattn_t* m);
+
+/* cleanup (apis.h:41-43; vattention.cu:601-609; cudaInternal.h:84-94): joins the mapper, unmaps
+ * everything, frees the virtual ranges, releases every physical handle. */
+int vattn_cleanup(vattn_t* m);
+void vattn_destroy(vattn_t* m);
+
+/* Introspection for bit-exact tests.  out = [B, pool_size, pagemap_rows, mapped[B], lens[B],
+ * pool page-ids bottom..top]; returns words written, or -(words needed). */
+int64_t vattn_state_dump(vattn_t* m, uint64_t* out, uint64_t cap);
+/* page map rows (slot, byte offset, layer, k page-id, v page-id) in key order; returns rows. */
+int64_t vattn_pagemap_dump(vattn_t* m, uint64_t* out, uint64_t cap_rows);
+int vattn_get_stats(vattn_t* m, vattn_stats* out);
+const char* vattn_last_error(const vattn_t* m);
+/* HIP VMM granularity probe for a device: 0 on success. */
+int vattn_hip_granularity(int device, uint64_t* min_gran, uint64_t* rec_gran);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VATTN_H_ */

@@ -1,0 +1,128 @@
+"""CPU oracle for the attention half of the hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+PARITY UNPINNED (stated as the task requires): the arithmetic of this path lives in the
+third-party package  flash-attn == 2.5.9.post1  (/root/reference/sarathi-lean/requirements.txt:22),
+whose sources are NOT under /root/reference and which cannot be built or imported here (CUDA
+only, no network).  The reference repository holds no golden vectors and no unit test for it
+(SURVEY §0.3, §8c).  This file therefore restates the *published* algorithm, following the
+in-tree FlashAttention-2.6.1 fork that documents the same operator:
+
+    semantics / docstring   /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291
+    argument rules          /root/reference/pod_attn/pod_attn/flash_api.cpp:1291-1578
+    visible keys            /root/reference/pod_attn/pod_attn/block_info.h:22-23
+    causal mask             /root/reference/pod_attn/pod_attn/mask.h:164-196  (bottom-right aligned)
+    softmax numerics        /root/reference/pod_attn/pod_attn/softmax.h:69-157
+    KV append               /root/reference/sarathi-lean/csrc/cache_kernels.cu:482-570 (cache_flat)
+
+and anchors on the reference's own call sites
+(/root/reference/sarathi-lean/sarathi/model_executor/attention/vattention_flashattention_wrapper.py:151-205).
+It is cross-checked against torch's independent CPU scaled_dot_product_attention in
+tests/test_attn_oracle.py.
+
+Two precisions:
+  * ``math="f64"``  — exact-arithmetic ground truth on the fp16/bf16 inputs (what tests compare to);
+  * ``math="f32"``  — fp32 accumulate, P rounded to the I/O dtype before PV (the reference kernel's
+                      numerics, flash_fwd_kernel.h:927,992) — used to bound the allowed error and as
+                      the timed CPU baseline.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import torch
+
+APPEND_ERR = "If key is supplied, it must have seqlen <= the seqlen of the KV cache"   # flash_api.cpp:1454
+
+
+def cache_flat_ref(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                   kv_cache_dtype: str = "auto") -> None:
+    """cache_kernels.cu:482-570: k_cache[t] = key[t], v_cache[t] = value[t] for t < num_tokens.
+    key/value [n, kvh, D]; caches are row views [>=n, kvh, D] (caller pre-slices at the offset)."""
+    if kv_cache_dtype != "auto":
+        raise RuntimeError("Unsupported data type of kv cache: " + kv_cache_dtype)   # :532-534
+    assert k_cache.stride(0) == v_cache.stride(0)                                     # :543
+    n = key.shape[0]
+    k_cache[:n].copy_(key)
+    v_cache[:n].copy_(value)
+
+
+def flash_attn_with_kvcache_ref(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                                k: Optional[torch.Tensor] = None, v: Optional[torch.Tensor] = None,
+                                cache_seqlens: Optional[Union[int, torch.Tensor]] = None,
+                                cache_batch_idx: Optional[torch.Tensor] = None,
+                                softmax_scale: Optional[float] = None, causal: bool = False,
+                                math: str = "f64", return_lse: bool = False):
+    """q [B,Sq,Hq,D]; caches [Bc,Sk,Hkv,D]; optional new k,v [B,Sn,Hkv,D] appended in place at row
+    cache_seqlens[b] of cache slot cache_batch_idx[b] (identity if None).  Returns [B,Sq,Hq,D] in
+    float64 (math="f64") or the input dtype (math="f32")."""
+    B, Sq, Hq, D = q.shape
+    Bc, Sk, Hkv, _ = k_cache.shape
+    assert Hq % Hkv == 0
+    G = Hq // Hkv
+    if softmax_scale is None:
+        softmax_scale = D ** -0.5
+    if cache_seqlens is None:
+        lens = [Sk] * B                                   # no seqlens -> whole cache visible
+    elif isinstance(cache_seqlens, int):
+        lens = [cache_seqlens] * B
+    else:
+        lens = [int(x) for x in cache_seqlens.tolist()]
+    idx = list(range(B)) if cache_batch_idx is None else [int(x) for x in cache_batch_idx.tolist()]
+    Sn = 0
+    if k is not None:
+        assert v is not None and cache_seqlens is not None       # flash_api.cpp:1452-1453
+        Sn = k.shape[1]
+        for b in range(B):                                        # append-then-attend
+            k_cache[idx[b], lens[b]:lens[b] + Sn] = k[b]
+            v_cache[idx[b], lens[b]:lens[b] + Sn] = v[b]
+    wt = torch.float64 if math == "f64" else torch.float32
+    out = torch.zeros(B, Sq, Hq, D, dtype=wt)
+    lse = torch.full((B, Hq, Sq), float("-inf"), dtype=wt)
+    for b in range(B):
+        Lk = lens[b] + Sn                                          # block_info.h:22-23
+        if Lk <= 0:
+            continue
+        Kb = k_cache[idx[b], :Lk].to(wt)                           # [Lk,Hkv,D]
+        Vb = v_cache[idx[b], :Lk].to(wt)
+        # GQA: query head h uses kv head h // G   (flash_attn_interface.py:1189-1192)
+        Kh = Kb.permute(1, 0, 2).repeat_interleave(G, dim=0)       # [Hq,Lk,D]
+        Vh = Vb.permute(1, 0, 2).repeat_interleave(G, dim=0)
+        QB = 512                                                    # query rows per block (bounds memory only)
+        for q0 in range(0, Sq, QB):
+            q1 = min(Sq, q0 + QB)
+            Qb = q[b, q0:q1].to(wt)                                 # [sq,Hq,D]
+            S = torch.matmul(Qb.permute(1, 0, 2), Kh.transpose(1, 2)) * softmax_scale   # [Hq,sq,Lk]
+            if causal and Sq > 1:                                   # Sq==1: causal dropped (flash_api.cpp:1364)
+                i = torch.arange(q0, q1).view(-1, 1)
+                j = torch.arange(Lk).view(1, Lk)
+                S = S.masked_fill(~(j <= i + (Lk - Sq)), float("-inf"))  # bottom-right aligned (mask.h:164-196)
+            m = S.max(dim=-1, keepdim=True).values
+            dead = torch.isinf(m) & (m < 0)                        # fully masked row -> output 0
+            m = torch.where(dead, torch.zeros_like(m), m)
+            P = torch.exp(S - m)
+            l = P.sum(dim=-1, keepdim=True)
+            if math == "f32":
+                P = P.to(q.dtype).to(wt)                           # P rounded before PV
+            O = torch.matmul(P, Vh) / torch.where(dead, torch.ones_like(l), l)
+            O = torch.where(dead, torch.zeros_like(O), O)
+            out[b, q0:q1] = O.permute(1, 0, 2)
+            row_lse = (m + torch.log(l)).squeeze(-1)
+            lse[b, :, q0:q1] = torch.where(dead.squeeze(-1), torch.full_like(row_lse, float("inf")), row_lse)
+    if math == "f32":
+        out = out.to(q.dtype)
+    return (out, lse) if return_lse else out
+
+
+def flash_attn_func_ref(q, k, v, softmax_scale=None, causal=False, math="f64"):
+    """flash_attn_func (no cache): q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D]."""
+    return flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=k.shape[1],
+                                       softmax_scale=softmax_scale, causal=causal, math=math)
+
+
+def check_append_shapes(seqlen_q_effective: int, seqlen_k_cache: int) -> None:
+    """flash_api.cpp:1454 — the reference raises when (possibly GQA-swapped) seqlen_q exceeds the
+    cache's seqlen dimension.  SURVEY §A.2: the product's shim does not raise there."""
+    if seqlen_q_effective > seqlen_k_cache:
+        raise RuntimeError(APPEND_ERR)

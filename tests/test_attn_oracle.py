@@ -1,0 +1,97 @@
+"""oracle/attn.py against an independent implementation (torch CPU SDPA) and its own invariants."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.attn import cache_flat_ref, flash_attn_func_ref, flash_attn_with_kvcache_ref
+
+
+def _sdpa(q, k, v, mask):
+    # q [B,Sq,Hq,D] k/v [B,Sk,Hkv,D]
+    G = q.shape[2] // k.shape[2]
+    kk = k.double().permute(0, 2, 1, 3).repeat_interleave(G, dim=1)
+    vv = v.double().permute(0, 2, 1, 3).repeat_interleave(G, dim=1)
+    o = F.scaled_dot_product_attention(q.double().permute(0, 2, 1, 3), kk, vv, attn_mask=mask)
+    return o.permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("Sq,Sk,Hq,Hkv", [(1, 77, 8, 2), (33, 33, 4, 4), (17, 90, 8, 1), (64, 300, 6, 2)])
+def test_matches_sdpa(Sq, Sk, Hq, Hkv):
+    torch.manual_seed(0)
+    B, D = 2, 64
+    q = torch.randn(B, Sq, Hq, D).half()
+    k = torch.randn(B, Sk, Hkv, D).half()
+    v = torch.randn(B, Sk, Hkv, D).half()
+    i = torch.arange(Sq).view(Sq, 1)
+    j = torch.arange(Sk).view(1, Sk)
+    mask = j <= i + (Sk - Sq)
+    ref = _sdpa(q, k, v, mask)
+    got = flash_attn_func_ref(q, k, v, causal=True)
+    assert torch.allclose(got, ref, atol=1e-9, rtol=1e-9)
+    got_nc = flash_attn_func_ref(q, k, v, causal=False)
+    assert torch.allclose(got_nc, _sdpa(q, k, v, None), atol=1e-9, rtol=1e-9)
+
+
+def test_bottom_right_alignment_docstring_examples():
+    # flash_attn_interface.py:1194-1206: seqlen_q=2,seqlen_k=5 and seqlen_q=5,seqlen_k=2
+    torch.manual_seed(1)
+    q = torch.randn(1, 5, 1, 16).half()
+    k = torch.randn(1, 2, 1, 16).half()
+    v = torch.randn(1, 2, 1, 16).half()
+    o = flash_attn_func_ref(q, k, v, causal=True)
+    assert torch.all(o[0, :3] == 0)                     # fully masked rows -> 0
+    assert torch.allclose(o[0, 3, 0], v[0, 0, 0].double())   # row 3 sees only key 0
+    assert not torch.all(o[0, 4] == 0)
+
+
+def test_append_and_batch_idx_and_chunked_equals_unchunked():
+    torch.manual_seed(2)
+    Hq, Hkv, D, ctx = 8, 2, 64, 256
+    kc = torch.zeros(5, ctx, Hkv, D).half()
+    vc = torch.zeros(5, ctx, Hkv, D).half()
+    n = 100
+    q = torch.randn(1, n, Hq, D).half()
+    k = torch.randn(n, Hkv, D).half()
+    v = torch.randn(n, Hkv, D).half()
+    slot = 3
+    # unchunked prefill through cache_flat + kvcache attention (wrapper :151-166)
+    cache_flat_ref(k, v, kc[slot], vc[slot])
+    full = flash_attn_with_kvcache_ref(q, kc[slot:slot + 1], vc[slot:slot + 1], cache_seqlens=torch.tensor([n], dtype=torch.int32), causal=True)
+    # chunked: 4 x 25
+    kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    outs = []
+    for c in range(0, n, 25):
+        cache_flat_ref(k[c:c + 25], v[c:c + 25], kc2[slot][c:], vc2[slot][c:])
+        outs.append(flash_attn_with_kvcache_ref(q[:, c:c + 25], kc2[slot:slot + 1], vc2[slot:slot + 1],
+                                                cache_seqlens=torch.tensor([c + 25], dtype=torch.int32), causal=True))
+    assert torch.allclose(torch.cat(outs, 1), full, atol=1e-12)
+    # decode with append + cache_batch_idx
+    qd = torch.randn(2, 1, Hq, D).half()
+    kn = torch.randn(2, 1, Hkv, D).half()
+    vn = torch.randn(2, 1, Hkv, D).half()
+    cache_flat_ref(k[:40], v[:40], kc[1], vc[1])
+    lens = torch.tensor([n, 40], dtype=torch.int32)
+    idx = torch.tensor([slot, 1], dtype=torch.int32)
+    o = flash_attn_with_kvcache_ref(qd, kc[:, :n + 1], vc[:, :n + 1], kn, vn, cache_seqlens=lens, cache_batch_idx=idx, causal=True)
+    assert torch.equal(kc[slot, n], kn[0, 0]) and torch.equal(vc[1, 40], vn[1, 0])
+    ref0 = flash_attn_func_ref(qd[:1], kc[slot:slot + 1, :n + 1], vc[slot:slot + 1, :n + 1])
+    assert torch.allclose(o[:1], ref0, atol=1e-12)
+
+
+def test_f32_mode_error_budget():
+    torch.manual_seed(3)
+    q = torch.randn(1, 64, 8, 128).half()
+    k = torch.randn(1, 512, 2, 128).half()
+    v = torch.randn(1, 512, 2, 128).half()
+    a = flash_attn_func_ref(q, k, v, causal=True)
+    b = flash_attn_func_ref(q, k, v, causal=True, math="f32")
+    assert b.dtype == torch.float16
+    assert (a - b.double()).abs().max() < 2e-3
+
+
+def test_cache_flat_rejects_dtype():
+    k = torch.zeros(2, 1, 8).half()
+    with pytest.raises(RuntimeError, match="Unsupported data type"):
+        cache_flat_ref(k, k, k.clone(), k.clone(), "fp8")

@@ -1,0 +1,114 @@
+// HIP virtual-memory backend of the page manager: the product path on MI355X.
+// Replaces the reference's CUDA-driver backend (/root/reference/vattention/cudaInternal.h:15-94,
+// vtensor.h:21-46) and, for sub-2MiB pages, its patched-UVM-driver backend (uvmInternal.h) — on
+// gfx950 small pages are just a smaller multiple of the VMM granularity, no driver patch.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "page_manager.h"
+
+namespace vattn {
+
+struct HipCtx {
+    int device;
+    hipMemAllocationProp prop;
+    hipMemAccessDesc access;
+};
+
+static int hip_fail(const char* what, hipError_t e) {
+    fprintf(stderr, "[vattn] %s failed: %s (%d)\n", what, hipGetErrorString(e), (int)e);
+    return -1;
+}
+
+static int h_thread_init(void* c) {
+    auto* x = (HipCtx*)c;
+    hipError_t e = hipSetDevice(x->device);
+    return e == hipSuccess ? 0 : hip_fail("hipSetDevice", e);
+}
+static int h_granularity(void* c, uint64_t* mn, uint64_t* rec) {
+    auto* x = (HipCtx*)c;
+    size_t a = 0, b = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&a, &x->prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return hip_fail("hipMemGetAllocationGranularity(min)", e);
+    e = hipMemGetAllocationGranularity(&b, &x->prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess) return hip_fail("hipMemGetAllocationGranularity(rec)", e);
+    *mn = a;
+    *rec = b;
+    return 0;
+}
+static int h_reserve(void*, uint64_t bytes, uint64_t align, uint64_t* out) {
+    void* p = nullptr;
+    hipError_t e = hipMemAddressReserve(&p, bytes, align, nullptr, 0);
+    if (e != hipSuccess) return hip_fail("hipMemAddressReserve", e);
+    *out = (uint64_t)p;
+    return 0;
+}
+static int h_free_va(void*, uint64_t base, uint64_t bytes) {
+    hipError_t e = hipMemAddressFree((void*)base, bytes);
+    return e == hipSuccess ? 0 : hip_fail("hipMemAddressFree", e);
+}
+static int h_create(void* c, uint64_t bytes, uint64_t* out) {
+    auto* x = (HipCtx*)c;
+    hipMemGenericAllocationHandle_t h;
+    hipError_t e = hipMemCreate(&h, bytes, &x->prop, 0);
+    if (e != hipSuccess) return hip_fail("hipMemCreate", e);
+    static_assert(sizeof(h) <= sizeof(uint64_t), "handle must fit in 64 bits");
+    uint64_t v = 0;
+    memcpy(&v, &h, sizeof(h));
+    *out = v;
+    return 0;
+}
+static int h_release(void*, uint64_t handle) {
+    hipMemGenericAllocationHandle_t h;
+    memcpy(&h, &handle, sizeof(h));
+    hipError_t e = hipMemRelease(h);
+    return e == hipSuccess ? 0 : hip_fail("hipMemRelease", e);
+}
+static int h_map(void*, uint64_t va, uint64_t bytes, uint64_t handle) {
+    hipMemGenericAllocationHandle_t h;
+    memcpy(&h, &handle, sizeof(h));
+    hipError_t e = hipMemMap((void*)va, bytes, 0, h, 0);   // offset "currently must be zero" (hip_runtime_api.h:9396-9407)
+    return e == hipSuccess ? 0 : hip_fail("hipMemMap", e);
+}
+static int h_access(void* c, uint64_t va, uint64_t bytes) {
+    auto* x = (HipCtx*)c;
+    hipError_t e = hipMemSetAccess((void*)va, bytes, &x->access, 1);
+    return e == hipSuccess ? 0 : hip_fail("hipMemSetAccess", e);
+}
+static int h_unmap(void*, uint64_t va, uint64_t bytes) {
+    hipError_t e = hipMemUnmap((void*)va, bytes);
+    return e == hipSuccess ? 0 : hip_fail("hipMemUnmap", e);
+}
+
+// Fills `ops` with the HIP VMM table for `device`; the context object lives for the process.
+int make_hip_backend(int device, vattn_backend_ops* ops) {
+    // A HIP context must exist on the calling thread ("initialize PyTorch first", cudaInternal.h:20-25);
+    // hipSetDevice creates/binds the primary context, so no torch dependency is needed here.
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    auto* x = new HipCtx();
+    x->device = device;
+    memset(&x->prop, 0, sizeof(x->prop));
+    x->prop.type = hipMemAllocationTypePinned;
+    x->prop.location.type = hipMemLocationTypeDevice;
+    x->prop.location.id = device;
+    memset(&x->access, 0, sizeof(x->access));
+    x->access.location.type = hipMemLocationTypeDevice;
+    x->access.location.id = device;
+    x->access.flags = hipMemAccessFlagsProtReadWrite;
+    ops->ctx = x;
+    ops->granularity = h_granularity;
+    ops->reserve_va = h_reserve;
+    ops->free_va = h_free_va;
+    ops->create = h_create;
+    ops->release = h_release;
+    ops->map = h_map;
+    ops->set_access = h_access;
+    ops->unmap = h_unmap;
+    ops->thread_init = h_thread_init;
+    return 0;
+}
+
+}  // namespace vattn

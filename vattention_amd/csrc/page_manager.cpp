@@ -1,0 +1,636 @@
+// See page_manager.h.  Reference citations are relative to /root/reference/vattention/.
+#include "page_manager.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+namespace vattn {
+
+namespace {
+constexpr uint64_t kEagerNumSteps = 10;    // vattention.cu:484
+constexpr uint64_t kEagerNumKvBlocks = 2;  // vattention.cu:485
+constexpr uint64_t kPrecreateSlice = 16;   // handles created per idle slice of the mapper thread
+
+inline uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+inline uint64_t round_up(uint64_t x, uint64_t y) { return ((x + y - 1) / y) * y; }  // utils.h:10
+}  // namespace
+
+PageManager::PageManager(const vattn_config& cfg, const vattn_backend_ops& be) : cfg_(cfg), be_(be) {}
+
+PageManager::~PageManager() {
+    if (inited_ && !cleaned_) cleanup();
+    {
+        std::lock_guard<std::mutex> l(q_mu_);
+        stop_ = true;
+    }
+    q_cv_.notify_all();
+    if (mapper_.joinable()) mapper_.join();
+}
+
+int PageManager::fail(int code, const std::string& msg) {
+    last_error_ = msg;
+    return code;
+}
+
+void PageManager::log(const std::string& s) const {
+    if (verbose_) std::cout << s << std::endl;   // utils.h:230-238
+}
+
+// vattention.cu:97-128 (asserts :107-110 are explicit errors here), :38-74, utils.h:88-97
+int PageManager::init() {
+    if (!(cfg_.max_batch_size > 0 && cfg_.max_batch_size < 1000)) return fail(VATTN_ERR_INVALID, "max_batch_size must be in (0, 1000)");
+    if (!(cfg_.max_context_length > 0 && cfg_.max_context_length < 1000000)) return fail(VATTN_ERR_INVALID, "max_context_length must be in (0, 1000000)");
+    if (!(cfg_.num_layers > 0 && cfg_.num_layers < 100)) return fail(VATTN_ERR_INVALID, "num_layers must be in (0, 100)");
+    if (!(cfg_.num_kv_heads > 0 && cfg_.num_kv_heads < 256)) return fail(VATTN_ERR_INVALID, "num_kv_heads must be in (0, 256)");
+    if (cfg_.head_size == 0 || cfg_.itemsize == 0 || cfg_.page_size == 0) return fail(VATTN_ERR_INVALID, "head_size, itemsize and page_size must be non-zero");
+
+    uint64_t min_gran = 0, rec_gran = 0;
+    if (be_.granularity(be_.ctx, &min_gran, &rec_gran) != 0) return fail(VATTN_ERR_DRIVER, "granularity query failed");
+    if (min_gran == 0 || cfg_.page_size % min_gran != 0) {
+        std::ostringstream ss;
+        ss << "page_size " << cfg_.page_size << " is not a multiple of the device's minimum mapping granularity " << min_gran;
+        return fail(VATTN_ERR_INVALID, ss.str());
+    }
+    row_bytes_ = (uint64_t)cfg_.num_kv_heads * cfg_.head_size * cfg_.itemsize;
+    if (cfg_.megacache) row_bytes_ *= cfg_.num_layers;
+    tokens_per_page_ = cfg_.page_size / row_bytes_;
+    if (tokens_per_page_ == 0) return fail(VATTN_ERR_INVALID, "page_size is smaller than one token's KV row");
+    virt_per_req_ = round_up(row_bytes_ * cfg_.max_context_length, cfg_.page_size);
+    max_pages_per_req_ = virt_per_req_ / cfg_.page_size;
+    virt_total_ = virt_per_req_ * cfg_.max_batch_size;
+
+    mapped_pages_.assign(cfg_.max_batch_size, 0);
+    lens_.assign(cfg_.max_batch_size, 0);
+
+    const int nt = cfg_.megacache ? 2 : 2 * (int)cfg_.num_layers;
+    const uint64_t align = std::max<uint64_t>(cfg_.page_size, rec_gran);
+    for (int i = 0; i < nt; i++) {
+        uint64_t base = 0;
+        if (be_.reserve_va(be_.ctx, virt_total_, align, &base) != 0 || base == 0) {
+            for (uint64_t b : bases_) be_.free_va(be_.ctx, b, virt_total_);
+            bases_.clear();
+            std::ostringstream ss;
+            ss << "virtual address reservation of " << virt_total_ << " bytes failed (tensor " << i << ")";
+            return fail(VATTN_ERR_DRIVER, ss.str());
+        }
+        bases_.push_back(base);
+    }
+    if (!(cfg_.flags & VATTN_FLAG_NO_MAPPER_THREAD)) mapper_ = std::thread([this] { mapper_main(); });
+    inited_ = true;
+    return VATTN_OK;
+}
+
+void PageManager::layout(vattn_layout* o) const {
+    const uint64_t kvh = cfg_.num_kv_heads, D = cfg_.head_size, L = cfg_.num_layers;
+    const uint64_t bstride = virt_per_req_ / cfg_.itemsize;
+    if (cfg_.megacache) {   // vattention.cu:146-147
+        o->ndim = 5;
+        const uint64_t sh[5] = {cfg_.max_batch_size, cfg_.max_context_length, L, kvh, D};
+        const uint64_t st[5] = {bstride, L * kvh * D, kvh * D, D, 1};
+        for (int i = 0; i < 5; i++) { o->shape[i] = sh[i]; o->stride[i] = st[i]; }
+    } else {                // vattention.cu:149
+        o->ndim = 4;
+        const uint64_t sh[5] = {cfg_.max_batch_size, cfg_.max_context_length, kvh, D, 0};
+        const uint64_t st[5] = {bstride, kvh * D, D, 1, 0};
+        for (int i = 0; i < 5; i++) { o->shape[i] = sh[i]; o->stride[i] = st[i]; }
+    }
+    o->virt_bytes_per_req = virt_per_req_;
+    o->virt_bytes_total = virt_total_;
+    o->tokens_per_page = tokens_per_page_;
+    o->max_pages_per_req = max_pages_per_req_;
+    o->page_size = cfg_.page_size;
+}
+
+// ------------------------------------------------------------------------------------------
+// bookkeeping planners
+// ------------------------------------------------------------------------------------------
+
+uint64_t PageManager::need_new_page_async(int r, uint64_t eager) const {   // utils.h:206-219
+    if (!active(r)) return 0;
+    const uint64_t mapped = mapped_pages_[r];
+    if (mapped == max_pages_per_req_) return 0;
+    const uint64_t req = tokens_to_pages(lens_[r] + eager);
+    return req <= mapped ? 0 : req - mapped;
+}
+
+int PageManager::plan_map_pair(int r, uint32_t layer, uint64_t off) {      // mux.h:37-48, cudaInternal.h:70-82
+    if (pool_.size() < 2) return fail(VATTN_ERR_POOL_EMPTY, "***** page pool is empty *****");
+    const uint32_t k = pool_.back(); pool_.pop_back();
+    const uint32_t v = pool_.back(); pool_.pop_back();
+    plan_.push_back({0, k_tensor(layer), k, off});
+    plan_.push_back({0, v_tensor(layer), v, off});
+    pagemap_[std::make_tuple((uint64_t)r, off, (uint64_t)layer)] = std::make_pair(k, v);
+    return VATTN_OK;
+}
+
+void PageManager::plan_unmap_pair(int r, uint32_t layer, uint64_t off) {   // mux.h:51-66
+    plan_.push_back({1, k_tensor(layer), 0, off});
+    plan_.push_back({1, v_tensor(layer), 0, off});
+    auto key = std::make_tuple((uint64_t)r, off, (uint64_t)layer);
+    auto it = pagemap_.find(key);
+    if (it != pagemap_.end()) {
+        pool_.push_back(it->second.first);      // K first, then V
+        pool_.push_back(it->second.second);
+        pagemap_.erase(it);
+    }
+}
+
+void PageManager::unmap_req_page_one(int r) {    // vattention.cu:219-241, utils.h:193-204
+    const uint64_t off = (uint64_t)r * virt_per_req_ + (mapped_pages_[r] - 1) * cfg_.page_size;
+    if (cfg_.megacache) {
+        plan_unmap_pair(r, 0, off);
+    } else {
+        for (uint32_t l = 0; l < cfg_.num_layers; l++) plan_unmap_pair(r, l, off);
+    }
+    mapped_pages_[r]--;
+}
+
+void PageManager::release_some(int r, uint64_t retain) {   // vattention.cu:243-247
+    while (mapped_pages_[r] > retain) unmap_req_page_one(r);
+}
+
+int PageManager::grow(int r, uint64_t nblocks, bool sync) {   // vattention.cu:268-323
+    if (nblocks == 0) return VATTN_OK;
+    if (!kvblocks_available(nblocks)) {
+        if (!sync) return VATTN_OK;               // background attempt: silently give up
+        verbose_ = true;                          // the reference flips verbose on here (:283)
+        log("free pages: " + std::to_string(pages_to_kvblocks(pool_.size())));
+        log("required: " + std::to_string(nblocks));
+        show_allocator_state();
+        return fail(VATTN_ERR_OOM, "***** OOM on demand: not enough free pages to continue *****");
+    }
+    for (uint64_t c = 0; c < nblocks; c++) {
+        const uint64_t off = (uint64_t)r * virt_per_req_ + mapped_pages_[r] * cfg_.page_size;   // utils.h:185-191
+        if (!(off < (uint64_t)(r + 1) * virt_per_req_)) return VATTN_OK;   // is_valid_offset, :254-265 (never throws)
+        if (cfg_.megacache) {
+            int rc = plan_map_pair(r, 0, off);
+            if (rc) return rc;
+        } else {
+            for (uint32_t l = 0; l < cfg_.num_layers; l++) {
+                int rc = plan_map_pair(r, l, off);
+                if (rc) return rc;
+            }
+        }
+        mapped_pages_[r]++;
+    }
+    return VATTN_OK;
+}
+
+void PageManager::reclaim_on_demand(uint64_t nblocks) {   // vattention.cu:420-438
+    for (int r = (int)cfg_.max_batch_size - 1; r >= 0; r--) {
+        if (kvblocks_available(nblocks)) break;
+        const uint64_t mapped = mapped_pages_[r];
+        const uint64_t required = tokens_to_pages(lens_[r]);
+        if (mapped <= required) continue;
+        release_some(r, required);
+    }
+}
+
+void PageManager::do_reclaim_pages() {   // vattention.cu:444-469
+    if (deferred_reclaim_) return;
+    int next_prefill = -1;
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++)
+        if (!active(r)) { next_prefill = r; break; }
+    for (int r = (int)cfg_.max_batch_size - 1; r >= 0; r--) {
+        if (active(r) || r == next_prefill) continue;
+        if (mapped_pages_[r] == 0) continue;
+        unmap_req_page_one(r);
+        break;
+    }
+}
+
+int PageManager::map_pages_for_curr_step(int r, uint64_t seq_len) {   // vattention.cu:376-392
+    uint64_t required = tokens_to_pages(seq_len);
+    const uint64_t mapped = mapped_pages_[r];
+    if (required <= mapped) return VATTN_OK;
+    required -= mapped;
+    if (!kvblocks_available(required)) reclaim_on_demand(required);
+    log("[DEBUG] allocating " + std::to_string(required) + " pages for reqId: " + std::to_string(r));
+    int rc = grow(r, required, true);
+    if (rc) return rc;
+    lens_[r] = seq_len;
+    return VATTN_OK;
+}
+
+void PageManager::background_management() {   // vattention.cu:486-536
+    uint64_t required = 0;
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++) required += need_new_page_async(r, 1);
+    if (!kvblocks_available(required)) {
+        log("[DEBUG] reclaiming " + std::to_string(required) + " KV blocks in background thread...");
+        reclaim_on_demand(required);
+    }
+    if (!kvblocks_available(required)) return;
+    uint64_t mapped_curr = 0;
+    bool done = false;
+    for (uint64_t eager = 1; eager < kEagerNumSteps && !done; eager++) {
+        for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
+            const uint64_t n = need_new_page_async(r, eager);
+            grow(r, n, false);
+            mapped_curr += n;
+            if (eager == 1) continue;
+            if (mapped_curr >= kEagerNumKvBlocks) { done = true; break; }
+        }
+    }
+    if (required) return;
+    do_reclaim_pages();
+}
+
+// ------------------------------------------------------------------------------------------
+// API
+// ------------------------------------------------------------------------------------------
+
+int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInternal.h:45-59, utils.h:221-228
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (!inited_ || cleaned_) return fail(VATTN_ERR_INVALID, "allocator is not initialised");
+    uint64_t n = free_memory / cfg_.page_size;
+    n -= n % (2ull * cfg_.num_layers);            // multiple of 2*L even in megacache mode
+    if (n > 0xFFFFFFF0ull) return fail(VATTN_ERR_INVALID, "page count exceeds 32-bit page ids");
+    {
+        std::lock_guard<std::mutex> e(exec_mu_);
+        while (pool_.size() < n) {
+            const uint32_t id = (uint32_t)num_pages_++;
+            pool_.push_back(id);
+            handles_.push_back(0);
+            created_.push_back(0);
+        }
+    }
+    if (cfg_.flags & VATTN_FLAG_EAGER_CREATE) {
+        std::lock_guard<std::mutex> e(exec_mu_);
+        for (uint32_t id = 0; id < num_pages_; id++) {
+            int rc = ensure_created(id);
+            if (rc) return fail(rc, async_error_msg_);
+        }
+    } else if (!(cfg_.flags & VATTN_FLAG_NO_MAPPER_THREAD)) {
+        // lazy pool: the mapper materialises handles while it is idle, top of the LIFO first
+        {
+            std::lock_guard<std::mutex> q(q_mu_);
+            precreate_left_.store(num_pages_);
+        }
+        q_cv_.notify_all();
+    }
+    return (int64_t)(int32_t)(uint32_t)pool_.size();   // apis.h:23 returns int
+}
+
+int PageManager::step(const uint64_t* lens, uint32_t n, bool eager_reclaim) {   // vattention.cu:395-409
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (!inited_ || cleaned_) return fail(VATTN_ERR_INVALID, "allocator is not initialised");
+    if (n != cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "seq_lens must have max_batch_size entries");
+    int rc = wait_locked_free();
+    if (rc) return rc;
+    int err = VATTN_OK;
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
+        lens_[r] = lens[r];
+        if (eager_reclaim && lens[r] == 0 && mapped_pages_[r] != 0) {
+            release_some(r, 0);
+            continue;
+        }
+        err = map_pages_for_curr_step(r, lens[r]);
+        if (err) break;
+    }
+    rc = flush_sync();
+    return err ? err : rc;
+}
+
+int PageManager::step_async(const uint64_t* lens, uint32_t n) {   // vattention.cu:549-558
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (!inited_ || cleaned_) return fail(VATTN_ERR_INVALID, "allocator is not initialised");
+    if (n != cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "seq_lens must have max_batch_size entries");
+    lens_.assign(lens, lens + n);                       // utils.h:155-158
+    int rc = wait_locked_free();                        // wait_kvcache_manager_sync
+    if (rc) return rc;
+    int err = VATTN_OK;
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++) {   // prepare_prefill_kvcache, :411-418
+        err = map_pages_for_curr_step(r, lens_[r]);
+        if (err) break;
+    }
+    rc = flush_sync();
+    if (err) return err;
+    if (rc) return rc;
+    background_management();                            // planned now, executed by the mapper
+    flush_async();
+    return VATTN_OK;
+}
+
+int PageManager::wait() {
+    std::lock_guard<std::mutex> l(state_mu_);
+    return wait_locked_free();
+}
+
+int PageManager::alloc_new_batch_idx(uint64_t seqlen) {   // vattention.cu:564-589
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (!inited_ || cleaned_) return -1;
+    int new_id = -1;
+    const uint64_t required = tokens_to_pages(seqlen);
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
+        if (active(r)) continue;
+        if (new_id == -1) { new_id = r; continue; }
+        if (mapped_pages_[r] >= required && mapped_pages_[r] < mapped_pages_[new_id]) new_id = r;
+    }
+    if (new_id != -1) lens_[new_id] = seqlen;
+    return new_id;
+}
+
+int PageManager::free_batch_idx(int slot) {   // vattention.cu:591-594
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (slot < 0 || slot >= (int)cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "slot out of range");
+    lens_[slot] = 0;
+    return VATTN_OK;
+}
+
+uint64_t PageManager::num_free_kvblocks() {   // vattention.cu:189-210, utils.h:177-183 (u64 wrap kept)
+    std::lock_guard<std::mutex> l(state_mu_);
+    uint64_t over = 0;
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++) over += mapped_pages_[r] - tokens_to_pages(lens_[r]);
+    return pages_to_kvblocks(pool_.size()) + over;
+}
+
+int PageManager::set_deferred_reclamation(bool on) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    deferred_reclaim_ = on;
+    return VATTN_OK;
+}
+
+int PageManager::set_verbose(bool on) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    verbose_ = on;
+    return VATTN_OK;
+}
+
+int PageManager::map_common_pages(uint64_t num_tokens) {   // vattention.cu:325-373, mux.h:68-85
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (!inited_ || cleaned_) return fail(VATTN_ERR_INVALID, "allocator is not initialised");
+    int rc = wait_locked_free();
+    if (rc) return rc;
+    const uint64_t nblocks = tokens_to_pages(num_tokens);
+    if (nblocks == 0) return VATTN_OK;
+    if (!kvblocks_available(nblocks)) return fail(VATTN_ERR_OOM, "***** OOM on demand: not enough free pages to continue *****");
+    int err = VATTN_OK;
+    for (uint64_t c = 0; c < nblocks && !err; c++) {
+        const uint32_t nl = cfg_.megacache ? 1 : cfg_.num_layers;
+        for (uint32_t layer = 0; layer < nl && !err; layer++) {
+            if (pool_.size() < 2) { err = fail(VATTN_ERR_POOL_EMPTY, "***** page pool is empty *****"); break; }
+            const uint32_t k = pool_.back(); pool_.pop_back();
+            const uint32_t v = pool_.back(); pool_.pop_back();
+            for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
+                const uint64_t off = (uint64_t)r * virt_per_req_ + mapped_pages_[r] * cfg_.page_size;
+                plan_.push_back({0, k_tensor(layer), k, off});
+                plan_.push_back({0, v_tensor(layer), v, off});
+                pagemap_[std::make_tuple((uint64_t)r, off, (uint64_t)layer)] = std::make_pair(k, v);
+            }
+        }
+        if (!err)
+            for (int r = 0; r < (int)cfg_.max_batch_size; r++) mapped_pages_[r]++;
+    }
+    rc = flush_sync();
+    return err ? err : rc;
+}
+
+int PageManager::show_kvcache_config() {   // vattention.cu:130-140
+    std::lock_guard<std::mutex> l(state_mu_);
+    log("Num layers: " + std::to_string(cfg_.num_layers));
+    log("Num kv_heads: " + std::to_string(cfg_.num_kv_heads));
+    log("Head size: " + std::to_string(cfg_.head_size));
+    log("Max batch size: " + std::to_string(cfg_.max_batch_size));
+    log("Max context length: " + std::to_string(cfg_.max_context_length));
+    log("Bytes per elem: " + std::to_string(cfg_.itemsize));
+    log("virt_buff_size_per_req: " + std::to_string(virt_per_req_));
+    log("virt_buff_size: " + std::to_string(virt_total_));
+    return VATTN_OK;
+}
+
+int PageManager::show_allocator_state() {   // vattention.cu:76-95 (caller holds state_mu_ or is internal)
+    log("Free pool: " + std::to_string(pages_to_kvblocks(pool_.size())) + " KV blocks");
+    log("reqId : seqlen: mapped: required");
+    for (int i = 0; i < (int)cfg_.max_batch_size; i++) {
+        std::ostringstream ss;
+        ss << std::setw(8) << i << ": " << std::setw(8) << lens_[i] << " : " << std::setw(8) << mapped_pages_[i]
+           << " : " << std::setw(8) << tokens_to_pages(lens_[i]);
+        log(ss.str());
+    }
+    return VATTN_OK;
+}
+
+int PageManager::cleanup() {   // vattention.cu:601-609, mux.h:24-35, cudaInternal.h:84-94
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (!inited_ || cleaned_) return VATTN_OK;
+    wait_locked_free();
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++) release_some(r, 0);
+    int rc = flush_sync();
+    {
+        std::lock_guard<std::mutex> e(exec_mu_);
+        for (uint64_t b : bases_) be_.free_va(be_.ctx, b, virt_total_);
+        bases_.clear();
+        for (size_t i = 0; i < handles_.size(); i++) {
+            if (created_[i]) {
+                be_.release(be_.ctx, handles_[i]);
+                created_[i] = 0;
+                st_.handles_released++;
+            }
+        }
+        precreate_left_.store(0);
+    }
+    pool_.clear();
+    cleaned_ = true;
+    log("released memory and cleaned up vattention ...");
+    return rc;
+}
+
+int64_t PageManager::state_dump(uint64_t* out, uint64_t cap) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    const uint64_t B = cfg_.max_batch_size;
+    const uint64_t need = 3 + 2 * B + pool_.size();
+    if (cap < need) return -(int64_t)need;
+    uint64_t k = 0;
+    out[k++] = B;
+    out[k++] = pool_.size();
+    out[k++] = pagemap_.size();
+    for (uint64_t i = 0; i < B; i++) out[k++] = mapped_pages_[i];
+    for (uint64_t i = 0; i < B; i++) out[k++] = lens_[i];
+    for (uint32_t p : pool_) out[k++] = p;
+    return (int64_t)k;
+}
+
+int64_t PageManager::pagemap_dump(uint64_t* out, uint64_t cap_rows) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    uint64_t n = 0;
+    for (auto& kv : pagemap_) {
+        if (n >= cap_rows) return -(int64_t)pagemap_.size();
+        out[5 * n + 0] = std::get<0>(kv.first);
+        out[5 * n + 1] = std::get<1>(kv.first);
+        out[5 * n + 2] = std::get<2>(kv.first);
+        out[5 * n + 3] = kv.second.first;
+        out[5 * n + 4] = kv.second.second;
+        n++;
+    }
+    return (int64_t)n;
+}
+
+void PageManager::stats(vattn_stats* out) {
+    std::lock_guard<std::mutex> e(exec_mu_);
+    *out = st_;
+    out->join_wait_ns = join_wait_ns_.load();
+}
+
+// ------------------------------------------------------------------------------------------
+// executor
+// ------------------------------------------------------------------------------------------
+
+int PageManager::ensure_created(uint32_t page) {   // exec_mu_ held
+    if (created_[page]) return VATTN_OK;
+    const uint64_t t0 = now_ns();
+    uint64_t h = 0;
+    if (be_.create(be_.ctx, cfg_.page_size, &h) != 0) {
+        async_error_msg_ = "physical page allocation failed (out of device memory?)";
+        return VATTN_ERR_DRIVER;
+    }
+    handles_[page] = h;
+    created_[page] = 1;
+    st_.handles_created++;
+    st_.create_ns += now_ns() - t0;
+    return VATTN_OK;
+}
+
+int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async) {   // exec_mu_ held
+    const uint64_t t0 = now_ns();
+    const uint64_t page = cfg_.page_size;
+    const bool merge = !(cfg_.flags & VATTN_FLAG_NO_ACCESS_MERGE);
+    // pending set-access runs: (tensor, start offset, bytes); flushed before any unmap and at the end
+    std::vector<std::tuple<uint32_t, uint64_t, uint64_t>> runs;
+    auto flush_access = [&]() -> int {
+        if (runs.empty()) return 0;
+        if (merge) {
+            std::sort(runs.begin(), runs.end());
+            size_t w = 0;
+            for (size_t i = 1; i < runs.size(); i++) {
+                auto& a = runs[w];
+                auto& b = runs[i];
+                if (std::get<0>(a) == std::get<0>(b) && std::get<1>(a) + std::get<2>(a) == std::get<1>(b))
+                    std::get<2>(a) += std::get<2>(b);
+                else
+                    runs[++w] = b;
+            }
+            runs.resize(w + 1);
+        }
+        for (auto& r : runs) {
+            if (be_.set_access(be_.ctx, bases_[std::get<0>(r)] + std::get<1>(r), std::get<2>(r)) != 0) return -1;
+            st_.access_calls++;
+        }
+        runs.clear();
+        return 0;
+    };
+    int rc = VATTN_OK;
+    for (const PhysOp& op : ops) {
+        if (op.kind == 0) {
+            rc = ensure_created(op.page);
+            if (rc) break;
+            if (be_.map(be_.ctx, bases_[op.tensor] + op.offset, page, handles_[op.page]) != 0) {
+                async_error_msg_ = "hipMemMap failed";
+                rc = VATTN_ERR_DRIVER;
+                break;
+            }
+            st_.map_calls++;
+            st_.pages_mapped_now++;
+            runs.emplace_back(op.tensor, op.offset, page);
+        } else {
+            if (flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; break; }
+            if (be_.unmap(be_.ctx, bases_[op.tensor] + op.offset, page) != 0) {
+                async_error_msg_ = "hipMemUnmap failed";
+                rc = VATTN_ERR_DRIVER;
+                break;
+            }
+            st_.unmap_calls++;
+            st_.pages_mapped_now--;
+        }
+    }
+    if (!rc && flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; }
+    const uint64_t dt = now_ns() - t0;
+    if (is_async) { st_.async_batches++; st_.async_ns += dt; } else { st_.sync_batches++; st_.sync_ns += dt; }
+    return rc;
+}
+
+int PageManager::wait_locked_free() {   // state_mu_ held; joins every queued background batch
+    const uint64_t t0 = now_ns();
+    std::unique_lock<std::mutex> q(q_mu_);
+    done_cv_.wait(q, [this] { return inflight_ == 0; });
+    join_wait_ns_ += now_ns() - t0;
+    if (async_error_) {
+        int e = async_error_;
+        last_error_ = async_error_msg_;
+        return e;
+    }
+    return VATTN_OK;
+}
+
+int PageManager::flush_sync() {   // state_mu_ held, mapper idle (callers join first)
+    if (plan_.empty()) return VATTN_OK;
+    std::vector<PhysOp> ops;
+    ops.swap(plan_);
+    std::lock_guard<std::mutex> e(exec_mu_);
+    int rc = execute(ops, false);
+    if (rc) last_error_ = async_error_msg_;
+    return rc;
+}
+
+void PageManager::flush_async() {   // state_mu_ held
+    if (plan_.empty()) return;
+    std::vector<PhysOp> ops;
+    ops.swap(plan_);
+    if (cfg_.flags & VATTN_FLAG_NO_MAPPER_THREAD) {
+        std::lock_guard<std::mutex> e(exec_mu_);
+        int rc = execute(ops, true);
+        if (rc) async_error_ = rc;
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> q(q_mu_);
+        queue_.push_back(std::move(ops));
+        inflight_++;
+    }
+    q_cv_.notify_all();
+}
+
+void PageManager::mapper_main() {
+    if (be_.thread_init) be_.thread_init(be_.ctx);
+    std::unique_lock<std::mutex> q(q_mu_);
+    for (;;) {
+        q_cv_.wait(q, [this] { return stop_ || !queue_.empty() || precreate_left_.load() > 0; });
+        if (stop_) return;
+        if (!queue_.empty()) {
+            std::vector<PhysOp> ops = std::move(queue_.front());
+            queue_.pop_front();
+            q.unlock();
+            int rc;
+            {
+                std::lock_guard<std::mutex> e(exec_mu_);
+                rc = execute(ops, true);
+            }
+            q.lock();
+            if (rc && !async_error_) async_error_ = rc;
+            inflight_--;
+            if (inflight_ == 0) done_cv_.notify_all();
+            continue;
+        }
+        // idle: materialise a few physical handles ahead of demand (lazy pool)
+        q.unlock();
+        {
+            std::lock_guard<std::mutex> e(exec_mu_);
+            for (uint64_t i = 0; i < kPrecreateSlice; i++) {
+                const uint64_t left = precreate_left_.load();
+                if (left == 0) break;
+                if (left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) { precreate_left_.store(0); break; }
+                precreate_left_.store(left - 1);
+            }
+        }
+        q.lock();
+    }
+}
+
+}  // namespace vattn

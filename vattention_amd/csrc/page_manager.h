@@ -1,0 +1,127 @@
+// MI355X-native vAttention page manager — bookkeeping core + mapper thread.
+// No torch, no HIP in this header: the physical backend is a vattn_backend_ops table.
+//
+// Bookkeeping follows the reference state machine line by line where it is observable
+// (/root/reference/vattention/vattention.cu:189-609, utils.h:83-228, mux.h:1-85); what is new is
+// the execution model: every bookkeeping routine only *plans* physical operations (PhysOp); the
+// plan is then executed either before the API call returns (what the current step needs) or by a
+// single mapper thread (look-ahead / reclamation), see include/vattn.h.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/vattn.h"
+
+namespace vattn {
+
+struct PhysOp {
+    uint8_t kind;        // 0 = map page at (tensor, offset), 1 = unmap (tensor, offset)
+    uint32_t tensor;
+    uint32_t page;       // physical page id (index into handles_), map only
+    uint64_t offset;     // byte offset inside the tensor's virtual range
+};
+
+class PageManager {
+public:
+    PageManager(const vattn_config& cfg, const vattn_backend_ops& be);
+    ~PageManager();
+
+    int init();                                   // reserve virtual ranges, start the mapper
+    int num_tensors() const { return (int)bases_.size(); }
+    uint64_t tensor_base(int i) const { return bases_[i]; }
+    void layout(vattn_layout* out) const;
+
+    int64_t reserve_physical_pages(uint64_t free_memory);
+    int step(const uint64_t* lens, uint32_t n, bool eager_reclaim);
+    int step_async(const uint64_t* lens, uint32_t n);
+    int wait();
+    int alloc_new_batch_idx(uint64_t seqlen);
+    int free_batch_idx(int slot);
+    uint64_t num_free_kvblocks();
+    int set_deferred_reclamation(bool on);
+    int set_verbose(bool on);
+    int map_common_pages(uint64_t num_tokens);
+    int show_kvcache_config();
+    int show_allocator_state();
+    int cleanup();
+
+    int64_t state_dump(uint64_t* out, uint64_t cap);
+    int64_t pagemap_dump(uint64_t* out, uint64_t cap_rows);
+    void stats(vattn_stats* out);
+    const char* last_error() const { return last_error_.c_str(); }
+
+private:
+    // ---- configuration (vattention.cu:38-74) ----
+    vattn_config cfg_;
+    vattn_backend_ops be_;
+    uint64_t tokens_per_page_ = 0, virt_per_req_ = 0, max_pages_per_req_ = 0, virt_total_ = 0;
+    uint64_t row_bytes_ = 0;
+    bool cleaned_ = false, inited_ = false;
+
+    // ---- bookkeeping state (utils.h:12-81) ----
+    std::vector<uint64_t> mapped_pages_, lens_;
+    std::vector<uint32_t> pool_;                                  // LIFO of page ids
+    std::map<std::tuple<uint64_t, uint64_t, uint64_t>, std::pair<uint32_t, uint32_t>> pagemap_;
+    bool deferred_reclaim_ = true, verbose_ = false;
+    uint64_t num_pages_ = 0;                                      // page ids handed out so far
+    std::mutex state_mu_;
+    std::vector<PhysOp> plan_;
+    std::string last_error_;
+
+    // ---- helpers mirrored from utils.h ----
+    uint64_t tokens_to_pages(uint64_t n) const { return (n + tokens_per_page_ - 1) / tokens_per_page_; }
+    bool active(int r) const { return lens_[r] != 0; }
+    uint64_t pages_to_kvblocks(uint64_t pages) const { return cfg_.megacache ? pages / 2 : pages / (2ull * cfg_.num_layers); }
+    bool kvblocks_available(uint64_t n) const { return pages_to_kvblocks(pool_.size()) >= n; }
+    uint64_t need_new_page_async(int r, uint64_t eager) const;
+    uint32_t k_tensor(uint32_t layer) const { return cfg_.megacache ? 0 : layer; }
+    uint32_t v_tensor(uint32_t layer) const { return cfg_.megacache ? 1 : cfg_.num_layers + layer; }
+
+    // ---- planners (each mirrors one reference routine) ----
+    int plan_map_pair(int r, uint32_t layer, uint64_t off);
+    void plan_unmap_pair(int r, uint32_t layer, uint64_t off);
+    void unmap_req_page_one(int r);
+    void release_some(int r, uint64_t retain);
+    int grow(int r, uint64_t nblocks, bool sync);
+    void reclaim_on_demand(uint64_t nblocks);
+    void do_reclaim_pages();
+    int map_pages_for_curr_step(int r, uint64_t seq_len);
+    void background_management();
+    void log(const std::string& s) const;
+    int fail(int code, const std::string& msg);
+
+    // ---- executor ----
+    std::vector<uint64_t> bases_;
+    std::vector<uint64_t> handles_;              // page id -> backend handle (0 = not created yet)
+    std::vector<uint8_t> created_;
+    std::atomic<uint64_t> precreate_left_{0};   // ids [0, precreate_left_) still to be looked at, top down
+    std::atomic<uint64_t> join_wait_ns_{0};
+    std::mutex exec_mu_;                         // serialises driver calls
+    std::mutex q_mu_;
+    std::condition_variable q_cv_, done_cv_;
+    std::deque<std::vector<PhysOp>> queue_;
+    uint64_t inflight_ = 0;
+    bool stop_ = false;
+    std::thread mapper_;
+    int async_error_ = 0;
+    std::string async_error_msg_;
+    vattn_stats st_{};
+
+    int flush_sync();
+    void flush_async();
+    int execute(const std::vector<PhysOp>& ops, bool is_async);
+    int ensure_created(uint32_t page);
+    void mapper_main();
+    int wait_locked_free();
+};
+
+}  // namespace vattn
