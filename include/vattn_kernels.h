@@ -1,0 +1,94 @@
+/*
+ * vattn_kernels.h — C ABI of the gfx950 attention / KV-append kernels in libvattn_amd.so.
+ *
+ * These entry points are what the reference's FFI for this path binds:
+ *   - vattn_flash_attn_with_kvcache  replaces flash_attn_cuda.fwd_kvcache
+ *       (call sites /root/reference/sarathi-lean/sarathi/model_executor/attention/
+ *        vattention_flashattention_wrapper.py:159-166 (prefill) and :194-205 (decode);
+ *        semantics /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291,
+ *        argument rules /root/reference/pod_attn/pod_attn/flash_api.cpp:1291-1578;
+ *        the parameter block is the plain-C analogue of Flash_fwd_params,
+ *        /root/reference/pod_attn/pod_attn/flash.h:24-154)
+ *   - vattn_cache_flat               replaces sarathi.cache_ops.cache_flat
+ *       (/root/reference/sarathi-lean/csrc/cache_kernels.cu:482-570, cache.cpp:40-46)
+ *
+ * All pointers are DEVICE pointers; strides are in ELEMENTS; `stream` is a hipStream_t.
+ * Every function returns 0 on success, a negative VATTN_K_* code otherwise, and never touches
+ * key/value rows at or beyond a sequence's visible length (those virtual pages may be unmapped).
+ */
+#ifndef VATTN_KERNELS_H_
+#define VATTN_KERNELS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VATTN_K_OK 0
+#define VATTN_K_ERR_UNSUPPORTED (-10)   /* dtype / head_dim / layout not supported */
+#define VATTN_K_ERR_INVALID (-11)       /* argument rule violated (message via vattn_kernels_last_error) */
+#define VATTN_K_ERR_LAUNCH (-12)        /* HIP launch failure */
+
+#define VATTN_DTYPE_F16 0
+#define VATTN_DTYPE_BF16 1
+
+typedef struct vattn_attn_params {
+    /* q / out: [b, seqlen_q, h, d] */
+    const void* q;
+    void* out;
+    int64_t q_batch_stride, q_row_stride, q_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+    /* caches: [batch_cache, seqlen_k, h_k, d]; last dim contiguous, other strides arbitrary
+     * (the decode call passes a [:, :max_cache_len] strided view) */
+    void* k_cache;
+    void* v_cache;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    /* optional new keys/values [b, seqlen_knew, h_k, d], appended at row cache_seqlens[b] */
+    const void* k_new;
+    const void* v_new;
+    int64_t knew_batch_stride, knew_row_stride, knew_head_stride;
+    int64_t vnew_batch_stride, vnew_row_stride, vnew_head_stride;
+    const int32_t* cache_seqlens;     /* int32[b] on device, or NULL: every sequence uses seqlen_k      */
+    const int32_t* cache_batch_idx;   /* int32[b] on device, or NULL: identity                          */
+    float* softmax_lse;               /* optional float[b, h, seqlen_q] (natural log), or NULL          */
+    /* split-KV workspace (decode form); sized by vattn_attn_workspace_bytes, may be NULL if 0 */
+    void* workspace;
+    int32_t b, seqlen_q, seqlen_k, seqlen_knew, h, h_k, d;
+    int32_t is_causal;                /* bottom-right aligned; ignored when seqlen_q == 1               */
+    int32_t dtype;                    /* VATTN_DTYPE_*                                                  */
+    int32_t num_splits;               /* 0 = heuristic                                                  */
+    float softmax_scale;
+    int32_t variant;                  /* 0 = default; debug variants select alternative operand paths   */
+} vattn_attn_params;
+
+/* Bytes of split-KV workspace the call will need (0 for the prefill form). */
+size_t vattn_attn_workspace_bytes(const vattn_attn_params* p);
+
+/* flash_attn_with_kvcache: appends k_new/v_new (if given) and attends; prefill form (seqlen_q > 1,
+ * causal chunk against the growing cache) and decode form (seqlen_q == 1, split-KV + combine). */
+int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream);
+
+/* cache_flat: k_cache[t*k_cache_stride + i] = key[t*key_stride + i], same for value,
+ * t < num_tokens, i < num_heads*head_size (cache_kernels.cu:483-520). */
+int vattn_cache_flat(const void* key, const void* value, void* k_cache, void* v_cache,
+                     int64_t num_tokens, int32_t num_heads, int32_t head_size,
+                     int64_t key_stride, int64_t value_stride, int64_t k_cache_stride, int64_t v_cache_stride,
+                     int32_t itemsize, void* stream);
+
+/* Device-side self-tests of the hardware layout assumptions (MFMA fragment maps, LDS transpose
+ * read); 0 = all assumptions hold.  Used by tests/test_hw_layouts.py on the GPU box. */
+int vattn_selftest_layouts(void* stream, int32_t* detail_out /* int32[8] host buffer */);
+
+/* Times `iters` launches of the kernel family last used by vattn_flash_attn_with_kvcache with HIP
+ * events on `stream`; returns average milliseconds per call (negative on error). */
+float vattn_time_attn(const vattn_attn_params* p, void* stream, int32_t warmup, int32_t iters);
+
+const char* vattn_kernels_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VATTN_KERNELS_H_ */

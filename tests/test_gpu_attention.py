@@ -1,0 +1,202 @@
+"""GPU parity: HIP kernels (through the C ABI, via the flash_attn / cache_ops drop-ins) vs the CPU oracle.
+
+Tolerance: fp16/bf16 I/O compared with the float64 oracle at atol = rtol = 2e-3
+(fp16) / 1.6e-2 (bf16, 8 mantissa bits), AND the kernel's max error must stay within 2x the error
+of the reference-numerics CPU run (fp32 accumulate, P rounded to the I/O dtype) + 1e-5.
+"""
+import pytest
+import torch
+
+from oracle.attn import cache_flat_ref, flash_attn_with_kvcache_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _tol(dtype):
+    return (2e-3, 2e-3) if dtype == torch.float16 else (1.6e-2, 1.6e-2)
+
+
+def _check(out_gpu, ref64, ref32, dtype, what):
+    atol, rtol = _tol(dtype)
+    got = out_gpu.double().cpu()
+    err = (got - ref64).abs()
+    bound = atol + rtol * ref64.abs()
+    assert bool((err <= bound).all()), "%s: max err %.3e (allowed %.3e)" % (what, err.max().item(), bound.max().item())
+    e_ref = (ref32.double() - ref64).abs().max().item()
+    assert err.max().item() <= 2 * e_ref + 1e-5 + (0 if dtype == torch.float16 else 4e-3), \
+        "%s: kernel err %.3e vs reference-numerics err %.3e" % (what, err.max().item(), e_ref)
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["tr_read", "plain_read"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("B,G,Hkv,lens", [
+    (1, 8, 4, [777]),                    # Yi-6B group size
+    (3, 4, 2, [1, 31, 1025]),            # Llama-3-8B group size; tiny and tile-boundary contexts
+    (2, 7, 1, [5000, 63]),               # Yi-34B TP2 group size 7 (not a power of two)
+    (4, 1, 2, [300, 2, 4095, 64]),       # MHA
+])
+def test_decode_parity(B, G, Hkv, lens, dtype, variant):
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(1234)
+    Hq, D, ctx, slots = G * Hkv, 128, 6000, 7
+    kc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    vc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    q = torch.randn(B, 1, Hq, D).to(dtype)
+    kn = torch.randn(B, 1, Hkv, D).to(dtype)
+    vn = torch.randn(B, 1, Hkv, D).to(dtype)
+    idx = torch.tensor([5, 0, 3, 6][:B], dtype=torch.int32)
+    cl = torch.tensor(lens, dtype=torch.int32)
+    max_len = max(lens) + 1
+    kc1, vc1 = kc.clone(), vc.clone()
+    ref64 = flash_attn_with_kvcache_ref(q, kc1[:, :max_len], vc1[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+    kc2, vc2 = kc.clone(), vc.clone()
+    ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :max_len], vc2[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
+    kg, vg = kc.to(DEV), vc.to(DEV)
+    for splits in (0, 1, 3):
+        kgi, vgi = kg.clone(), vg.clone()
+        out = flash_attn_with_kvcache(q.to(DEV), kgi[:, :max_len], vgi[:, :max_len], kn.to(DEV), vn.to(DEV),
+                                      cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True,
+                                      num_splits=splits, _variant=variant)
+        torch.cuda.synchronize()
+        _check(out, ref64, ref32, dtype, "decode splits=%d" % splits)
+        assert torch.equal(kgi.cpu(), kc1) and torch.equal(vgi.cpu(), vc1)     # in-place append, bit-exact, nothing else touched
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["tr_read", "plain_read"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("n,c,Hq,Hkv", [
+    (128, 0, 8, 2), (1, 5, 4, 4), (200, 0, 4, 1), (77, 333, 8, 4), (512, 1000, 4, 2), (130, 62, 2, 2), (64, 64, 4, 2),
+])
+def test_prefill_chunk_parity(n, c, Hq, Hkv, dtype, variant):
+    """Wrapper's prefill form (:151-166): cache_flat at offset c, then causal attention with cache_seqlens=[c+n]."""
+    from vattention_amd.cache_ops import cache_flat
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(n * 7 + c)
+    D, ctx = 128, 1600
+    kc = torch.randn(3, ctx, Hkv, D).to(dtype)       # pre-existing cache rows [0, c)
+    vc = torch.randn(3, ctx, Hkv, D).to(dtype)
+    q = torch.randn(1, n, Hq, D).to(dtype)
+    k = torch.randn(n, Hkv, D).to(dtype)
+    v = torch.randn(n, Hkv, D).to(dtype)
+    slot = 1
+    cl = torch.tensor([c + n], dtype=torch.int32)
+    kc1, vc1 = kc.clone(), vc.clone()
+    cache_flat_ref(k, v, kc1[slot][c:], vc1[slot][c:])
+    if n == 1:
+        pytest.skip("seqlen_q == 1 takes the decode form; covered by test_decode_parity")
+    ref64 = flash_attn_with_kvcache_ref(q, kc1[slot:slot + 1], vc1[slot:slot + 1], cache_seqlens=cl, causal=True)
+    ref32 = flash_attn_with_kvcache_ref(q, kc1[slot:slot + 1], vc1[slot:slot + 1], cache_seqlens=cl, causal=True, math="f32")
+    kg, vg = kc.to(DEV), vc.to(DEV)
+    key_cache = kg[slot].reshape(1, -1, Hkv, D)
+    value_cache = vg[slot].reshape(1, -1, Hkv, D)
+    cache_flat(k.to(DEV), v.to(DEV), key_cache.squeeze(0)[c:], value_cache.squeeze(0)[c:], "auto")
+    out = flash_attn_with_kvcache(q.to(DEV), key_cache, value_cache, cache_seqlens=cl.to(DEV), causal=True, _variant=variant)
+    torch.cuda.synchronize()
+    assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)           # cache_flat bit-exact
+    _check(out, ref64, ref32, dtype, "prefill n=%d c=%d" % (n, c))
+
+
+def test_prefill_non_causal_and_seqlen_q_gt_k():
+    from vattention_amd.flash_attn import flash_attn_func, flash_attn_with_kvcache
+    torch.manual_seed(5)
+    q = torch.randn(2, 150, 4, 128).half()
+    k = torch.randn(2, 90, 2, 128).half()
+    v = torch.randn(2, 90, 2, 128).half()
+    for causal in (False, True):                       # causal with Sq > Sk: leading rows fully masked -> 0
+        ref64 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=90, causal=causal)
+        ref32 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=90, causal=causal, math="f32")
+        out = flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal)
+        torch.cuda.synchronize()
+        _check(out, ref64, ref32, torch.float16, "flash_attn_func causal=%s" % causal)
+        if causal:
+            assert torch.all(out[:, :60] == 0)
+
+
+def test_online_softmax_rescale_is_exercised():
+    """cdna guide rule 26: force the running max to jump at a late tile (spiked key) and check against fp64."""
+    from vattention_amd.flash_attn import flash_attn_func
+    torch.manual_seed(9)
+    q = torch.randn(1, 256, 2, 128).half()
+    k = (torch.randn(1, 700, 2, 128) * 0.3).half()
+    v = torch.randn(1, 700, 2, 128).half()
+    k[0, 650] = (q[0, 255, 0] * 0.5).half()            # huge score for the last query at key 650 (tile 10)
+    k[0, 100] = (q[0, 200, 1] * 0.5).half()
+    ref64 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=700, causal=True)
+    ref32 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=700, causal=True, math="f32")
+    out = flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
+    torch.cuda.synchronize()
+    _check(out, ref64, ref32, torch.float16, "spiked keys")
+
+
+def test_cache_flat_edge_cases():
+    from vattention_amd.cache_ops import cache_flat
+    k = torch.randn(0, 2, 128).half().to(DEV)
+    kc = torch.zeros(4, 2, 128).half().to(DEV)
+    cache_flat(k, k, kc, kc.clone(), "auto")            # empty input: no-op
+    with pytest.raises(RuntimeError, match="Unsupported data type"):
+        cache_flat(k, k, kc, kc, "fp8")
+    # non-16-byte rows take the scalar kernel: head_size 20 -> 40-byte rows... kvh*hs*2 = 120 bytes
+    k2 = torch.randn(9, 3, 20).half()
+    v2 = torch.randn(9, 3, 20).half()
+    kc2 = torch.zeros(12, 3, 20).half().to(DEV)
+    vc2 = torch.zeros(12, 3, 20).half().to(DEV)
+    cache_flat(k2.to(DEV), v2.to(DEV), kc2[2:], vc2[2:], "auto")
+    torch.cuda.synchronize()
+    assert torch.equal(kc2[2:11].cpu(), k2) and torch.equal(vc2[2:11].cpu(), v2) and torch.all(kc2[:2] == 0) and torch.all(kc2[11:] == 0)
+
+
+def test_attention_on_virtual_tensors_never_touches_unmapped_pages():
+    """End to end on vAttention tensors: only the prefix of each slot is mapped; the decode call passes the
+    [:, :max_cache_len] view over ALL slots (wrapper :196-197).  A read past a mapped prefix would fault."""
+    from vattention_amd import vattention
+    from vattention_amd.cache_ops import cache_flat
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.zeros(1, device=DEV)
+    mn, _ = vattention.granularity(0)
+    page = 64 << 10 if (64 << 10) % mn == 0 else 2 << 20
+    L, kvh, Hq, D, B, ctx = 1, 2, 8, 128, 8, 8192
+    ts = vattention.init_kvcache(L, kvh, D, B, ctx, 0, torch.float16, page, False)
+    try:
+        K, V = ts[0], ts[1]
+        vattention.reserve_physical_pages(512 * page)
+        torch.manual_seed(3)
+        lens = [0] * B
+        seqs = {}
+        for n in (700, 33, 2500):
+            s = vattention.alloc_new_batch_idx(n)
+            lens[s] = n
+            seqs[s] = n
+        vattention.step_async(lens)
+        host = {}
+        for s, n in seqs.items():
+            k = torch.randn(n, kvh, D).half()
+            v = torch.randn(n, kvh, D).half()
+            host[s] = (k, v)
+            kc = K[s].reshape(1, -1, kvh, D)
+            vc = V[s].reshape(1, -1, kvh, D)
+            cache_flat(k.to(DEV), v.to(DEV), kc.squeeze(0)[0:], vc.squeeze(0)[0:], "auto")
+            q = torch.randn(1, n, Hq, D).half()
+            out = flash_attn_with_kvcache(q.to(DEV), kc, vc, cache_seqlens=torch.tensor([n], dtype=torch.int32, device=DEV), causal=True)
+            ref = flash_attn_with_kvcache_ref(q, k.unsqueeze(0).clone(), v.unsqueeze(0).clone(), cache_seqlens=n, causal=True)
+            assert (out.double().cpu() - ref).abs().max() < 4e-3
+        # one decode step for all three sequences
+        slots = sorted(seqs)
+        for s in slots:
+            lens[s] += 1
+        vattention.step_async(lens)
+        q = torch.randn(len(slots), 1, Hq, D).half()
+        kn = torch.randn(len(slots), 1, kvh, D).half()
+        vn = torch.randn(len(slots), 1, kvh, D).half()
+        cl = torch.tensor([seqs[s] for s in slots], dtype=torch.int32)
+        mx = int(cl.max()) + 1
+        out = flash_attn_with_kvcache(q.to(DEV), K[:, :mx], V[:, :mx], kn.to(DEV), vn.to(DEV), cache_seqlens=cl.to(DEV),
+                                      cache_batch_idx=torch.tensor(slots, dtype=torch.int32, device=DEV), causal=True)
+        torch.cuda.synchronize()
+        for i, s in enumerate(slots):
+            kf = torch.cat([host[s][0], kn[i]], 0).unsqueeze(0)
+            vf = torch.cat([host[s][1], vn[i]], 0).unsqueeze(0)
+            ref = flash_attn_with_kvcache_ref(q[i:i + 1], kf, vf, cache_seqlens=seqs[s] + 1)
+            assert (out[i:i + 1].double().cpu() - ref).abs().max() < 4e-3
+    finally:
+        vattention.cleanup()

@@ -1,0 +1,133 @@
+"""The `fa_vattn` attention backend: mirror of sarathi-lean's VAttentionFlashAttentionWrapper
+(/root/reference/sarathi-lean/sarathi/model_executor/attention/vattention_flashattention_wrapper.py:17-224).
+
+Same interface (init / begin_forward / set_batch_idx / forward / end_forward, is_profiling_iteration),
+same per-iteration dataflow:
+  prefill sequences first — append the chunk's K/V to the sequence's contiguous cache rows
+  (cache_flat) and run causal attention of the chunk against the cache prefix [0, processed+chunk);
+  then ONE batched decode call over the [:, :max_cache_len] view of every slot with the new K/V
+  appended in-kernel at cache_seqlens and the slots selected by cache_batch_idx.
+Both kernels are the gfx950 kernels of libvattn_amd.so.
+
+Differences from the reference, on purpose:
+  * slot indices are kept on the host as well, so selecting a prefill's row-block costs no
+    device->host sync per prefill per layer (SURVEY §3.3 calls the reference's `.item()` there
+    "a reference inefficiency worth not copying");
+  * the decode call never hits the reference's transient "seqlen" error path, so
+    decode rows are always computed.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from ..cache_ops import cache_flat
+from ..flash_attn import flash_attn_with_kvcache
+from .base_attention_wrapper import BaseAttentionWrapper
+from .timers import OperationMetrics
+
+
+class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
+    _inst = None
+
+    def init(self, model_config, parallel_config, block_size: int, device: torch.device):
+        super().init(model_config, parallel_config, block_size, device)
+        self.is_metadata_initialized = False
+        self.is_profiling_iteration = False
+        self._reset()
+
+    def _reset(self):
+        self.prefill_query_lens: List[int] = []
+        self.prefill_cache_lens: List[int] = []
+        self.current_total_len_device_lst: List[torch.Tensor] = []
+        self.decode_cache_lens: Optional[torch.Tensor] = None
+        self.batch_index: Optional[torch.Tensor] = None
+        self.batch_index_gen: Optional[torch.Tensor] = None
+        self._batch_index_host: Optional[List[int]] = None
+        self.max_cache_len = 0
+        self.decode_batch_size = 0
+
+    def get_cache_block(self, num_blocks: int, **kwargs):
+        return None          # vAttention has no block tables
+
+    def begin_forward(self, seq_metadata_list) -> None:
+        self.is_profiling_iteration = False
+        self.is_metadata_initialized = True
+        q_lens, c_lens, totals, dec = [], [], [], []
+        for md in seq_metadata_list:
+            if md.is_prompt:
+                chunk = md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len)
+                done = md.seq.get_num_prompt_tokens_processed()
+                q_lens.append(chunk)
+                c_lens.append(done)
+                totals.append(done + chunk)
+        for md in seq_metadata_list:
+            if not md.is_prompt:
+                dec.append(md.seq.get_len() - 1)
+        self.prefill_query_lens = q_lens
+        self.prefill_cache_lens = c_lens
+        if totals:      # one H2D copy for all prefills, then 1-element views
+            allt = torch.tensor(totals, dtype=torch.int32, device=self.device)
+            self.current_total_len_device_lst = [allt[i:i + 1] for i in range(len(totals))]
+        else:
+            self.current_total_len_device_lst = []
+        if not dec:
+            self.decode_batch_size = 0
+            return
+        self.decode_batch_size = len(dec)
+        self.decode_cache_lens = torch.tensor(dec, dtype=torch.int32, device=self.device)
+        self.max_cache_len = max(dec) + 1
+
+    def end_forward(self):
+        self.is_metadata_initialized = False
+        self._reset()
+
+    def set_batch_idx(self, batch_idx: torch.Tensor, batch_idx_gen: torch.Tensor, batch_idx_host: Optional[List[int]] = None) -> None:
+        self.batch_index = batch_idx.to(torch.int32)
+        self.batch_index_gen = batch_idx_gen.to(torch.int32)
+        # the cache engine passes the host copy it already has; a foreign caller costs one sync per iteration
+        self._batch_index_host = list(batch_idx_host) if batch_idx_host is not None else [int(x) for x in batch_idx.tolist()]
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                kv_cache: Tuple[torch.Tensor, torch.Tensor], softmax_scale: float = 1.0,
+                layer_id: Optional[int] = None) -> torch.Tensor:
+        assert self.is_metadata_initialized, "Metadata is not initialized."
+        if self.is_profiling_iteration:
+            return torch.zeros_like(query)       # memory-profiling pass: no attention (model_runner.py:192-201)
+        Hq, Hkv, D = self.num_q_heads, self.num_kv_heads, self.head_dim
+        k_all, v_all = kv_cache
+        output = torch.empty_like(query)
+        tok = 0
+        for i, (c_len, q_len) in enumerate(zip(self.prefill_cache_lens, self.prefill_query_lens)):
+            slot = self._batch_index_host[i]
+            with self.get_timer(OperationMetrics.ATTN_INPUT_RESHAPE, layer_id):
+                q = query[tok:tok + q_len].view(1, q_len, Hq, D)
+                k = key[tok:tok + q_len].view(q_len, Hkv, D)
+                v = value[tok:tok + q_len].view(q_len, Hkv, D)
+                k_rows = k_all[slot]             # [max_ctx, kvh, D]: the slot's whole (virtual) row-block
+                v_rows = v_all[slot]
+            with self.get_timer(OperationMetrics.ATTN_KV_CACHE_SAVE, layer_id):
+                cache_flat(k, v, k_rows[c_len:], v_rows[c_len:], "auto")
+            with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id):
+                o = flash_attn_with_kvcache(q, k_rows.unsqueeze(0), v_rows.unsqueeze(0),
+                                            cache_seqlens=self.current_total_len_device_lst[i],
+                                            causal=True, softmax_scale=softmax_scale)
+            with self.get_timer(OperationMetrics.ATTN_OUTPUT_RESHAPE, layer_id):
+                output[tok:tok + q_len].copy_(o.view(q_len, Hq * D))
+            tok += q_len
+        if self.decode_batch_size == 0:
+            return output
+        nb = self.decode_batch_size
+        with self.get_timer(OperationMetrics.ATTN_INPUT_RESHAPE, layer_id):
+            dq = query[tok:tok + nb].view(nb, 1, Hq, D)
+            dk = key[tok:tok + nb].view(nb, 1, Hkv, D)
+            dv = value[tok:tok + nb].view(nb, 1, Hkv, D)
+        with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id):
+            o = flash_attn_with_kvcache(dq, k_all[:, :self.max_cache_len], v_all[:, :self.max_cache_len], dk, dv,
+                                        cache_seqlens=self.decode_cache_lens, block_table=None,
+                                        softmax_scale=softmax_scale, causal=True,
+                                        cache_batch_idx=self.batch_index_gen)
+        with self.get_timer(OperationMetrics.ATTN_OUTPUT_RESHAPE, layer_id):
+            output[tok:tok + nb].copy_(o.view(nb, Hq * D))
+        return output

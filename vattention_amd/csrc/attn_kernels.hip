@@ -1,0 +1,872 @@
+// gfx950 (CDNA4) attention kernels over virtually-contiguous KV tensors.
+//
+//   prefill_kernel : chunked causal prefill (seqlen_q > 1).  One workgroup = 4 waves x 32 query rows,
+//                    KV tiles of 64 keys double-buffered in LDS (register-staged global loads issued
+//                    one tile ahead), S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_{f16,bf16},
+//                    softmax entirely in registers (the "swapped QK^T" form: a lane owns one query
+//                    column), K tile XOR-swizzled for conflict-free ds_read_b128, V tile stored as
+//                    [d-block][key][32 d] sub-tiles and consumed through ds_read_b64_tr_b16.
+//   decode_kernel  : seqlen_q == 1, GQA group packed into the MFMA N dimension, split-KV over the
+//                    context, K fragments loaded straight from HBM into MFMA operand registers,
+//                    V through a wave-private LDS transpose stage, fp32 online softmax, in-workgroup
+//                    merge of the 4 waves, LSE-weighted combine across splits (combine_kernel).
+//   cache_flat / append : contiguous KV append (16-byte vector copies).
+//
+// Semantics follow the operator the reference calls (flash_attn_with_kvcache):
+//   /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, flash_api.cpp:1291-1578,
+//   mask.h:164-196 (bottom-right causal), softmax.h:69-157 (fp32 max/sum, exp2, P rounded to the
+//   I/O dtype before PV), flash_fwd_kernel.h:1116-1297 (split combine).
+// Every K/V access is predicated on the sequence's visible length: rows at or beyond it may sit
+// on unmapped virtual pages (SURVEY §7 "never touch unmapped VA").
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/vattn_kernels.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+template <typename T> struct Tr;
+template <> struct Tr<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)x; }
+};
+template <> struct Tr<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ __bf16 cvt(float x) { return (__bf16)x; }
+};
+
+template <typename V8> __device__ __forceinline__ V8 as_v8(uint4 x) {
+    V8 r;
+    __builtin_memcpy(&r, &x, 16);
+    return r;
+}
+template <typename V8> __device__ __forceinline__ V8 join_tr(s16x4 lo, s16x4 hi) {
+    s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    V8 r;
+    __builtin_memcpy(&r, &t, 16);
+    return r;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float xor_shuffle(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// ============================================================================================
+// cache_flat / append
+// ============================================================================================
+
+// One 16-byte chunk per thread; K and V rows copied by the same launch (cache_kernels.cu:483-520).
+__global__ void cache_flat_vec_kernel(const uint4* __restrict__ key, const uint4* __restrict__ value,
+                                      uint4* __restrict__ k_cache, uint4* __restrict__ v_cache,
+                                      int64_t num_tokens, int chunks_per_row, int64_t key_stride, int64_t value_stride,
+                                      int64_t k_cache_stride, int64_t v_cache_stride) {
+    // strides are in 16-byte chunks here
+    const int64_t total = num_tokens * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / chunks_per_row;
+        const int c = (int)(i - t * chunks_per_row);
+        const uint4 kv = key[t * key_stride + c];
+        const uint4 vv = value[t * value_stride + c];
+        k_cache[t * k_cache_stride + c] = kv;
+        v_cache[t * v_cache_stride + c] = vv;
+    }
+}
+
+template <typename E>
+__global__ void cache_flat_scalar_kernel(const E* __restrict__ key, const E* __restrict__ value, E* __restrict__ k_cache,
+                                         E* __restrict__ v_cache, int64_t num_tokens, int n, int64_t key_stride,
+                                         int64_t value_stride, int64_t k_cache_stride, int64_t v_cache_stride) {
+    const int64_t total = num_tokens * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / n;
+        const int c = (int)(i - t * n);
+        k_cache[t * k_cache_stride + c] = key[t * key_stride + c];
+        v_cache[t * v_cache_stride + c] = value[t * value_stride + c];
+    }
+}
+
+// Append of k_new/v_new [b, sn, h_k, d] at row cache_seqlens[b] of slot cache_batch_idx[b]
+// (flash_attn_interface.py:1168-1176).  16-byte chunks; d*itemsize is a multiple of 16.
+__global__ void append_kv_kernel(vattn_attn_params p) {
+    const int b = blockIdx.y;
+    const int slot = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+    const int len = p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k;
+    const int cpr = p.d / 8;                       // 16-byte chunks per head row
+    const int total = p.seqlen_knew * p.h_k * cpr;
+    const uint16_t* kn = (const uint16_t*)p.k_new;
+    const uint16_t* vn = (const uint16_t*)p.v_new;
+    uint16_t* kc = (uint16_t*)p.k_cache;
+    uint16_t* vc = (uint16_t*)p.v_cache;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i % cpr;
+        const int hk = (i / cpr) % p.h_k;
+        const int t = i / (cpr * p.h_k);
+        const int row = len + t;
+        if (row >= p.seqlen_k) continue;           // never write past the cache view
+        const uint4 kv = *(const uint4*)(kn + b * p.knew_batch_stride + t * p.knew_row_stride + hk * p.knew_head_stride + c * 8);
+        const uint4 vv = *(const uint4*)(vn + b * p.vnew_batch_stride + t * p.vnew_row_stride + hk * p.vnew_head_stride + c * 8);
+        *(uint4*)(kc + (int64_t)slot * p.k_batch_stride + (int64_t)row * p.k_row_stride + hk * p.k_head_stride + c * 8) = kv;
+        *(uint4*)(vc + (int64_t)slot * p.v_batch_stride + (int64_t)row * p.v_row_stride + hk * p.v_head_stride + c * 8) = vv;
+    }
+}
+
+// ============================================================================================
+// prefill
+// ============================================================================================
+
+constexpr int PF_WAVES = 4;
+constexpr int PF_BM = 32 * PF_WAVES;   // query rows per workgroup
+constexpr int PF_BN = 64;              // keys per tile
+
+template <int HD> struct PfSmem {
+    static constexpr int kRowBytes = HD * 2;
+    static constexpr int kTileBytes = PF_BN * HD * 2;           // K tile == V tile size
+    static constexpr int kBufBytes = 2 * kTileBytes;            // K + V
+    static constexpr int kTotal = 2 * kBufBytes;                // double buffered
+    static constexpr int kVSubBytes = PF_BN * 64;               // one [64 keys][32 d] sub-tile
+};
+
+template <typename T, int HD, bool USE_TR>
+__global__ __launch_bounds__(64 * PF_WAVES, 2) void prefill_kernel(vattn_attn_params p) {
+    using X = Tr<T>;
+    using V8 = typename X::v8;
+    using S = PfSmem<HD>;
+    constexpr int KK = HD / 16;        // k-steps of the S^T MFMA chain
+    constexpr int DB = HD / 32;        // 32-wide d blocks of O^T
+    constexpr int CPR = HD / 8;        // 16-byte chunks per K/V row
+    constexpr int PASSES = (PF_BN * CPR) / (64 * PF_WAVES);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+
+    const int b = blockIdx.z;
+    const int h = blockIdx.y;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;      // heaviest (last) query blocks first
+    const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
+    const int slot = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+    const int Lk = (p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew;
+    const int Sq = p.seqlen_q;
+    const bool causal = p.is_causal != 0;
+    const int off = Lk - Sq;                                   // bottom-right alignment (mask.h:164-196)
+    const int q_wg0 = qb * PF_BM;
+    const int qw0 = q_wg0 + wave * 32;
+    const int my_q = qw0 + l31;
+
+    int n_end = Lk;
+    if (causal) n_end = min(Lk, q_wg0 + PF_BM + off);          // last key any row of this block may see, +1
+    if (n_end < 0) n_end = 0;
+    const int nt = (n_end + PF_BN - 1) / PF_BN;
+
+    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
+    T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
+    const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
+    const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
+
+    // ---- Q^T fragments (B operand of S^T = K.Q^T): slot (g, j) <-> d = 16*kk + 8*g + j ----
+    V8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+        qf[kk] = as_v8<V8>(v);
+    }
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; i++) o[i] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY;     // running max of raw scores (both half-lanes hold the same value)
+    float l_run = 0.f;           // lane-local partial sum (combined across the half-lanes at the end)
+    const float sc = p.softmax_scale * kLog2e;
+
+    uint4 kreg[PASSES], vreg[PASSES];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int idx = ps * (64 * PF_WAVES) + tid;
+            const int row = idx / CPR;
+            const int c = idx % CPR;
+            const int key = t * PF_BN + row;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (key < Lk) {
+                kv = *(const uint4*)(kbase + (int64_t)key * p.k_row_stride + c * 8);
+                vv = *(const uint4*)(vbase + (int64_t)key * p.v_row_stride + c * 8);
+            }
+            kreg[ps] = kv;
+            vreg[ps] = vv;
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* ksm = smem + buf * S::kBufBytes;
+        char* vsm = ksm + S::kTileBytes;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int idx = ps * (64 * PF_WAVES) + tid;
+            const int row = idx / CPR;
+            const int c = idx % CPR;
+            // K: row-major, 16-byte chunk index XOR-swizzled with (row & 15) -> conflict-free ds_read_b128
+            *(uint4*)(ksm + row * S::kRowBytes + ((c ^ (row & 15)) << 4)) = kreg[ps];
+            // V: [d/32][key][32 d] sub-tiles (64-byte rows) for the transpose reads
+            *(uint4*)(vsm + (c >> 2) * S::kVSubBytes + row * 64 + ((c & 3) << 4)) = vreg[ps];
+        }
+    };
+
+    if (nt > 0) {
+        stage_load(0);
+        stage_write(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nt; t++) {
+        const int buf = t & 1;
+        if (t + 1 < nt) stage_load(t + 1);     // global loads in flight across the whole compute phase
+
+        const int n0 = t * PF_BN;
+        // wave-uniform tile classification
+        const bool wave_dead = causal && (n0 > qw0 + 31 + off);          // every (row, key) pair masked
+        if (!wave_dead) {
+            const char* ksm = smem + buf * S::kBufBytes;
+            const char* vsm = ksm + S::kTileBytes;
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+                s[kb] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const char* krow = ksm + (kb * 32 + l31) * S::kRowBytes;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) {
+                    const V8 a = *(const V8*)(krow + (((2 * kk + g) ^ (l31 & 15)) << 4));
+                    s[kb] = X::mfma32(a, qf[kk], s[kb]);
+                }
+            }
+            // s[kb][r] = S^T[key = n0 + 32*kb + 8*(r>>2) + 4*g + (r&3)][query = my_q]
+            const bool need_mask = (n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off));
+            if (need_mask) {
+                const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;     // last visible key for this query
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int key = n0 + 32 * kb + 8 * (r >> 2) + 4 * g + (r & 3);
+                        if (key > lim) s[kb][r] = -INFINITY;
+                    }
+            }
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, s[kb][r]);
+            mloc = fmaxf(mloc, xor_shuffle(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);
+            const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;   // softmax.h: all-masked rows use 0
+            const float alpha = fast_exp2(m_run * sc - msub);              // m_run = -inf -> 0
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float e = fast_exp2(__builtin_fmaf(s[kb][r], sc, -msub));
+                    s[kb][r] = e;
+                    psum += e;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < DB; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+
+            // O^T += V^T . P^T : B operand slot (g, j) <-> key 16*u + (j<4 ? 4g+j : 8+4g+j-4) = S^T regs 8u..8u+7
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    V8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) pf[j] = X::cvt(s[kb][8 * u + j]);
+                    const int krow0 = kb * 32 + 16 * u;
+#pragma unroll
+                    for (int db = 0; db < DB; db++) {
+                        V8 a;
+                        if constexpr (USE_TR) {
+                            const int i16 = lane & 15, dh = (lane >> 4) & 1;
+                            const char* a1 = vsm + db * S::kVSubBytes + (krow0 + 4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2;
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
+                            a = join_tr<V8>(lo, hi);
+                        } else {
+                            const T* vs = (const T*)(vsm + db * S::kVSubBytes);
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const int key = krow0 + (j < 4 ? 4 * g + j : 8 + 4 * g + (j - 4));
+                                a[j] = vs[key * 32 + l31];
+                            }
+                        }
+                        o[db] = X::mfma32(a, pf, o[db]);
+                    }
+                }
+        }
+        if (t + 1 < nt) stage_write(buf ^ 1);   // buffer last read in iteration t-1; every wave passed that barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
+    const float l_tot = l_run + xor_shuffle(l_run, 32);
+    const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+    if (my_q < Sq) {
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int tq = 0; tq < 4; tq++) {
+                typename X::v4 w;
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][4 * tq + e] * inv);
+                *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+            }
+        if (p.softmax_lse && g == 0) {
+            // natural-log LSE of scale*QK^T; +inf for fully masked rows (flash convention)
+            const float lse = (l_tot == 0.f) ? INFINITY : (m_run * p.softmax_scale + __logf(l_tot));
+            p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
+        }
+    }
+}
+
+// ============================================================================================
+// decode (seqlen_q == 1): split-KV
+// ============================================================================================
+
+constexpr int DC_WAVES = 4;
+constexpr int DC_BN = 32;     // keys per wave tile
+
+// workspace layout: float o_accum[splits][b][h][d]; float lse_accum[splits][b][h]  (log2 domain, scaled)
+template <typename T, int HD, bool USE_TR>
+__global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks) {
+    using X = Tr<T>;
+    using V8 = typename X::v8;
+    constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
+    constexpr int DB = HD / 16;          // 16-wide d blocks of O^T
+    constexpr int CPR = HD / 8;          // 16-byte chunks per row
+    constexpr int VPASS = (DC_BN * CPR) / 64;
+    constexpr int V_WAVE_BYTES = DC_BN * HD * 2;        // [d/16][32 keys][16 d] sub-tiles, 32-byte rows
+    constexpr int VSUB = DC_BN * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15;
+    const int g4 = lane >> 4;
+
+    const int split = blockIdx.x;
+    const int hk = blockIdx.y / gblocks;
+    const int gb = blockIdx.y % gblocks;
+    const int b = blockIdx.z;
+    const int G = p.h / p.h_k;
+    const int slot = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+    const int Lk = (p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew;
+
+    // each sequence divides ITS OWN length evenly over the splits (balanced for ragged batches)
+    const int ntiles_total = (Lk + DC_BN - 1) / DC_BN;
+    const int tiles_per_split = (ntiles_total + num_splits - 1) / num_splits;
+    const int tile_begin = split * tiles_per_split;
+    const int tile_end = min(ntiles_total, tile_begin + tiles_per_split);
+
+    const int row_head = gb * 16 + l15;                 // query head within the group handled by this lane's column
+    const bool row_valid = row_head < G;
+    const int h = hk * G + row_head;
+    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
+    const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
+    const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
+
+    // Q^T fragments (B operand, n = query head): slot (g4, j) <-> d = 32*kk + 8*g4 + j
+    V8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row_valid) v = *(const uint4*)(qptr + 32 * kk + 8 * g4);
+        qf[kk] = as_v8<V8>(v);
+    }
+
+    f32x4 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; i++) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.softmax_scale * kLog2e;
+    char* vsm = smem + wave * V_WAVE_BYTES;
+
+    uint4 kreg[2][KK], vreg[VPASS];
+    auto load_tile = [&](int tile) {
+        const int k0 = tile * DC_BN;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            const int key = k0 + 16 * kb + l15;
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (key < Lk) v = *(const uint4*)(kbase + (int64_t)key * p.k_row_stride + 32 * kk + 8 * g4);
+                kreg[kb][kk] = v;
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < VPASS; ps++) {
+            const int idx = ps * 64 + lane;
+            const int row = idx / CPR, c = idx % CPR;
+            const int key = k0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (key < Lk) v = *(const uint4*)(vbase + (int64_t)key * p.v_row_stride + c * 8);
+            vreg[ps] = v;
+        }
+    };
+
+    int tile = tile_begin + wave;
+    if (tile < tile_end) load_tile(tile);
+    for (; tile < tile_end; tile += DC_WAVES) {
+        const int k0 = tile * DC_BN;
+        // ---- V: registers -> wave-private LDS ([d/16][key][16 d]) ----
+#pragma unroll
+        for (int ps = 0; ps < VPASS; ps++) {
+            const int idx = ps * 64 + lane;
+            const int row = idx / CPR, c = idx % CPR;
+            *(uint4*)(vsm + (c >> 1) * VSUB + row * 32 + ((c & 1) << 4)) = vreg[ps];
+        }
+        // ---- S^T = K.Q^T on the register-resident K fragments ----
+        f32x4 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) s[kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qf[kk], s[kb]);
+        }
+        // prefetch the wave's next tile while this one is being consumed
+        if (tile + DC_WAVES < tile_end) load_tile(tile + DC_WAVES);
+
+        // s[kb][r] = S^T[key = k0 + 16*kb + 4*g4 + r][head row l15]
+        if (k0 + DC_BN > Lk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (k0 + 16 * kb + 4 * g4 + r >= Lk) s[kb][r] = -INFINITY;
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) mloc = fmaxf(mloc, s[kb][r]);
+        mloc = fmaxf(mloc, xor_shuffle(mloc, 16));
+        mloc = fmaxf(mloc, xor_shuffle(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
+        const float alpha = fast_exp2(m_run * sc - msub);
+        m_run = m_new;
+        float psum = 0.f;
+        V8 pf;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = fast_exp2(__builtin_fmaf(s[kb][r], sc, -msub));
+                psum += e;
+                pf[4 * kb + r] = X::cvt(e);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < DB; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[i][r] *= alpha;
+
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- O^T += V^T.P^T : A slot (g4, j) <-> key k0 + (j<4 ? 4*g4 + j : 16 + 4*g4 + j-4) ----
+#pragma unroll
+        for (int db = 0; db < DB; db++) {
+            V8 a;
+            if constexpr (USE_TR) {
+                const char* a1 = vsm + db * VSUB + (4 * g4 + (l15 >> 2)) * 32 + (4 * (l15 & 3)) * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 16 * 32));
+                a = join_tr<V8>(lo, hi);
+            } else {
+                const T* vs = (const T*)(vsm + db * VSUB);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int key = (j < 4) ? 4 * g4 + j : 16 + 4 * g4 + (j - 4);
+                    a[j] = vs[key * 16 + l15];
+                }
+            }
+            o[db] = X::mfma16(a, pf, o[db]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- merge the 4 waves (each holds a partial softmax over its own tiles) ----
+    l_run += xor_shuffle(l_run, 16);
+    l_run += xor_shuffle(l_run, 32);
+    __syncthreads();                                    // all waves are done with their V staging area
+    // o[db][r] = O^T[d = 16*db + 4*g4 + r][head row l15]
+    float* osm = (float*)smem;                          // [wave][16 rows][HD]
+    float* msm = (float*)(smem + DC_WAVES * 16 * HD * 4);   // [wave][16] m, then [wave][16] l
+    float* lsm = msm + DC_WAVES * 16;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) osm[(wave * 16 + l15) * HD + 16 * db + 4 * g4 + r] = o[db][r];
+    if (g4 == 0) {
+        msm[wave * 16 + l15] = m_run;
+        lsm[wave * 16 + l15] = l_run;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * HD; idx += 64 * DC_WAVES) {
+        const int row = idx / HD, d = idx % HD;
+        const int rh = gb * 16 + row;
+        if (rh >= G) continue;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < DC_WAVES; w++) mx = fmaxf(mx, msm[w * 16 + row]);
+        float acc = 0.f, lsum = 0.f;
+        const float mxs = (mx == -INFINITY) ? 0.f : mx * sc;
+#pragma unroll
+        for (int w = 0; w < DC_WAVES; w++) {
+            const float f = fast_exp2(msm[w * 16 + row] * sc - mxs);
+            acc += f * osm[(w * 16 + row) * HD + d];
+            lsum += f * lsm[w * 16 + row];
+        }
+        const int hh = hk * G + rh;
+        const float inv = (lsum == 0.f || lsum != lsum) ? 1.f : 1.f / lsum;
+        if (num_splits == 1) {
+            ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d] = X::cvt(acc * inv);
+            if (p.softmax_lse && d == 0)
+                p.softmax_lse[(int64_t)b * p.h + hh] = (lsum == 0.f) ? INFINITY : (mx * p.softmax_scale + __logf(lsum));
+        } else {
+            float* oacc = (float*)p.workspace;
+            float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
+            const int64_t row_idx = ((int64_t)split * p.b + b) * p.h + hh;
+            oacc[row_idx * HD + d] = acc * inv;
+            if (d == 0) lacc[row_idx] = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
+        }
+    }
+}
+
+// LSE-weighted merge of the split partials (flash_fwd_kernel.h:1116-1297). One block per (b, h).
+template <typename T, int HD>
+__global__ void combine_kernel(vattn_attn_params p, int num_splits) {
+    const int bh = blockIdx.x;                       // b * h + head
+    const int b = bh / p.h, hh = bh % p.h;
+    const float* oacc = (const float*)p.workspace;
+    const float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
+    float mx = -INFINITY;
+    for (int s = 0; s < num_splits; s++) mx = fmaxf(mx, lacc[(int64_t)s * p.b * p.h + bh]);
+    const float mxs = (mx == -INFINITY) ? 0.f : mx;
+    float wsum = 0.f;
+    for (int s = 0; s < num_splits; s++) wsum += fast_exp2(lacc[(int64_t)s * p.b * p.h + bh] - mxs);
+    const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+    for (int d = threadIdx.x; d < HD; d += blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < num_splits; s++) {
+            const float w = fast_exp2(lacc[(int64_t)s * p.b * p.h + bh] - mxs);
+            if (w != 0.f) acc += w * oacc[((int64_t)s * p.b * p.h + bh) * HD + d];
+        }
+        ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d] = Tr<T>::cvt(acc * inv);
+    }
+    if (p.softmax_lse && threadIdx.x == 0)
+        p.softmax_lse[bh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+}
+
+// ============================================================================================
+// hardware-layout self test
+// ============================================================================================
+
+// Checks, against plain integer arithmetic, the three layout facts the kernels rely on:
+//  [0] 32x32x16 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+//  [1] 16x16x32 C/D map: col = lane&15, row = 4*(lane>>4) + r
+//  [2] ds_read_b64_tr_b16: lane i of a 16-lane group receives element (i&3) of the 8-byte chunks
+//      addressed by lanes 4*j + (i>>2), j = 0..3, of the same group
+//  [3] A/B operands: lane (x = lane&31, g = lane>>5) contributes row/col x with k-slots (g, 0..7) (32x32x16)
+//  [4] same for 16x16x32 with g = lane>>4
+__global__ void selftest_kernel(int* res) {
+    __shared__ __attribute__((aligned(16))) short lds[64 * 4];
+    const int lane = threadIdx.x;
+    // [0],[3]: A = one-hot rows, B = one-hot cols with distinct values -> C[m][n] = sum_k A[m][k]B[k][n]
+    {
+        // A[m][slot] = (m + 1) if slot == (m & 15) else 0 ; B[slot][n] = (n + 1) * 64 + ... keep small ints
+        f16x8 a, bq;
+        const int x = lane & 31, g = lane >> 5;
+        for (int j = 0; j < 8; j++) {
+            const int slot = 8 * g + j;                 // logical k index shared by A and B
+            a[j] = (_Float16)((slot == (x & 15)) ? (float)(x + 1) : 0.f);      // A[m=x][k]
+            bq[j] = (_Float16)((slot == 3) ? 0.f : 0.f);
+        }
+        // B[k][n=x] = 1 for every k -> C[m][n] = sum_k A[m][k] = m + 1 for every n
+        for (int j = 0; j < 8; j++) bq[j] = (_Float16)1.f;
+        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, c, 0, 0, 0);
+        int bad = 0;
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (c[r] != (float)(row + 1)) bad = 1;
+        }
+        // columns: A[m][k] = 1 for all, B[k][n] = (n+1) if k-slot == (n & 15) -> C[m][n] = n + 1
+        for (int j = 0; j < 8; j++) {
+            a[j] = (_Float16)1.f;
+            bq[j] = (_Float16)(((8 * g + j) == (x & 15)) ? (float)(x + 1) : 0.f);
+        }
+        f32x16 c2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, c2, 0, 0, 0);
+        int bad3 = 0;
+        for (int r = 0; r < 16; r++)
+            if (c2[r] != (float)(x + 1)) bad3 = 1;
+        if (bad) atomicOr(&res[0], 1);
+        if (bad3) atomicOr(&res[3], 1);
+    }
+    {
+        f16x8 a, bq;
+        const int x = lane & 15, g = lane >> 4;
+        for (int j = 0; j < 8; j++) {
+            a[j] = (_Float16)(((8 * g + j) == x) ? (float)(x + 1) : 0.f);
+            bq[j] = (_Float16)1.f;
+        }
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c, 0, 0, 0);
+        int bad = 0;
+        for (int r = 0; r < 4; r++)
+            if (c[r] != (float)(4 * g + r + 1)) bad = 1;
+        for (int j = 0; j < 8; j++) {
+            a[j] = (_Float16)1.f;
+            bq[j] = (_Float16)(((8 * g + j) == x) ? (float)(x + 1) : 0.f);
+        }
+        f32x4 c2 = {0.f, 0.f, 0.f, 0.f};
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c2, 0, 0, 0);
+        int bad4 = 0;
+        for (int r = 0; r < 4; r++)
+            if (c2[r] != (float)(x + 1)) bad4 = 1;
+        if (bad) atomicOr(&res[1], 1);
+        if (bad4) atomicOr(&res[4], 1);
+    }
+    {
+        // each lane owns the 8-byte chunk at lds[lane*4 .. lane*4+3]; value encodes (lane, element)
+        for (int e = 0; e < 4; e++) lds[lane * 4 + e] = (short)(lane * 4 + e);
+        __syncthreads();
+        const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, &lds[lane * 4]));
+        const int grp = lane >> 4, i = lane & 15;
+        int bad = 0;
+        for (int j = 0; j < 4; j++) {
+            const int src_lane = grp * 16 + 4 * j + (i >> 2);
+            if (t[j] != (short)(src_lane * 4 + (i & 3))) bad = 1;
+        }
+        if (bad) atomicOr(&res[2], 1);
+    }
+}
+
+// ============================================================================================
+// host side
+// ============================================================================================
+
+thread_local std::string g_err;
+int fail(int code, const char* msg) {
+    g_err = msg;
+    return code;
+}
+
+int pick_splits(const vattn_attn_params* p, int gblocks) {
+    if (p->num_splits > 0) return p->num_splits > 128 ? 128 : p->num_splits;
+    // enough workgroups to cover 256 CUs ~3x; never more splits than 8-tile chunks of the cache view
+    const long wg = (long)p->b * p->h_k * gblocks;
+    const int max_len = p->seqlen_k + p->seqlen_knew;
+    const int tiles = (max_len + DC_BN - 1) / DC_BN;
+    long s = (768 + wg - 1) / wg;
+    const long cap = tiles / 8 > 0 ? tiles / 8 : 1;
+    if (s > cap) s = cap;
+    if (s > 128) s = 128;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
+    (void)time_only_main;
+    const bool use_tr = (p->variant & 1) == 0;
+    if (p->seqlen_q == 1) {
+        const int G = p->h / p->h_k;
+        const int gblocks = (G + 15) / 16;
+        const int splits = pick_splits(p, gblocks);
+        if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
+        dim3 grid(splits, p->h_k * gblocks, p->b), block(64 * DC_WAVES);
+        const size_t smem = (size_t)DC_WAVES * 16 * 128 * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
+        if (use_tr)
+            hipLaunchKernelGGL((decode_kernel<T, 128, true>), grid, block, smem, st, *p, splits, gblocks);
+        else
+            hipLaunchKernelGGL((decode_kernel<T, 128, false>), grid, block, smem, st, *p, splits, gblocks);
+        if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, 128>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
+    } else {
+        const int nqb = (p->seqlen_q + PF_BM - 1) / PF_BM;
+        dim3 grid(nqb, p->h, p->b), block(64 * PF_WAVES);
+        const size_t smem = PfSmem<128>::kTotal;
+        static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
+            hipFuncSetAttribute((const void*)prefill_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+            hipFuncSetAttribute((const void*)prefill_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+            return true;
+        }();
+        (void)attr_once;
+        if (use_tr)
+            hipLaunchKernelGGL((prefill_kernel<T, 128, true>), grid, block, smem, st, *p);
+        else
+            hipLaunchKernelGGL((prefill_kernel<T, 128, false>), grid, block, smem, st, *p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
+    return VATTN_K_OK;
+}
+
+int validate(const vattn_attn_params* p) {
+    if (!p || !p->q || !p->out || !p->k_cache || !p->v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
+    if (p->dtype != VATTN_DTYPE_F16 && p->dtype != VATTN_DTYPE_BF16)
+        return fail(VATTN_K_ERR_UNSUPPORTED, "FlashAttention only support fp16 and bf16 data type");      // flash_api.cpp:1325-1326
+    if (p->d != 128) return fail(VATTN_K_ERR_UNSUPPORTED, "this build supports head dimension 128 only");
+    if (p->b <= 0) return fail(VATTN_K_ERR_INVALID, "batch size must be postive");                       // flash_api.cpp:1353
+    if (p->h_k <= 0 || p->h % p->h_k != 0)
+        return fail(VATTN_K_ERR_INVALID, "Number of heads in key/value must divide number of heads in query");   // :1355
+    if ((p->k_new == nullptr) != (p->v_new == nullptr))
+        return fail(VATTN_K_ERR_INVALID, "If key is supplied, value must also be passed in");            // :1452
+    if (p->k_new && !p->cache_seqlens)
+        return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");        // :1453
+    if (p->seqlen_q <= 0 || p->seqlen_k < 0) return fail(VATTN_K_ERR_INVALID, "bad sequence lengths");
+    // 16-byte vector access requirements
+    const int64_t strides[] = {p->q_batch_stride, p->q_row_stride, p->q_head_stride, p->k_batch_stride, p->k_row_stride,
+                               p->k_head_stride, p->v_batch_stride, p->v_row_stride, p->v_head_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0) return fail(VATTN_K_ERR_UNSUPPORTED, "strides must be multiples of 8 elements (16-byte vector access)");
+    if (((uintptr_t)p->q | (uintptr_t)p->k_cache | (uintptr_t)p->v_cache | (uintptr_t)p->out) & 15)
+        return fail(VATTN_K_ERR_UNSUPPORTED, "tensor base pointers must be 16-byte aligned");
+    if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
+        return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
+    return VATTN_K_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vattn_kernels_last_error(void) { return g_err.c_str(); }
+
+size_t vattn_attn_workspace_bytes(const vattn_attn_params* p) {
+    if (!p || p->seqlen_q != 1 || p->h_k <= 0) return 0;
+    const int G = p->h / p->h_k;
+    const int gblocks = (G + 15) / 16;
+    const int splits = pick_splits(p, gblocks);
+    if (splits <= 1) return 0;
+    return (size_t)splits * p->b * p->h * (p->d + 1) * sizeof(float);
+}
+
+int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
+    int rc = validate(p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->k_new && p->seqlen_knew > 0) {
+        const int total = p->seqlen_knew * p->h_k * (p->d / 8);
+        dim3 grid((total + 255) / 256, p->b), block(256);
+        hipLaunchKernelGGL(append_kv_kernel, grid, block, 0, st, *p);
+    }
+    if (p->dtype == VATTN_DTYPE_F16) return launch_attn_t<_Float16>(p, st, false);
+    return launch_attn_t<__bf16>(p, st, false);
+}
+
+int vattn_cache_flat(const void* key, const void* value, void* k_cache, void* v_cache, int64_t num_tokens,
+                     int32_t num_heads, int32_t head_size, int64_t key_stride, int64_t value_stride,
+                     int64_t k_cache_stride, int64_t v_cache_stride, int32_t itemsize, void* stream) {
+    if (num_tokens <= 0) return VATTN_K_OK;
+    if (!key || !value || !k_cache || !v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)num_heads * head_size;
+    const int64_t row_bytes = n * itemsize;
+    const bool vec = row_bytes % 16 == 0 && (key_stride * itemsize) % 16 == 0 && (value_stride * itemsize) % 16 == 0 &&
+                     (k_cache_stride * itemsize) % 16 == 0 && (v_cache_stride * itemsize) % 16 == 0 &&
+                     ((((uintptr_t)key) | ((uintptr_t)value) | ((uintptr_t)k_cache) | ((uintptr_t)v_cache)) & 15) == 0;
+    if (vec) {
+        const int cpr = (int)(row_bytes / 16);
+        const int64_t total = num_tokens * cpr;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        const int64_t f = 16 / itemsize;
+        hipLaunchKernelGGL(cache_flat_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)key, (const uint4*)value,
+                           (uint4*)k_cache, (uint4*)v_cache, num_tokens, cpr, key_stride / f, value_stride / f,
+                           k_cache_stride / f, v_cache_stride / f);
+    } else {
+        const int64_t total = num_tokens * n;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (itemsize == 2)
+            hipLaunchKernelGGL(cache_flat_scalar_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t*)key,
+                               (const uint16_t*)value, (uint16_t*)k_cache, (uint16_t*)v_cache, num_tokens, (int)n, key_stride,
+                               value_stride, k_cache_stride, v_cache_stride);
+        else if (itemsize == 4)
+            hipLaunchKernelGGL(cache_flat_scalar_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)key,
+                               (const uint32_t*)value, (uint32_t*)k_cache, (uint32_t*)v_cache, num_tokens, (int)n, key_stride,
+                               value_stride, k_cache_stride, v_cache_stride);
+        else
+            return fail(VATTN_K_ERR_UNSUPPORTED, "cache_flat supports 2- and 4-byte element types");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
+    return VATTN_K_OK;
+}
+
+int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
+    hipStream_t st = (hipStream_t)stream;
+    int* d = nullptr;
+    if (hipMalloc(&d, 8 * sizeof(int)) != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed");
+    hipMemsetAsync(d, 0, 8 * sizeof(int), st);
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d);
+    int h[8] = {0};
+    hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
+    int bad = 0;
+    for (int i = 0; i < 8; i++) {
+        if (detail_out) detail_out[i] = h[i];
+        bad |= h[i];
+    }
+    return bad ? fail(VATTN_K_ERR_INVALID, "hardware layout assumption violated") : VATTN_K_OK;
+}
+
+float vattn_time_attn(const vattn_attn_params* p, void* stream, int32_t warmup, int32_t iters) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < warmup; i++)
+        if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < iters; i++)
+        if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ms / (iters > 0 ? iters : 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Drop-in for the part of the `flash_attn` package the reference's vAttention wrappers use:
+`flash_attn_with_kvcache` and `flash_attn_func`
+(/root/reference/sarathi-lean/sarathi/model_executor/attention/vattention_flashattention_wrapper.py:4,159-166,194-205).
+
+Signature and semantics follow /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291;
+the work is done by the gfx950 kernels in libvattn_amd.so through the C ABI
+(include/vattn_kernels.h) on torch's current HIP stream.  Arguments this path never uses (rotary,
+paged block_table, alibi, sliding window, softcap, leftpad) raise NotImplementedError.
+
+Deliberate difference: the reference raises "If key is supplied, it must have seqlen
+<= the seqlen of the KV cache" when the GQA-swapped seqlen_q exceeds the cache view (contexts shorter
+than Hq/Hkv tokens) and its wrapper then silently returns unwritten output; this shim raises that
+message only when the new keys genuinely do not fit, and otherwise always computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Union
+
+import torch
+
+from . import kernels as K
+
+APPEND_ERR = "If key is supplied, it must have seqlen <= the seqlen of the KV cache"
+_workspaces = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _check_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vattention_amd.flash_attn: tensors must live on the GPU (there is no CPU path)")
+
+
+def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None, rotary_sin=None,
+                            cache_seqlens: Optional[Union[int, torch.Tensor]] = None,
+                            cache_batch_idx: Optional[torch.Tensor] = None, cache_leftpad=None, block_table=None,
+                            softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                            rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
+                            _variant=0):
+    if rotary_cos is not None or rotary_sin is not None:
+        raise NotImplementedError("rotary embedding inside flash_attn_with_kvcache is not used by the vAttention path")
+    if block_table is not None:
+        raise NotImplementedError("paged KV (block_table) is what vAttention replaces; not supported")
+    if alibi_slopes is not None or cache_leftpad is not None or tuple(window_size) != (-1, -1) or softcap != 0.0:
+        raise NotImplementedError("alibi / leftpad / sliding window / softcap are not used by the vAttention path")
+    _check_cuda(q, k_cache, v_cache, k, v)
+    assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
+    assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"
+    mc = lambda x: x.contiguous() if x is not None and x.stride(-1) != 1 else x
+    q, k, v = mc(q), mc(k), mc(v)
+    B, Sq, Hq, D = q.shape
+    Bc, Sk, Hkv, Dk = k_cache.shape
+    if k_cache.dtype != q.dtype:
+        raise RuntimeError("query and key must have the same dtype")
+    if v_cache.dtype != q.dtype:
+        raise RuntimeError("query and value must have the same dtype")
+    if softmax_scale is None:
+        softmax_scale = D ** (-0.5)
+    dev = q.device
+    if cache_seqlens is not None and isinstance(cache_seqlens, int):
+        cache_seqlens = torch.full((B,), cache_seqlens, dtype=torch.int32, device=dev)
+    if cache_seqlens is not None:
+        if cache_seqlens.dtype != torch.int32:
+            raise RuntimeError("seqlens_k must have dtype int32")
+        cache_seqlens = cache_seqlens.contiguous()
+        assert cache_seqlens.shape == (B,)
+    if cache_batch_idx is not None:
+        if cache_batch_idx.dtype != torch.int32:
+            raise RuntimeError("cache_batch_idx must have dtype int32")
+        cache_batch_idx = cache_batch_idx.contiguous()
+    elif Bc < B:
+        raise RuntimeError("batch size of the cache is smaller than the batch size of q")
+    Sn = 0
+    if k is not None:
+        if v is None:
+            raise RuntimeError("If key is supplied, value must also be passed in")
+        if cache_seqlens is None:
+            raise RuntimeError("If key is supplied, seqlens_k must also be passed in")
+        Sn = k.shape[1]
+        if Sn > Sk:
+            raise RuntimeError(APPEND_ERR)
+        assert k.shape == (B, Sn, Hkv, D) and v.shape == (B, Sn, Hkv, D)
+    out = torch.empty_like(q)
+    lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev) if return_softmax_lse else None
+
+    p = K.AttnParams()
+    p.q, p.out = q.data_ptr(), out.data_ptr()
+    p.q_batch_stride, p.q_row_stride, p.q_head_stride = q.stride(0), q.stride(1), q.stride(2)
+    p.o_batch_stride, p.o_row_stride, p.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
+    p.k_cache, p.v_cache = k_cache.data_ptr(), v_cache.data_ptr()
+    p.k_batch_stride, p.k_row_stride, p.k_head_stride = k_cache.stride(0), k_cache.stride(1), k_cache.stride(2)
+    p.v_batch_stride, p.v_row_stride, p.v_head_stride = v_cache.stride(0), v_cache.stride(1), v_cache.stride(2)
+    if k is not None:
+        p.k_new, p.v_new = k.data_ptr(), v.data_ptr()
+        p.knew_batch_stride, p.knew_row_stride, p.knew_head_stride = k.stride(0), k.stride(1), k.stride(2)
+        p.vnew_batch_stride, p.vnew_row_stride, p.vnew_head_stride = v.stride(0), v.stride(1), v.stride(2)
+    p.cache_seqlens = cache_seqlens.data_ptr() if cache_seqlens is not None else None
+    p.cache_batch_idx = cache_batch_idx.data_ptr() if cache_batch_idx is not None else None
+    p.softmax_lse = lse.data_ptr() if lse is not None else None
+    p.b, p.seqlen_q, p.seqlen_k, p.seqlen_knew, p.h, p.h_k, p.d = B, Sq, Sk, Sn, Hq, Hkv, D
+    p.is_causal = 1 if causal else 0
+    p.dtype = K.dtype_code(q.dtype)
+    p.num_splits = int(num_splits)
+    p.softmax_scale = float(softmax_scale)
+    p.variant = int(_variant)
+    lib = K.klib()
+    need = lib.vattn_attn_workspace_bytes(C.byref(p))
+    ws = None
+    if need:
+        ws = _workspace(need, dev)
+        p.workspace = ws.data_ptr()
+    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), K.current_stream_ptr(dev))
+    if rc != 0:
+        raise RuntimeError(K.last_error())
+    return (out, lse) if return_softmax_lse else out
+
+
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                    alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """flash_attn_interface.py flash_attn_func (forward only, no dropout): q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D]."""
+    if dropout_p != 0.0 or return_attn_probs:
+        raise NotImplementedError("dropout / attention probabilities are not supported (inference path)")
+    return flash_attn_with_kvcache(q, k, v, softmax_scale=softmax_scale, causal=causal, window_size=window_size,
+                                   softcap=softcap, alibi_slopes=alibi_slopes)

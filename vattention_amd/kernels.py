@@ -1,0 +1,72 @@
+"""ctypes binding of the kernel C ABI (include/vattn_kernels.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", vp), ("out", vp),
+        ("q_batch_stride", i64), ("q_row_stride", i64), ("q_head_stride", i64),
+        ("o_batch_stride", i64), ("o_row_stride", i64), ("o_head_stride", i64),
+        ("k_cache", vp), ("v_cache", vp),
+        ("k_batch_stride", i64), ("k_row_stride", i64), ("k_head_stride", i64),
+        ("v_batch_stride", i64), ("v_row_stride", i64), ("v_head_stride", i64),
+        ("k_new", vp), ("v_new", vp),
+        ("knew_batch_stride", i64), ("knew_row_stride", i64), ("knew_head_stride", i64),
+        ("vnew_batch_stride", i64), ("vnew_row_stride", i64), ("vnew_head_stride", i64),
+        ("cache_seqlens", vp), ("cache_batch_idx", vp), ("softmax_lse", vp), ("workspace", vp),
+        ("b", i32), ("seqlen_q", i32), ("seqlen_k", i32), ("seqlen_knew", i32), ("h", i32), ("h_k", i32), ("d", i32),
+        ("is_causal", i32), ("dtype", i32), ("num_splits", i32), ("softmax_scale", C.c_float), ("variant", i32),
+    ]
+
+
+_bound = False
+
+
+def klib():
+    global _bound
+    lib = L.lib()
+    if not _bound:
+        lib.vattn_attn_workspace_bytes.restype = C.c_size_t
+        lib.vattn_attn_workspace_bytes.argtypes = [C.POINTER(AttnParams)]
+        lib.vattn_flash_attn_with_kvcache.restype = i32
+        lib.vattn_flash_attn_with_kvcache.argtypes = [C.POINTER(AttnParams), vp]
+        lib.vattn_cache_flat.restype = i32
+        lib.vattn_cache_flat.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp]
+        lib.vattn_selftest_layouts.restype = i32
+        lib.vattn_selftest_layouts.argtypes = [vp, C.POINTER(i32)]
+        lib.vattn_time_attn.restype = C.c_float
+        lib.vattn_time_attn.argtypes = [C.POINTER(AttnParams), vp, i32, i32]
+        lib.vattn_kernels_last_error.restype = C.c_char_p
+        _bound = True
+    return lib
+
+
+def last_error() -> str:
+    return klib().vattn_kernels_last_error().decode()
+
+
+def current_stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def selftest_layouts(device=None):
+    detail = (i32 * 8)()
+    rc = klib().vattn_selftest_layouts(current_stream_ptr(device), detail)
+    return rc, list(detail)
+
+
+_DT = {torch.float16: 0, torch.bfloat16: 1}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt not in _DT:
+        raise RuntimeError("FlashAttention only support fp16 and bf16 data type")    # flash_api.cpp:1325-1326
+    return _DT[dt]

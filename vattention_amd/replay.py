@@ -1,0 +1,215 @@
+"""Ray-free replay harness for the hot path: drives vATTNCacheEngine + the fa_vattn wrapper exactly the way
+sarathi-lean's worker does (BaseWorker.execute_model -> cache_engine.step -> per-layer wrapper.forward ->
+on_step_completion; /root/reference/sarathi-lean/sarathi/worker/base_worker.py:173-208,
+model_executor/model_runner.py:227-259) with synthetic q/k/v in place of the transformer body.
+
+The light Sequence / SequenceMetadata / *Config classes expose only what the wrapper and cache engine read
+(/root/reference/sarathi-lean/sarathi/core/datatypes/sequence.py, sarathi/config.py:139-167).
+Workloads restate the reference's run scripts:
+  static trace  scripts/benchmark_e2e_static_trace.py:6-57 — all requests at t=0, equal lengths, P:D ratio,
+                vLLM scheduler: whole prompts, prefills prioritised, decode batches up to max_batch_size.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+# per-GPU shapes: (num_layers, num_q_heads, num_kv_heads, head_size)  SURVEY §8
+MODELS = {
+    "yi-6b": (32, 32, 4, 128),
+    "llama-3-8b": (32, 32, 8, 128),
+    "yi-34b": (60, 56, 8, 128),
+    "llama-3-70b": (80, 64, 8, 128),
+}
+
+
+@dataclass
+class ParallelConfig:
+    tensor_parallel_size: int = 1
+    pipeline_parallel_size: int = 1
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    dtype: torch.dtype = torch.float16
+    max_model_len: int = 32768
+    attention_backend: str = "fa_vattn"
+    num_layers: int = 32
+    num_q_heads: int = 32
+    num_kv_heads: int = 4
+    head_size: int = 128
+
+    @classmethod
+    def named(cls, name: str, **kw):
+        L, hq, hkv, d = MODELS[name]
+        return cls(name=name, num_layers=L, num_q_heads=hq, num_kv_heads=hkv, head_size=d, **kw)
+
+    def get_num_q_heads(self, pc):
+        return self.num_q_heads // pc.tensor_parallel_size
+
+    def get_num_kv_heads(self, pc):        # config.py:139-167: KV heads divided per TP rank (at least 1)
+        return max(1, self.num_kv_heads // pc.tensor_parallel_size)
+
+    def get_head_size(self):
+        return self.head_size
+
+    def get_num_layers(self, pc):
+        return self.num_layers // pc.pipeline_parallel_size
+
+
+@dataclass
+class CacheConfig:
+    page_size: int
+    max_batch_size: int
+    memory_for_gpu: int
+    block_size: Optional[int] = None
+    num_gpu_blocks: Optional[int] = None
+
+
+class Sequence:
+    def __init__(self, seq_id: int, prompt_len: int, total_len: int):
+        self.seq_id, self.prompt_len, self.total_len = seq_id, prompt_len, total_len
+        self.prompt_processed = 0
+        self.output_len = 0
+
+    def get_next_prompt_chunk_len(self, chunk_size: int) -> int:
+        return min(chunk_size, self.prompt_len - self.prompt_processed)
+
+    def get_num_prompt_tokens_processed(self) -> int:
+        return self.prompt_processed
+
+    def get_len(self) -> int:
+        return self.prompt_len + self.output_len
+
+    def is_finished(self) -> bool:
+        return self.get_len() >= self.total_len
+
+    @property
+    def prompt_done(self) -> bool:
+        return self.prompt_processed >= self.prompt_len
+
+
+@dataclass
+class SequenceMetadata:
+    seq: Sequence
+    prompt_chunk_len: int
+    is_prompt: bool
+
+
+@dataclass
+class ReplayStats:
+    iterations: int = 0
+    prefill_tokens: int = 0
+    decode_tokens: int = 0
+    kv_util_samples: List[float] = field(default_factory=list)     # live-token bytes / mapped bytes
+    mapped_over_reserved: List[float] = field(default_factory=list)
+
+
+class HotPathRunner:
+    """Owns the cache engine + wrapper for one GPU and replays scheduler iterations."""
+
+    def __init__(self, model: ModelConfig, parallel: ParallelConfig, cache: CacheConfig, device="cuda:0", seed=42):
+        from .attention import get_attention_wrapper, set_attention_backend
+        from .cache_engine import get_cache_engine, get_cache_mem_alloc_backend
+        self.model, self.parallel, self.cache_cfg = model, parallel, cache
+        self.device = torch.device(device)
+        set_attention_backend(model.attention_backend)
+        self.wrapper = get_attention_wrapper()
+        self.wrapper.init(model, parallel, 0, self.device)
+        eng = get_cache_engine(model.attention_backend)
+        self.engine = eng(cache, model, parallel, get_cache_mem_alloc_backend(model.attention_backend))
+        self.Hq = model.get_num_q_heads(parallel)
+        self.Hkv = model.get_num_kv_heads(parallel)
+        self.D = model.get_head_size()
+        self.L = model.get_num_layers(parallel)
+        self.scale = self.D ** -0.5
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        self._gen = g
+        self._bufs = {}
+        self.stats = ReplayStats()
+        self.sample_kv_util = True
+
+    def _qkv(self, T: int):
+        # synthetic N(0,1) activations, one set per token count (the transformer body is out of scope)
+        b = self._bufs.get(T)
+        if b is None:
+            mk = lambda h: torch.randn(T, h * self.D, generator=self._gen, device=self.device, dtype=torch.float32).to(self.model.dtype)
+            b = self._bufs[T] = (mk(self.Hq), mk(self.Hkv), mk(self.Hkv))
+            if len(self._bufs) > 8:
+                self._bufs.pop(next(iter(self._bufs)))
+        return b
+
+    def run_iteration(self, mds: List[SequenceMetadata]) -> torch.Tensor:
+        """One scheduler iteration: prefills must precede decodes in `mds` (seq_manager.on_schedule order)."""
+        T = 0
+        for md in mds:
+            T += md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len) if md.is_prompt else 1
+        q, k, v = self._qkv(T)
+        self.engine.step(mds)
+        self.wrapper.begin_forward(mds)
+        out = None
+        for layer in range(self.L):
+            out = self.wrapper.forward(q, k, v, self.engine.gpu_cache[layer], self.scale, layer)
+        self.wrapper.end_forward()
+        for md in mds:                               # seq_manager.on_step_completed
+            if md.is_prompt:
+                n = md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len)
+                md.seq.prompt_processed += n
+                self.stats.prefill_tokens += n
+                if md.seq.prompt_done:
+                    md.seq.output_len += 1           # the prefill iteration emits the first output token
+                    self.stats.decode_tokens += 1
+            else:
+                md.seq.output_len += 1
+                self.stats.decode_tokens += 1
+        if self.sample_kv_util:
+            self._sample_util()
+        self.engine.on_step_completion(mds)
+        self.stats.iterations += 1
+        return out
+
+    def _sample_util(self):
+        from . import vattention
+        st = vattention.state()
+        lay = vattention.layout()
+        mapped_tokens = sum(st["mapped"]) * lay["tokens_per_page"]
+        live = sum(self.engine.curr_seq_lens)
+        if mapped_tokens:
+            self.stats.kv_util_samples.append(live / mapped_tokens)
+        reserved_tokens = (st["pool"] // (2 * self.L) if not self.engine.vattn_mega_cache else st["pool"] // 2) * lay["tokens_per_page"] + mapped_tokens
+        if reserved_tokens:
+            self.stats.mapped_over_reserved.append(mapped_tokens / reserved_tokens)
+
+    def run_static_trace(self, num_requests: int, total_len: int, pd_ratio: float, chunk_size: Optional[int] = None) -> ReplayStats:
+        """scripts/benchmark_e2e_static_trace.py: decode = ceil(total/(1+P:D)), prefill = total - decode
+        (uniform_request_length_generator.py:12-27).  vLLM scheduler when chunk_size is None (whole prompts),
+        Sarathi-style chunked prefill otherwise (run_figure_6.sh:32-33)."""
+        decode = math.ceil(total_len / (1 + pd_ratio))
+        prefill = total_len - decode
+        waiting = [Sequence(i, prefill, total_len) for i in range(num_requests)]
+        running: List[Sequence] = []
+        B = self.cache_cfg.max_batch_size
+        chunk = chunk_size or prefill
+        while waiting or running:
+            prefilling = [s for s in running if not s.prompt_done]
+            if not prefilling and waiting and len(running) < B:
+                s = waiting.pop(0)
+                running.append(s)
+                prefilling = [s]
+            if prefilling:
+                mds = [SequenceMetadata(prefilling[0], chunk, True)]
+                if chunk_size:                       # Sarathi: piggy-back the running decodes on the prefill chunk
+                    mds += [SequenceMetadata(s, 0, False) for s in running if s.prompt_done]
+            else:
+                mds = [SequenceMetadata(s, 0, False) for s in running]
+            self.run_iteration(mds)
+            running = [s for s in running if not s.is_finished()]
+        return self.stats
+
+    def close(self):
+        self.engine.cleanup_kvcache()

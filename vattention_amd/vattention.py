@@ -1,0 +1,164 @@
+"""Drop-in for the reference's `vattention` Python module.
+
+Same 13 module-level functions on a process-global allocator, same argument order, return types
+and exceptions (/root/reference/vattention/vattention.cu:614-637, apis.h:1-63; callers:
+/root/reference/sarathi-lean/sarathi/worker/cache_engine/vATTN_cache_engine.py:44-191).
+Everything is forwarded to the C ABI of libvattn_amd.so (include/vattn.h): HIP VMM backend,
+mapper thread, no fallback.  `release_kvcache_physical` is called by the reference engine
+(vATTN_cache_engine.py:164-165) but never exported by the reference module; it is a no-op here.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+from .page_manager import PageManager
+
+_pm: Optional[PageManager] = None
+_tensors: List[torch.Tensor] = []
+_verbose = False
+_deferred = True
+_default_flags = 0
+
+
+def _vtensor():
+    from . import _vtensor as ext      # torch binding built by vattention_amd/build.py; fails loudly if absent
+    return ext
+
+
+def _require() -> PageManager:
+    if _pm is None:
+        raise RuntimeError("vattention: init_kvcache() has not been called")
+    return _pm
+
+
+def set_backend_flags(flags: int) -> None:
+    """MI355X extension: VATTN_FLAG_* bits applied by the next init_kvcache (see include/vattn.h)."""
+    global _default_flags
+    _default_flags = int(flags)
+
+
+def init_kvcache(num_layers: int, num_kv_heads: int, head_size: int, max_batch_size: int,
+                 max_context_length: int, device: int, dtype: torch.dtype, page_size: int,
+                 megacache: bool) -> List[torch.Tensor]:
+    """apis.h:3-13.  Returns 2*L virtual tensors [B, max_ctx, kvh, D] (K_0..K_{L-1}, V_0..V_{L-1}) —
+    or two [B, max_ctx, L, kvh, D] tensors with megacache — on cuda:<device>, with NO physical
+    memory behind them yet.  A HIP context must exist (the reference says "initialize PyTorch first")."""
+    global _pm, _tensors
+    if _pm is not None:
+        cleanup()
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    torch.cuda.set_device(device)
+    torch.cuda.current_stream(device)          # make sure the primary context is live on this thread
+    pm = PageManager(num_layers, num_kv_heads, head_size, max_batch_size, max_context_length, itemsize,
+                     device, page_size, bool(megacache), flags=_default_flags, backend=None)
+    pm.set_verbose(_verbose)
+    pm.set_deferred_reclamation(_deferred)
+    ext = _vtensor()
+    shape, stride = pm.shape(), pm.stride()
+    tensors = [ext.tensor_from_va(pm.tensor_base(i), shape, stride, dtype, device) for i in range(pm.num_tensors)]
+    _pm, _tensors = pm, tensors
+    return list(tensors)
+
+
+def reserve_physical_pages(free_memory: int) -> int:
+    """apis.h:23-25: number of physical pages in the pool (multiple of 2*L)."""
+    return _require().reserve_physical_pages(free_memory)
+
+
+def step(seq_lens: List[int], eager_reclaim: bool) -> None:
+    """apis.h:27-29 (the `_sync` backends)."""
+    _require().step(seq_lens, eager_reclaim)
+
+
+def step_async(seq_lens: List[int]) -> None:
+    """apis.h:31-35: maps what this iteration needs before returning, plans and hands the look-ahead
+    mapping to the mapper thread; the GIL is released for the duration of the native call."""
+    _require().step_async(seq_lens)
+
+
+def alloc_new_batch_idx(seqlen: int) -> int:
+    return _require().alloc_new_batch_idx(seqlen)
+
+
+def free_batch_idx(reqId: int) -> None:
+    _require().free_batch_idx(reqId)
+
+
+def num_free_kvblocks() -> int:
+    return _require().num_free_kvblocks()
+
+
+def cleanup() -> None:
+    """apis.h:41-43: joins the mapper, unmaps everything, frees VA and physical handles.  Tensors
+    returned by init_kvcache must not be used afterwards."""
+    global _pm, _tensors
+    if _pm is None:
+        return
+    torch.cuda.synchronize()
+    _pm.cleanup()
+    _pm.close()
+    _pm, _tensors = None, []
+
+
+def set_verbose(val: bool) -> None:
+    global _verbose
+    _verbose = bool(val)
+    if _pm is not None:
+        _pm.set_verbose(_verbose)
+
+
+def set_deferred_reclamation(val: bool) -> None:
+    global _deferred
+    _deferred = bool(val)
+    if _pm is not None:
+        _pm.set_deferred_reclamation(_deferred)
+
+
+def show_kvcache_config() -> None:
+    _require().show_kvcache_config()
+
+
+def show_allocator_state() -> None:
+    _require().show_allocator_state()
+
+
+def map_common_pages(num_tokens: int) -> None:
+    _require().map_common_pages(num_tokens)
+
+
+def release_kvcache_physical() -> None:
+    return None
+
+
+# ---- MI355X extensions (not in the reference surface) ----
+def wait() -> None:
+    """Join outstanding background mapping (the next step()/step_async() does this implicitly)."""
+    _require().wait()
+
+
+def stats() -> dict:
+    return _require().stats()
+
+
+def layout() -> dict:
+    pm = _require()
+    lay = pm.layout
+    return {"shape": pm.shape(), "stride": pm.stride(), "virt_bytes_per_req": int(lay.virt_bytes_per_req),
+            "virt_bytes_total": int(lay.virt_bytes_total), "tokens_per_page": int(lay.tokens_per_page),
+            "max_pages_per_req": int(lay.max_pages_per_req), "page_size": int(lay.page_size)}
+
+
+def state() -> dict:
+    return _require().state()
+
+
+def granularity(device: int = 0):
+    import ctypes as C
+    a, b = C.c_uint64(), C.c_uint64()
+    rc = L.lib().vattn_hip_granularity(device, C.byref(a), C.byref(b))
+    if rc != 0:
+        raise RuntimeError("HIP VMM granularity query failed")
+    return int(a.value), int(b.value)
