@@ -63,6 +63,12 @@ typedef struct vattn_backend_ops {
     int (*set_access)(void* ctx, uint64_t va, uint64_t bytes);
     int (*unmap)(void* ctx, uint64_t va, uint64_t bytes);
     int (*thread_init)(void* ctx);          /* called once on the mapper thread (may be NULL) */
+    /* Make every earlier unmap visible to the GPU (TLB invalidation).  On ROCm 7.2 / gfx950 a kernel keeps
+     * using the OLD translation of a virtual page after hipMemUnmap (+ hipMemMap of another handle at the
+     * same address) until the driver next services an ordinary allocation (tools/remap_probe*.cpp,
+     * profiles/r01_vmm_probe.md); the manager therefore calls this once after every batch that unmapped
+     * anything, before the batch is reported complete.  May be NULL (no-op). */
+    int (*tlb_flush)(void* ctx);
 } vattn_backend_ops;
 
 typedef struct vattn_layout {       /* element-unit description of every returned tensor */
@@ -84,6 +90,7 @@ typedef struct vattn_stats {
     uint64_t join_wait_ns;                /* time step()/step_async() spent waiting for the mapper */
     uint64_t create_ns;
     uint64_t pages_mapped_now;            /* currently mapped physical pages */
+    uint64_t tlb_flushes, tlb_flush_ns;
 } vattn_stats;
 
 typedef struct vattn_handle vattn_t;

@@ -22,10 +22,10 @@ def fake():
 
 
 def fake_counters():
-    buf = (C.c_uint64 * 10)()
+    buf = (C.c_uint64 * 12)()
     fake().vattn_fake_counters(buf)
     names = ["violations", "n_create", "n_map", "n_access", "n_unmap", "n_release", "live_handles", "mapped_pages",
-             "accessible_pages", "reserved_ranges"]
+             "accessible_pages", "reserved_ranges", "n_flush", "stale_vas"]
     return dict(zip(names, [int(x) for x in buf]))
 
 

@@ -19,6 +19,8 @@ struct Fake {
     std::map<uint64_t, std::pair<uint64_t, uint64_t>> mapped;   // va -> (bytes, handle)
     std::set<uint64_t> live_handles;
     std::set<uint64_t> accessible;                          // va of mapped pages with access set
+    std::set<uint64_t> stale;                               // VAs unmapped since the last TLB flush (GPU may still translate them)
+    uint64_t n_flush = 0;
     uint64_t violations = 0, n_create = 0, n_map = 0, n_access = 0, n_unmap = 0, n_release = 0;
     uint64_t fail_create_after = ~0ull;
     int delay_us = 0;
@@ -90,27 +92,36 @@ int f_unmap(void*, uint64_t va, uint64_t bytes) {
     if (it == g.mapped.end() || it->second.first != bytes) { g.violations++; return -1; }
     g.mapped.erase(it);
     g.accessible.erase(va);
+    g.stale.insert(va);
     return 0;
 }
-vattn_backend_ops g_ops = {nullptr, f_gran, f_reserve, f_free_va, f_create, f_release, f_map, f_access, f_unmap, nullptr};
+int f_flush(void*) {
+    std::lock_guard<std::mutex> l(g.mu);
+    g.n_flush++;
+    g.stale.clear();
+    return 0;
+}
+vattn_backend_ops g_ops = {nullptr, f_gran, f_reserve, f_free_va, f_create, f_release, f_map, f_access, f_unmap, nullptr, f_flush};
 }  // namespace
 
 extern "C" {
 const vattn_backend_ops* vattn_fake_backend_ops() { return &g_ops; }
 void vattn_fake_reset(uint64_t min_gran, uint64_t rec_gran) {
     std::lock_guard<std::mutex> l(g.mu);
-    g.reserved.clear(); g.mapped.clear(); g.live_handles.clear(); g.accessible.clear();
+    g.reserved.clear(); g.mapped.clear(); g.live_handles.clear(); g.accessible.clear(); g.stale.clear(); g.n_flush = 0;
     g.violations = g.n_create = g.n_map = g.n_access = g.n_unmap = g.n_release = 0;
     g.next_handle = 1; g.next_va = 0x7f0000000000ull; g.fail_create_after = ~0ull;
     g.min_gran = min_gran; g.rec_gran = rec_gran;
 }
 void vattn_fake_fail_create_after(uint64_t n) { g.fail_create_after = n; }
-// out = [violations, n_create, n_map, n_access, n_unmap, n_release, live_handles, mapped_pages, accessible_pages, reserved_ranges]
+// out = [violations, n_create, n_map, n_access, n_unmap, n_release, live_handles, mapped_pages, accessible_pages, reserved_ranges,
+//        n_flush, stale_vas (unmapped since the last flush)]
 void vattn_fake_counters(uint64_t* out) {
     std::lock_guard<std::mutex> l(g.mu);
     out[0] = g.violations; out[1] = g.n_create; out[2] = g.n_map; out[3] = g.n_access; out[4] = g.n_unmap;
     out[5] = g.n_release; out[6] = g.live_handles.size(); out[7] = g.mapped.size(); out[8] = g.accessible.size();
     out[9] = g.reserved.size();
+    out[10] = g.n_flush; out[11] = g.stale.size();
 }
 // every mapped page as (va, bytes, handle, accessible) rows; returns rows or -needed
 int64_t vattn_fake_mapped(uint64_t* out, uint64_t cap_rows) {

@@ -122,3 +122,43 @@ def test_sync_oom_raises_runtime_error():
     finally:
         vattention.set_verbose(False)
         vattention.cleanup()
+
+
+def test_remap_same_va_is_visible_to_kernels():
+    """ROCm 7.2 / gfx950 keeps stale GPU translations after hipMemUnmap (+ hipMemMap of another handle at
+    the same VA) until the driver services an allocation (tools/remap_probe3/4.cpp).  The manager issues a
+    TLB invalidation after every batch that unmapped something; without it this test reads stale data and
+    writes through stale translations corrupt pages that moved to other slots."""
+    from vattention_amd import vattention
+    torch.zeros(1, device="cuda")
+    for page in (64 << 10, 2 << 20):
+        L, kvh, D, B, ctx = 2, 2, 128, 4, 4096
+        ts = vattention.init_kvcache(L, kvh, D, B, ctx, 0, torch.float16, page, False)
+        try:
+            groups = 4096 * kvh * D * 2 // page          # page-groups for one full-length request
+            vattention.reserve_physical_pages(2 * groups * 2 * L * page)      # room for exactly two full requests
+            n = 4000
+            for it in range(6):
+                # slots 0 and 1 alternately own the physical pages: eager reclaim unmaps the idle slot, LIFO pool
+                # order hands its pages to the other one -> same VAs, different physical pages every iteration
+                a, b_ = it & 1, (it & 1) ^ 1
+                lens = [0] * B
+                lens[a] = n
+                vattention.step(lens, True)
+                va = float(10 + it)
+                for t in ts:
+                    t[a, :n].fill_(va)
+                lens[b_] = n
+                vattention.step(lens, True)
+                vb = float(100 + it)
+                for t in ts:
+                    t[b_, :n].fill_(vb)
+                torch.cuda.synchronize()
+                for t in ts:                              # device-side reads (reduction kernels) of both slots
+                    assert float(t[a, :n].float().min()) == va and float(t[a, :n].float().max()) == va
+                    assert float(t[b_, :n].float().min()) == vb and float(t[b_, :n].float().max()) == vb
+                    assert float(t[a, n - 1, 1, 7].item()) == va          # and through a D2H copy
+                vattention.step([0] * B, True)            # unmap everything
+            assert vattention.stats()["tlb_flushes"] > 0
+        finally:
+            vattention.cleanup()

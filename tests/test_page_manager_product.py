@@ -46,6 +46,7 @@ def test_physical_mappings_track_bookkeeping():
             rb = T.replay(p, [op])
             assert ra == rb
             assert p.mapped_ranges() == o.o.mapped_ranges()
+            assert fake_counters()["stale_vas"] == 0      # every unmap was followed by a TLB invalidation before the call returned / the batch completed
         st = p.pm.stats()
         assert st["access_calls"] <= st["map_calls"]
         assert fake_counters()["violations"] == 0

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Kernel microbenchmark (GPU): times the attention kernels through the C ABI with HIP events
+(vattn_time_attn) on the shapes of BASELINE.md §3 and prints TFLOP/s / GB/s against the rooflines.
+usage: python tools/kbench.py [prefill] [decode] [--variant N]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from vattention_amd import kernels as K  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def params(q, kc, vc, cl, idx=None, kn=None, vn=None, causal=True, splits=0, variant=0, ws=None):
+    out = torch.empty_like(q)
+    p = K.AttnParams()
+    p.q, p.out = q.data_ptr(), out.data_ptr()
+    p.q_batch_stride, p.q_row_stride, p.q_head_stride = q.stride(0), q.stride(1), q.stride(2)
+    p.o_batch_stride, p.o_row_stride, p.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
+    p.k_cache, p.v_cache = kc.data_ptr(), vc.data_ptr()
+    p.k_batch_stride, p.k_row_stride, p.k_head_stride = kc.stride(0), kc.stride(1), kc.stride(2)
+    p.v_batch_stride, p.v_row_stride, p.v_head_stride = vc.stride(0), vc.stride(1), vc.stride(2)
+    if kn is not None:
+        p.k_new, p.v_new = kn.data_ptr(), vn.data_ptr()
+        p.knew_batch_stride, p.knew_row_stride, p.knew_head_stride = kn.stride(0), kn.stride(1), kn.stride(2)
+        p.vnew_batch_stride, p.vnew_row_stride, p.vnew_head_stride = vn.stride(0), vn.stride(1), vn.stride(2)
+        p.seqlen_knew = kn.shape[1]
+    p.cache_seqlens = cl.data_ptr()
+    p.cache_batch_idx = idx.data_ptr() if idx is not None else None
+    p.b, p.seqlen_q, p.h, p.d = q.shape[0], q.shape[1], q.shape[2], q.shape[3]
+    p.seqlen_k, p.h_k = kc.shape[1], kc.shape[2]
+    p.is_causal, p.dtype, p.num_splits, p.softmax_scale, p.variant = int(causal), 0, splits, q.shape[3] ** -0.5, variant
+    keep = [out, q, kc, vc, cl, idx, kn, vn]
+    need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
+    if need:
+        w = torch.empty(need // 4 + 1, dtype=torch.float32, device=DEV)
+        p.workspace = w.data_ptr()
+        keep.append(w)
+    return p, keep
+
+
+def time_ms(p, warmup=2, iters=5):
+    ms = K.klib().vattn_time_attn(C.byref(p), torch.cuda.current_stream().cuda_stream, warmup, iters)
+    if ms < 0:
+        raise RuntimeError(K.last_error())
+    return ms
+
+
+def prefill(variant):
+    print("== prefill (causal chunk n against c cached), fp16, D=128 ==")
+    for name, Hq, Hkv, n, c in [("yi6b whole", 32, 4, 32702, 0), ("yi6b chunk4k@28k", 32, 4, 4096, 28672), ("yi6b chunk4k@0", 32, 4, 4096, 0),
+                                ("llama8b 16k", 32, 8, 16384, 0), ("yi34b/tp2 chunk16k@112k", 28, 4, 16384, 114688),
+                                ("llama70b/tp8 8k", 8, 1, 8192, 0), ("small 2k", 32, 4, 2048, 0)]:
+        if ONLY and ONLY not in name:
+            continue
+        torch.manual_seed(0)
+        q = torch.randn(1, n, Hq, 128, device=DEV, dtype=torch.float16)
+        kc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        vc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
+        p, keep = params(q, kc, vc, cl, variant=variant)
+        ms = time_ms(p, 1, 3 if n > 10000 else 10)
+        fl = 4.0 * Hq * 128 * (n * c + n * (n + 1) / 2)
+        print("  %-26s n=%6d c=%6d Hq=%2d Hkv=%d : %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)" % (name, n, c, Hq, Hkv, ms, fl / ms / 1e9, fl / ms / 1e9 / 25))
+        del keep
+
+
+def decode(variant):
+    print("== decode (Sq=1, append + split-KV + combine), fp16, D=128 ==")
+    for name, Hq, Hkv, B, ctx, slots in [("yi6b B16@32k", 32, 4, 16, 32768, 16), ("yi6b B1@32k", 32, 4, 1, 32768, 4), ("yi6b B4@32k", 32, 4, 4, 32768, 4),
+                                         ("llama8b B64@8k", 32, 8, 64, 8192, 64), ("llama8b B256@2k", 32, 8, 256, 2048, 256),
+                                         ("llama70b/tp8 B64@32k", 8, 1, 64, 32768, 64), ("yi34b/tp2 B8@128k", 28, 4, 8, 131072, 8)]:
+        if ONLY and ONLY not in name:
+            continue
+        torch.manual_seed(0)
+        q = torch.randn(B, 1, Hq, 128, device=DEV, dtype=torch.float16)
+        kc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=torch.float16)
+        vc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=torch.float16)
+        kn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=torch.float16)
+        vn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=torch.float16)
+        cl = torch.full((B,), ctx - 1, dtype=torch.int32, device=DEV)
+        idx = torch.arange(B, dtype=torch.int32, device=DEV) % slots
+        for splits in (0,):
+            p, keep = params(q, kc, vc, cl, idx, kn, vn, splits=splits, variant=variant)
+            ms = time_ms(p, 3, 20)
+            by = B * 2.0 * ctx * Hkv * 128 * 2 + B * Hq * 128 * 2 * 2
+            print("  %-22s B=%3d ctx=%6d Hq=%2d Hkv=%d splits=%d : %8.4f ms  %7.1f GB/s  (%.1f%% of 8000, %.1f%% of 6290)" % (
+                name, B, ctx, Hq, Hkv, splits, ms, by / ms / 1e6, by / ms / 1e6 / 80, by / ms / 1e6 / 62.9))
+        del keep, kc, vc
+
+
+ONLY = None
+
+if __name__ == "__main__":
+    variant = 0
+    if "--only" in sys.argv:
+        ONLY = sys.argv[sys.argv.index("--only") + 1]
+    if "--variant" in sys.argv:
+        variant = int(sys.argv[sys.argv.index("--variant") + 1])
+    what = [a for a in sys.argv[1:] if a in ("prefill", "decode")] or ["prefill", "decode"]
+    torch.zeros(1, device=DEV)
+    if "prefill" in what:
+        for v in ([variant] if "--variant" in sys.argv else [0, 2, 4]):
+            print("-- prefill variant %d (tiling %s) --" % (v, {0: "4 waves x 32 rows", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows"}[(v >> 1) & 3]))
+            prefill(v)
+    if "decode" in what:
+        decode(variant)

@@ -22,10 +22,11 @@ static double now_us() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-__global__ void spin_kernel(float* p, long iters) {
-    float x = p[threadIdx.x];
-    for (long i = 0; i < iters; i++) x = x * 1.0000001f + 1e-9f;
-    p[threadIdx.x] = x;
+__global__ void spin_kernel(float* p, long long cycles) {
+    const long long t0 = wall_clock64();                 // 100 MHz constant clock
+    long long n = 0;
+    while (wall_clock64() - t0 < cycles) n++;
+    p[threadIdx.x] = (float)n;
 }
 __global__ void touch_kernel(char* p, size_t n, char v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
@@ -109,23 +110,35 @@ int main() {
             printf("    read through alias: %d (expect 7)\n", c);
             CK(hipMemUnmap(va + N * page, page));
         } else (void)hipGetLastError();
-        // map while a kernel is running on another stream
-        {
+        // Which VMM calls block on running kernels?  For each call type, with a 0.3 s kernel in flight on
+        // (a) a default-flag stream and (b) a hipStreamNonBlocking stream, time the call and ask whether
+        // the kernel is still running afterwards.
+        if (page == 2097152 || page == 65536) {
             float* buf;
             CK(hipMalloc(&buf, 1024 * sizeof(float)));
-            hipStream_t s;
-            CK(hipStreamCreate(&s));
-            spin_kernel<<<1, 64, 0, s>>>(buf, 200000000L);
-            CK(hipMemUnmap(va, page));
-            double a0 = now_us();
-            CK(hipMemMap(va, page, 0, h[0], 0));
-            CK(hipMemSetAccess(va, page, &ad, 1));
-            double a1 = now_us();
-            hipError_t q = hipStreamQuery(s);
-            printf("  map+access while a kernel runs: %.2f us, kernel still running: %s\n", a1 - a0, q == hipErrorNotReady ? "yes" : "no");
-            (void)hipGetLastError();
-            CK(hipStreamSynchronize(s));
-            CK(hipStreamDestroy(s));
+            for (int nb = 0; nb < 2; nb++) {
+                hipStream_t s;
+                CK(hipStreamCreateWithFlags(&s, nb ? hipStreamNonBlocking : hipStreamDefault));
+                const char* names[4] = {"hipMemCreate", "hipMemMap", "hipMemSetAccess", "hipMemUnmap"};
+                hipMemGenericAllocationHandle_t hx;
+                char* tgt = va + (N + 8) * page;
+                for (int op = 0; op < 4; op++) {
+                    spin_kernel<<<1, 64, 0, s>>>(buf, 30000000LL);      // 0.3 s at 100 MHz
+                    double a0 = now_us();
+                    if (op == 0) CK(hipMemCreate(&hx, page, &ap, 0));
+                    if (op == 1) CK(hipMemMap(tgt, page, 0, hx, 0));
+                    if (op == 2) CK(hipMemSetAccess(tgt, page, &ad, 1));
+                    if (op == 3) CK(hipMemUnmap(tgt, page));
+                    double a1 = now_us();
+                    hipError_t q = hipStreamQuery(s);
+                    (void)hipGetLastError();
+                    CK(hipStreamSynchronize(s));
+                    printf("  [%s stream] %-16s %10.2f us, kernel still running afterwards: %s\n", nb ? "non-blocking" : "default-flag", names[op], a1 - a0,
+                           q == hipErrorNotReady ? "yes" : "NO (call waited for it)");
+                }
+                CK(hipMemRelease(hx));
+                CK(hipStreamDestroy(s));
+            }
             CK(hipFree(buf));
         }
         t0 = now_us();

@@ -70,6 +70,34 @@ template <typename V8> __device__ __forceinline__ V8 join_tr(s16x4 lo, s16x4 hi)
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float xor_shuffle(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// value of lane (l ^ 32): one v_permlane32_swap (VALU) instead of a ds_bpermute round trip through LDS
+__device__ __forceinline__ float swap_halves(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = {lo,lo}, r[1] = {hi,hi}
+    const unsigned other = (threadIdx.x & 32) ? r[0] : r[1];
+    return __builtin_bit_cast(float, other);
+}
+
+// Bounds-checked 16-byte loads through a buffer descriptor: a lane whose byte offset lies at or beyond
+// `bytes` gets zeros WITHOUT touching memory, so rows past the sequence's visible length (possibly on
+// unmapped virtual pages) are never accessed, and the load stream is branch-free (counted vmcnt waits).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    // the byte count comes out of a clamp that instruction selection turns into a VALU v_med3: pull it
+    // back into an SGPR, otherwise every load is wrapped in a waterfall loop
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+// wave-uniform pointer: make the uniformity provable so the descriptor lives in SGPRs (no waterfall loop)
+template <typename P> __device__ __forceinline__ const P* uniform_ptr(const P* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const P*)(((unsigned long long)hi << 32) | lo);
+}
 
 // ============================================================================================
 // cache_flat / append
@@ -134,8 +162,6 @@ __global__ void append_kv_kernel(vattn_attn_params p) {
 // prefill
 // ============================================================================================
 
-constexpr int PF_WAVES = 4;
-constexpr int PF_BM = 32 * PF_WAVES;   // query rows per workgroup
 constexpr int PF_BN = 64;              // keys per tile
 
 template <int HD> struct PfSmem {
@@ -146,15 +172,20 @@ template <int HD> struct PfSmem {
     static constexpr int kVSubBytes = PF_BN * 64;               // one [64 keys][32 d] sub-tile
 };
 
-template <typename T, int HD, bool USE_TR>
-__global__ __launch_bounds__(64 * PF_WAVES, 2) void prefill_kernel(vattn_attn_params p) {
+// WAVES waves per workgroup, each owning QC blocks of 32 query rows (BM = 32*QC*WAVES rows per workgroup).
+// QC = 2 halves the LDS fragment traffic per flop (each K / V^T fragment read feeds two MFMAs) at the price
+// of a 512-register budget (one wave per SIMD).
+template <typename T, int HD, bool USE_TR, int WAVES, int QC>
+__global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC == 2 ? 1 : 2)) void prefill_kernel(vattn_attn_params p) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     using S = PfSmem<HD>;
+    constexpr int NT = 64 * WAVES;
+    constexpr int BM = 32 * QC * WAVES;
     constexpr int KK = HD / 16;        // k-steps of the S^T MFMA chain
     constexpr int DB = HD / 32;        // 32-wide d blocks of O^T
     constexpr int CPR = HD / 8;        // 16-byte chunks per K/V row
-    constexpr int PASSES = (PF_BN * CPR) / (64 * PF_WAVES);
+    constexpr int PASSES = (PF_BN * CPR) / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -167,56 +198,69 @@ __global__ __launch_bounds__(64 * PF_WAVES, 2) void prefill_kernel(vattn_attn_pa
     const int h = blockIdx.y;
     const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;      // heaviest (last) query blocks first
     const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
-    const int slot = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
-    const int Lk = (p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew;
+    // loaded values are wave-uniform; readfirstlane makes that provable (descriptors must live in SGPRs)
+    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
     const int Sq = p.seqlen_q;
     const bool causal = p.is_causal != 0;
     const int off = Lk - Sq;                                   // bottom-right alignment (mask.h:164-196)
-    const int q_wg0 = qb * PF_BM;
-    const int qw0 = q_wg0 + wave * 32;
-    const int my_q = qw0 + l31;
+    const int q_wg0 = qb * BM;
+    const int qw0 = q_wg0 + wave * 32 * QC;                    // first query row of this wave
 
     int n_end = Lk;
-    if (causal) n_end = min(Lk, q_wg0 + PF_BM + off);          // last key any row of this block may see, +1
+    if (causal) n_end = min(Lk, q_wg0 + BM + off);             // last key any row of this block may see, +1
     if (n_end < 0) n_end = 0;
     const int nt = (n_end + PF_BN - 1) / PF_BN;
 
-    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
-    T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
     const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
     const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
 
     // ---- Q^T fragments (B operand of S^T = K.Q^T): slot (g, j) <-> d = 16*kk + 8*g + j ----
-    V8 qf[KK];
+    V8 qf[QC][KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
-        qf[kk] = as_v8<V8>(v);
+    for (int qc = 0; qc < QC; qc++) {
+        const int my_q = qw0 + 32 * qc + l31;
+        const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+            qf[qc][kk] = as_v8<V8>(v);
+        }
     }
 
-    f32x16 o[DB];
+    f32x16 o[DB][QC];
 #pragma unroll
-    for (int i = 0; i < DB; i++) o[i] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY;     // running max of raw scores (both half-lanes hold the same value)
-    float l_run = 0.f;           // lane-local partial sum (combined across the half-lanes at the end)
+    for (int i = 0; i < DB; i++)
+#pragma unroll
+        for (int qc = 0; qc < QC; qc++) o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m_run[QC], l_run[QC];   // running max of raw scores (same in both half-lanes); lane-local partial sums
+#pragma unroll
+    for (int qc = 0; qc < QC; qc++) { m_run[qc] = -INFINITY; l_run[qc] = 0.f; }
     const float sc = p.softmax_scale * kLog2e;
 
     uint4 kreg[PASSES], vreg[PASSES];
+    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
+    // per-thread byte offsets inside a tile (row-major rows of the cache, 16-byte chunk c)
+    unsigned koff[PASSES], voff[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int idx = ps * NT + tid;
+        koff[ps] = (unsigned)(idx / CPR) * k_rs_bytes + (unsigned)(idx % CPR) * 16u;
+        voff[ps] = (unsigned)(idx / CPR) * v_rs_bytes + (unsigned)(idx % CPR) * 16u;
+    }
+    const T* kbase_u = uniform_ptr(kbase);
+    const T* vbase_u = uniform_ptr(vbase);
     auto stage_load = [&](int t) {
+        // descriptor rebased per tile: rows at or beyond Lk fall outside num_records -> zeros, no access
+        int rem = Lk - t * PF_BN;
+        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
+        const __amdgpu_buffer_rsrc_t kr = make_rsrc(kbase_u + (int64_t)t * PF_BN * p.k_row_stride, (unsigned)rem * k_rs_bytes);
+        const __amdgpu_buffer_rsrc_t vr = make_rsrc(vbase_u + (int64_t)t * PF_BN * p.v_row_stride, (unsigned)rem * v_rs_bytes);
 #pragma unroll
         for (int ps = 0; ps < PASSES; ps++) {
-            const int idx = ps * (64 * PF_WAVES) + tid;
-            const int row = idx / CPR;
-            const int c = idx % CPR;
-            const int key = t * PF_BN + row;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (key < Lk) {
-                kv = *(const uint4*)(kbase + (int64_t)key * p.k_row_stride + c * 8);
-                vv = *(const uint4*)(vbase + (int64_t)key * p.v_row_stride + c * 8);
-            }
-            kreg[ps] = kv;
-            vreg[ps] = vv;
+            kreg[ps] = buf_load16(kr, koff[ps]);
+            vreg[ps] = buf_load16(vr, voff[ps]);
         }
     };
     auto stage_write = [&](int buf) {
@@ -224,7 +268,7 @@ __global__ __launch_bounds__(64 * PF_WAVES, 2) void prefill_kernel(vattn_attn_pa
         char* vsm = ksm + S::kTileBytes;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ps++) {
-            const int idx = ps * (64 * PF_WAVES) + tid;
+            const int idx = ps * NT + tid;
             const int row = idx / CPR;
             const int c = idx % CPR;
             // K: row-major, 16-byte chunk index XOR-swizzled with (row & 15) -> conflict-free ds_read_b128
@@ -242,70 +286,79 @@ __global__ __launch_bounds__(64 * PF_WAVES, 2) void prefill_kernel(vattn_attn_pa
 
     for (int t = 0; t < nt; t++) {
         const int buf = t & 1;
-        if (t + 1 < nt) stage_load(t + 1);     // global loads in flight across the whole compute phase
+        stage_load(t + 1);     // in flight across the whole compute phase (past the last tile: all lanes out of range)
 
         const int n0 = t * PF_BN;
         // wave-uniform tile classification
-        const bool wave_dead = causal && (n0 > qw0 + 31 + off);          // every (row, key) pair masked
+        const bool wave_dead = causal && (n0 > qw0 + 32 * QC - 1 + off);          // every (row, key) pair masked
         if (!wave_dead) {
             const char* ksm = smem + buf * S::kBufBytes;
             const char* vsm = ksm + S::kTileBytes;
-            f32x16 s[2];
+            f32x16 s[2][QC];
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
-                s[kb] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qc = 0; qc < QC; qc++) s[kb][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const char* krow = ksm + (kb * 32 + l31) * S::kRowBytes;
 #pragma unroll
                 for (int kk = 0; kk < KK; kk++) {
                     const V8 a = *(const V8*)(krow + (((2 * kk + g) ^ (l31 & 15)) << 4));
-                    s[kb] = X::mfma32(a, qf[kk], s[kb]);
+#pragma unroll
+                    for (int qc = 0; qc < QC; qc++) s[kb][qc] = X::mfma32(a, qf[qc][kk], s[kb][qc]);
                 }
             }
-            // s[kb][r] = S^T[key = n0 + 32*kb + 8*(r>>2) + 4*g + (r&3)][query = my_q]
+            // s[kb][qc][r] = S^T[key = n0 + 32*kb + 8*(r>>2) + 4*g + (r&3)][query = qw0 + 32*qc + l31]
             const bool need_mask = (n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off));
-            if (need_mask) {
-                const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;     // last visible key for this query
+            float alpha[QC];
+#pragma unroll
+            for (int qc = 0; qc < QC; qc++) {
+                if (need_mask) {
+                    const int my_q = qw0 + 32 * qc + l31;
+                    const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;     // last visible key for this query
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int key = n0 + 32 * kb + 8 * (r >> 2) + 4 * g + (r & 3);
+                            if (key > lim) s[kb][qc][r] = -INFINITY;
+                        }
+                }
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, s[kb][qc][r]);
+                mloc = fmaxf(mloc, swap_halves(mloc));
+                const float m_new = fmaxf(m_run[qc], mloc);
+                const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;   // softmax.h: all-masked rows use 0
+                alpha[qc] = fast_exp2(m_run[qc] * sc - msub);                  // m_run = -inf -> 0
+                m_run[qc] = m_new;
+                float psum = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const int key = n0 + 32 * kb + 8 * (r >> 2) + 4 * g + (r & 3);
-                        if (key > lim) s[kb][r] = -INFINITY;
+                        const float e = fast_exp2(__builtin_fmaf(s[kb][qc][r], sc, -msub));
+                        s[kb][qc][r] = e;
+                        psum += e;
                     }
+                l_run[qc] = l_run[qc] * alpha[qc] + psum;
+#pragma unroll
+                for (int i = 0; i < DB; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha[qc];
             }
-            float mloc = -INFINITY;
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, s[kb][r]);
-            mloc = fmaxf(mloc, xor_shuffle(mloc, 32));
-            const float m_new = fmaxf(m_run, mloc);
-            const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;   // softmax.h: all-masked rows use 0
-            const float alpha = fast_exp2(m_run * sc - msub);              // m_run = -inf -> 0
-            m_run = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float e = fast_exp2(__builtin_fmaf(s[kb][r], sc, -msub));
-                    s[kb][r] = e;
-                    psum += e;
-                }
-            l_run = l_run * alpha + psum;
-#pragma unroll
-            for (int i = 0; i < DB; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
 
             // O^T += V^T . P^T : B operand slot (g, j) <-> key 16*u + (j<4 ? 4g+j : 8+4g+j-4) = S^T regs 8u..8u+7
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    V8 pf;
+                    V8 pf[QC];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) pf[j] = X::cvt(s[kb][8 * u + j]);
+                    for (int qc = 0; qc < QC; qc++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) pf[qc][j] = X::cvt(s[kb][qc][8 * u + j]);
                     const int krow0 = kb * 32 + 16 * u;
 #pragma unroll
                     for (int db = 0; db < DB; db++) {
@@ -324,31 +377,37 @@ __global__ __launch_bounds__(64 * PF_WAVES, 2) void prefill_kernel(vattn_attn_pa
                                 a[j] = vs[key * 32 + l31];
                             }
                         }
-                        o[db] = X::mfma32(a, pf, o[db]);
+#pragma unroll
+                        for (int qc = 0; qc < QC; qc++) o[db][qc] = X::mfma32(a, pf[qc], o[db][qc]);
                     }
                 }
         }
-        if (t + 1 < nt) stage_write(buf ^ 1);   // buffer last read in iteration t-1; every wave passed that barrier
+        stage_write(buf ^ 1);   // buffer last read in iteration t-1; every wave passed that barrier
         __syncthreads();
     }
 
     // ---- epilogue: O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
-    const float l_tot = l_run + xor_shuffle(l_run, 32);
-    const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-    if (my_q < Sq) {
 #pragma unroll
-        for (int db = 0; db < DB; db++)
+    for (int qc = 0; qc < QC; qc++) {
+        const int my_q = qw0 + 32 * qc + l31;
+        const float l_tot = l_run[qc] + swap_halves(l_run[qc]);
+        const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+        if (my_q < Sq) {
+            T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
 #pragma unroll
-            for (int tq = 0; tq < 4; tq++) {
-                typename X::v4 w;
+            for (int db = 0; db < DB; db++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][4 * tq + e] * inv);
-                *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+                for (int tq = 0; tq < 4; tq++) {
+                    typename X::v4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][qc][4 * tq + e] * inv);
+                    *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+                }
+            if (p.softmax_lse && g == 0) {
+                // natural-log LSE of scale*QK^T; +inf for fully masked rows (flash convention)
+                const float lse = (l_tot == 0.f) ? INFINITY : (m_run[qc] * p.softmax_scale + __logf(l_tot));
+                p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
             }
-        if (p.softmax_lse && g == 0) {
-            // natural-log LSE of scale*QK^T; +inf for fully masked rows (flash convention)
-            const float lse = (l_tot == 0.f) ? INFINITY : (m_run * p.softmax_scale + __logf(l_tot));
-            p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
         }
     }
 }
@@ -384,8 +443,8 @@ __global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params
     const int gb = blockIdx.y % gblocks;
     const int b = blockIdx.z;
     const int G = p.h / p.h_k;
-    const int slot = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
-    const int Lk = (p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew;
+    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
 
     // each sequence divides ITS OWN length evenly over the splits (balanced for ragged batches)
     const int ntiles_total = (Lk + DC_BN - 1) / DC_BN;
@@ -417,31 +476,33 @@ __global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params
     char* vsm = smem + wave * V_WAVE_BYTES;
 
     uint4 kreg[2][KK], vreg[VPASS];
+    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
+    const T* kbase_u = uniform_ptr(kbase);
+    const T* vbase_u = uniform_ptr(vbase);
+    unsigned koff[2], voff[VPASS];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) koff[kb] = (unsigned)(16 * kb + l15) * k_rs_bytes + (unsigned)g4 * 16u;
+#pragma unroll
+    for (int ps = 0; ps < VPASS; ps++) {
+        const int idx = ps * 64 + lane;
+        voff[ps] = (unsigned)(idx / CPR) * v_rs_bytes + (unsigned)(idx % CPR) * 16u;
+    }
     auto load_tile = [&](int tile) {
         const int k0 = tile * DC_BN;
+        int rem = Lk - k0;
+        rem = rem < 0 ? 0 : (rem > DC_BN ? DC_BN : rem);
+        const __amdgpu_buffer_rsrc_t kr = make_rsrc(kbase_u + (int64_t)k0 * p.k_row_stride, (unsigned)rem * k_rs_bytes);
+        const __amdgpu_buffer_rsrc_t vr = make_rsrc(vbase_u + (int64_t)k0 * p.v_row_stride, (unsigned)rem * v_rs_bytes);
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-            const int key = k0 + 16 * kb + l15;
+        for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-            for (int kk = 0; kk < KK; kk++) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (key < Lk) v = *(const uint4*)(kbase + (int64_t)key * p.k_row_stride + 32 * kk + 8 * g4);
-                kreg[kb][kk] = v;
-            }
-        }
+            for (int kk = 0; kk < KK; kk++) kreg[kb][kk] = buf_load16(kr, koff[kb] + 64u * kk);
 #pragma unroll
-        for (int ps = 0; ps < VPASS; ps++) {
-            const int idx = ps * 64 + lane;
-            const int row = idx / CPR, c = idx % CPR;
-            const int key = k0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < Lk) v = *(const uint4*)(vbase + (int64_t)key * p.v_row_stride + c * 8);
-            vreg[ps] = v;
-        }
+        for (int ps = 0; ps < VPASS; ps++) vreg[ps] = buf_load16(vr, voff[ps]);
     };
 
-    int tile = tile_begin + wave;
-    if (tile < tile_end) load_tile(tile);
+    int tile = __builtin_amdgcn_readfirstlane(tile_begin + wave);
+    load_tile(tile < tile_end ? tile : ntiles_total);     // past the end: every lane out of range, no access
     for (; tile < tile_end; tile += DC_WAVES) {
         const int k0 = tile * DC_BN;
         // ---- V: registers -> wave-private LDS ([d/16][key][16 d]) ----
@@ -459,8 +520,8 @@ __global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params
 #pragma unroll
             for (int kk = 0; kk < KK; kk++) s[kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qf[kk], s[kb]);
         }
-        // prefetch the wave's next tile while this one is being consumed
-        if (tile + DC_WAVES < tile_end) load_tile(tile + DC_WAVES);
+        // prefetch the wave's next tile while this one is being consumed (out of range past the split's end)
+        load_tile(tile + DC_WAVES < tile_end ? tile + DC_WAVES : ntiles_total);
 
         // s[kb][r] = S^T[key = k0 + 16*kb + 4*g4 + r][head row l15]
         if (k0 + DC_BN > Lk) {
@@ -569,28 +630,42 @@ __global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params
     }
 }
 
-// LSE-weighted merge of the split partials (flash_fwd_kernel.h:1116-1297). One block per (b, h).
+// LSE-weighted merge of the split partials (flash_fwd_kernel.h:1116-1297). One 128-thread block per
+// (b, h): the split weights are computed once (lanes over splits), then every thread owns one d and
+// streams its partials with independent loads.
 template <typename T, int HD>
-__global__ void combine_kernel(vattn_attn_params p, int num_splits) {
+__global__ __launch_bounds__(HD) void combine_kernel(vattn_attn_params p, int num_splits) {
+    __shared__ float wsm[128];
+    __shared__ float red[4];
     const int bh = blockIdx.x;                       // b * h + head
     const int b = bh / p.h, hh = bh % p.h;
+    const int tid = threadIdx.x;
     const float* oacc = (const float*)p.workspace;
     const float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
-    float mx = -INFINITY;
-    for (int s = 0; s < num_splits; s++) mx = fmaxf(mx, lacc[(int64_t)s * p.b * p.h + bh]);
+    const int64_t sstride = (int64_t)p.b * p.h;
+    const float my = (tid < num_splits) ? lacc[(int64_t)tid * sstride + bh] : -INFINITY;    // num_splits <= 128
+    float mx = my;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
     const float mxs = (mx == -INFINITY) ? 0.f : mx;
-    float wsum = 0.f;
-    for (int s = 0; s < num_splits; s++) wsum += fast_exp2(lacc[(int64_t)s * p.b * p.h + bh] - mxs);
+    const float w = (tid < num_splits) ? fast_exp2(my - mxs) : 0.f;
+    float ws = w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ws += xor_shuffle(ws, o);
+    if ((tid & 63) == 0) red[2 + (tid >> 6)] = ws;
+    wsm[tid] = w;
+    __syncthreads();
+    const float wsum = red[2] + red[3];
     const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
-    for (int d = threadIdx.x; d < HD; d += blockDim.x) {
-        float acc = 0.f;
-        for (int s = 0; s < num_splits; s++) {
-            const float w = fast_exp2(lacc[(int64_t)s * p.b * p.h + bh] - mxs);
-            if (w != 0.f) acc += w * oacc[((int64_t)s * p.b * p.h + bh) * HD + d];
-        }
-        ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d] = Tr<T>::cvt(acc * inv);
-    }
-    if (p.softmax_lse && threadIdx.x == 0)
+    const float* src = oacc + (int64_t)bh * HD + tid;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < num_splits; s++) acc += wsm[s] * src[(int64_t)s * sstride * HD];
+    ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
+    if (p.softmax_lse && tid == 0)
         p.softmax_lse[bh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
 }
 
@@ -703,6 +778,23 @@ int pick_splits(const vattn_attn_params* p, int gblocks) {
     return (int)s;
 }
 
+template <typename T, int WAVES, int QC> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
+    constexpr int BM = 32 * QC * WAVES;
+    const int nqb = (p->seqlen_q + BM - 1) / BM;
+    dim3 grid(nqb, p->h, p->b), block(64 * WAVES);
+    const size_t smem = PfSmem<128>::kTotal;
+    static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
+        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, true, WAVES, QC>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, false, WAVES, QC>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        return true;
+    }();
+    (void)attr_once;
+    if (use_tr)
+        hipLaunchKernelGGL((prefill_kernel<T, 128, true, WAVES, QC>), grid, block, smem, st, *p);
+    else
+        hipLaunchKernelGGL((prefill_kernel<T, 128, false, WAVES, QC>), grid, block, smem, st, *p);
+}
+
 template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
     (void)time_only_main;
     const bool use_tr = (p->variant & 1) == 0;
@@ -719,19 +811,10 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
             hipLaunchKernelGGL((decode_kernel<T, 128, false>), grid, block, smem, st, *p, splits, gblocks);
         if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, 128>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
     } else {
-        const int nqb = (p->seqlen_q + PF_BM - 1) / PF_BM;
-        dim3 grid(nqb, p->h, p->b), block(64 * PF_WAVES);
-        const size_t smem = PfSmem<128>::kTotal;
-        static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
-            hipFuncSetAttribute((const void*)prefill_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-            hipFuncSetAttribute((const void*)prefill_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-            return true;
-        }();
-        (void)attr_once;
-        if (use_tr)
-            hipLaunchKernelGGL((prefill_kernel<T, 128, true>), grid, block, smem, st, *p);
-        else
-            hipLaunchKernelGGL((prefill_kernel<T, 128, false>), grid, block, smem, st, *p);
+        const int tiling = (p->variant >> 1) & 3;
+        if (tiling == 1) launch_prefill<T, 8, 1>(p, st, use_tr);
+        else if (tiling == 2) launch_prefill<T, 4, 2>(p, st, use_tr);
+        else launch_prefill<T, 4, 1>(p, st, use_tr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));

@@ -6,6 +6,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "page_manager.h"
 
@@ -15,6 +17,8 @@ struct HipCtx {
     int device;
     hipMemAllocationProp prop;
     hipMemAccessDesc access;
+    std::vector<void*> flush_allocs;     // see h_tlb_flush
+    std::mutex mu;
 };
 
 static int hip_fail(const char* what, hipError_t e) {
@@ -82,6 +86,27 @@ static int h_unmap(void*, uint64_t va, uint64_t bytes) {
     return e == hipSuccess ? 0 : hip_fail("hipMemUnmap", e);
 }
 
+// TLB invalidation after unmap.  Measured on MI355X / ROCm 7.2 (tools/remap_probe3.cpp, remap_probe4.cpp):
+// after hipMemUnmap + hipMemMap(other handle) at the same address a kernel still reads the OLD physical
+// page — sleeping, hipDeviceSynchronize or launching kernels do not help — until the driver services an
+// ordinary device allocation (its map ioctl carries the pending invalidation).  A 2 MiB hipMalloc costs
+// ~160 us and is only paid by batches that unmapped something.  hipFree synchronises the device, so the
+// probe allocations are parked and released in bulk (every 32 flushes and at teardown).
+static int h_tlb_flush(void* c) {
+    auto* x = (HipCtx*)c;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, 2u << 20);
+    if (e != hipSuccess) return hip_fail("hipMalloc (TLB invalidation probe)", e);
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> l(x->mu);
+        x->flush_allocs.push_back(p);
+        if (x->flush_allocs.size() >= 32) drop.swap(x->flush_allocs);
+    }
+    for (void* q : drop) (void)hipFree(q);
+    return 0;
+}
+
 // Fills `ops` with the HIP VMM table for `device`; the context object lives for the process.
 int make_hip_backend(int device, vattn_backend_ops* ops) {
     // A HIP context must exist on the calling thread ("initialize PyTorch first", cudaInternal.h:20-25);
@@ -108,6 +133,7 @@ int make_hip_backend(int device, vattn_backend_ops* ops) {
     ops->set_access = h_access;
     ops->unmap = h_unmap;
     ops->thread_init = h_thread_init;
+    ops->tlb_flush = h_tlb_flush;
     return 0;
 }
 

@@ -527,6 +527,7 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async) {   // e
         return 0;
     };
     int rc = VATTN_OK;
+    bool unmapped = false;
     for (const PhysOp& op : ops) {
         if (op.kind == 0) {
             rc = ensure_created(op.page);
@@ -548,9 +549,17 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async) {   // e
             }
             st_.unmap_calls++;
             st_.pages_mapped_now--;
+            unmapped = true;
         }
     }
     if (!rc && flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; }
+    if (unmapped && be_.tlb_flush) {
+        // stale GPU translations of the unmapped pages must be gone before anyone may rely on this batch
+        const uint64_t f0 = now_ns();
+        if (be_.tlb_flush(be_.ctx) != 0 && !rc) { async_error_msg_ = "TLB invalidation after unmap failed"; rc = VATTN_ERR_DRIVER; }
+        st_.tlb_flushes++;
+        st_.tlb_flush_ns += now_ns() - f0;
+    }
     const uint64_t dt = now_ns() - t0;
     if (is_async) { st_.async_batches++; st_.async_ns += dt; } else { st_.sync_batches++; st_.sync_ns += dt; }
     return rc;

@@ -133,15 +133,21 @@ class HotPathRunner:
         self._bufs = {}
         self.stats = ReplayStats()
         self.sample_kv_util = True
+        # Compute runs on a NON-BLOCKING stream: on ROCm 7.2 hipMemMap / hipMemUnmap wait for work queued on
+        # the legacy default stream (and every blocking stream) but not for non-blocking streams
+        # (tools/vmm_probe.cpp, profiles/r01_vmm_probe.md), so this is what lets page mapping — on the
+        # mapper thread or in step_async's synchronous part — overlap the forward pass.
+        self.stream = torch.cuda.Stream(device=self.device)
 
     def _qkv(self, T: int):
         # synthetic N(0,1) activations, one set per token count (the transformer body is out of scope)
         b = self._bufs.get(T)
         if b is None:
-            mk = lambda h: torch.randn(T, h * self.D, generator=self._gen, device=self.device, dtype=torch.float32).to(self.model.dtype)
-            b = self._bufs[T] = (mk(self.Hq), mk(self.Hkv), mk(self.Hkv))
-            if len(self._bufs) > 8:
-                self._bufs.pop(next(iter(self._bufs)))
+            with torch.cuda.stream(self.stream):        # allocated and consumed on the compute stream
+                mk = lambda h: torch.randn(T, h * self.D, generator=self._gen, device=self.device, dtype=torch.float32).to(self.model.dtype)
+                b = self._bufs[T] = (mk(self.Hq), mk(self.Hkv), mk(self.Hkv))
+                if len(self._bufs) > 8:
+                    self._bufs.pop(next(iter(self._bufs)))
         return b
 
     def run_iteration(self, mds: List[SequenceMetadata]) -> torch.Tensor:
@@ -150,12 +156,13 @@ class HotPathRunner:
         for md in mds:
             T += md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len) if md.is_prompt else 1
         q, k, v = self._qkv(T)
-        self.engine.step(mds)
-        self.wrapper.begin_forward(mds)
-        out = None
-        for layer in range(self.L):
-            out = self.wrapper.forward(q, k, v, self.engine.gpu_cache[layer], self.scale, layer)
-        self.wrapper.end_forward()
+        with torch.cuda.stream(self.stream):
+            self.engine.step(mds)
+            self.wrapper.begin_forward(mds)
+            out = None
+            for layer in range(self.L):
+                out = self.wrapper.forward(q, k, v, self.engine.gpu_cache[layer], self.scale, layer)
+            self.wrapper.end_forward()
         for md in mds:                               # seq_manager.on_step_completed
             if md.is_prompt:
                 n = md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len)
