@@ -103,8 +103,8 @@ if __name__ == "__main__":
     what = [a for a in sys.argv[1:] if a in ("prefill", "decode")] or ["prefill", "decode"]
     torch.zeros(1, device=DEV)
     if "prefill" in what:
-        for v in ([variant] if "--variant" in sys.argv else [0, 2, 4]):
-            print("-- prefill variant %d (tiling %s) --" % (v, {0: "4 waves x 32 rows", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows"}[(v >> 1) & 3]))
+        for v in ([variant] if "--variant" in sys.argv else [0, 2, 6]):
+            print("-- prefill variant %d (tiling %s) --" % (v, {0: "4 waves x 32 rows", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined"}[(v >> 1) & 3]))
             prefill(v)
     if "decode" in what:
         decode(variant)

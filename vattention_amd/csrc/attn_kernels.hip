@@ -163,6 +163,12 @@ __global__ void append_kv_kernel(vattn_attn_params p) {
 // ============================================================================================
 
 constexpr int PF_BN = 64;              // keys per tile
+// Debug-only ablation switch for tools/kbench.py (cdna guide §5.4: "ablate before optimizing"); the product
+// build leaves it at 0.  1: exp2 replaced by a multiply; 2: V^T fragments not read from LDS; 3: K fragments
+// not read from LDS; 4: no global loads / LDS stores of the next tile; 5: no per-tile barrier; 6: no softmax VALU at all
+#ifndef VATTN_ABLATE
+#define VATTN_ABLATE 0
+#endif
 
 template <int HD> struct PfSmem {
     static constexpr int kRowBytes = HD * 2;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
 
     for (int t = 0; t < nt; t++) {
         const int buf = t & 1;
-        stage_load(t + 1);     // in flight across the whole compute phase (past the last tile: all lanes out of range)
+        if (VATTN_ABLATE != 4) stage_load(t + 1);     // in flight across the whole compute phase (past the last tile: all lanes out of range)
 
         const int n0 = t * PF_BN;
         // wave-uniform tile classification
@@ -296,22 +302,47 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
             const char* vsm = ksm + S::kTileBytes;
             f32x16 s[2][QC];
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
+            for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int qc = 0; qc < QC; qc++) s[kb][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const char* krow = ksm + (kb * 32 + l31) * S::kRowBytes;
+            // k-step outer, key-block inner: consecutive MFMAs hit DIFFERENT accumulators, so the dependent
+            // accumulate latency of one chain is covered by the other chain's issue slot; the K fragments of
+            // step kk+1 are read from LDS while the MFMAs of step kk run (explicit two-deep register ring)
+            auto kfrag = [&](int kb, int kk) -> V8 {
+                if (VATTN_ABLATE == 3) return qf[0][(kk + kb) % KK];
+                return *(const V8*)(ksm + (kb * 32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
+            };
+            V8 a_cur[2], a_nxt[2];
+            a_cur[0] = kfrag(0, 0);
+            a_cur[1] = kfrag(1, 0);
 #pragma unroll
-                for (int kk = 0; kk < KK; kk++) {
-                    const V8 a = *(const V8*)(krow + (((2 * kk + g) ^ (l31 & 15)) << 4));
-#pragma unroll
-                    for (int qc = 0; qc < QC; qc++) s[kb][qc] = X::mfma32(a, qf[qc][kk], s[kb][qc]);
+            for (int kk = 0; kk < KK; kk++) {
+                if (kk + 1 < KK) {
+                    a_nxt[0] = kfrag(0, kk + 1);
+                    a_nxt[1] = kfrag(1, kk + 1);
                 }
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int qc = 0; qc < QC; qc++) s[kb][qc] = X::mfma32(a_cur[kb], qf[qc][kk], s[kb][qc]);
+                a_cur[0] = a_nxt[0];
+                a_cur[1] = a_nxt[1];
             }
+            // pin the issue order the ring is meant to have (hipcc otherwise sinks every read next to its use):
+            // reads of step kk+1, then the MFMAs of step kk   (LLVM SchedGroupMask: 0x100 = DS read, 0x8 = MFMA)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int kk = 0; kk + 1 < KK; kk++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * QC, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * QC, 0);
             // s[kb][qc][r] = S^T[key = n0 + 32*kb + 8*(r>>2) + 4*g + (r&3)][query = qw0 + 32*qc + l31]
             const bool need_mask = (n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off));
             float alpha[QC];
 #pragma unroll
             for (int qc = 0; qc < QC; qc++) {
+                if (VATTN_ABLATE == 6) { alpha[qc] = 1.f; continue; }
                 if (need_mask) {
                     const int my_q = qw0 + 32 * qc + l31;
                     const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;     // last visible key for this query
@@ -338,15 +369,20 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
                 for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const float e = fast_exp2(__builtin_fmaf(s[kb][qc][r], sc, -msub));
+                        float e;
+                        if (VATTN_ABLATE == 1) e = s[kb][qc][r] * sc; else e = fast_exp2(__builtin_fmaf(s[kb][qc][r], sc, -msub));
                         s[kb][qc][r] = e;
                         psum += e;
                     }
                 l_run[qc] = l_run[qc] * alpha[qc] + psum;
+                // O only needs rescaling when some row's running max actually moved (rare after the first
+                // tiles); the test is exact (alpha == 1 otherwise) and wave-uniform
+                if (__builtin_amdgcn_ballot_w64(alpha[qc] != 1.0f) != 0) {
 #pragma unroll
-                for (int i = 0; i < DB; i++)
+                    for (int i = 0; i < DB; i++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha[qc];
+                        for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha[qc];
+                }
             }
 
             // O^T += V^T . P^T : B operand slot (g, j) <-> key 16*u + (j<4 ? 4g+j : 8+4g+j-4) = S^T regs 8u..8u+7
@@ -363,7 +399,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
 #pragma unroll
                     for (int db = 0; db < DB; db++) {
                         V8 a;
-                        if constexpr (USE_TR) {
+                        if (VATTN_ABLATE == 2) {
+                            a = qf[0][(db + u + 2 * kb) % KK];
+                        } else if constexpr (USE_TR) {
                             const int i16 = lane & 15, dh = (lane >> 4) & 1;
                             const char* a1 = vsm + db * S::kVSubBytes + (krow0 + 4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2;
                             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
@@ -382,8 +420,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
                     }
                 }
         }
-        stage_write(buf ^ 1);   // buffer last read in iteration t-1; every wave passed that barrier
-        __syncthreads();
+        if (VATTN_ABLATE != 4) stage_write(buf ^ 1);   // buffer last read in iteration t-1; every wave passed that barrier
+        if (VATTN_ABLATE != 5 && VATTN_ABLATE != 4) __syncthreads();
     }
 
     // ---- epilogue: O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
@@ -408,6 +446,238 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
                 const float lse = (l_tot == 0.f) ? INFINITY : (m_run[qc] * p.softmax_scale + __logf(l_tot));
                 p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
             }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Software-pipelined prefill: while the VALU runs the softmax of tile t, the matrix pipe already
+// accumulates S^T of tile t+1 (both live in registers), then P(t).V(t) follows.  A wave's MFMA work
+// and its own softmax therefore overlap instead of alternating, which is what lifts the matrix-pipe
+// duty of a wave (measured on the non-pipelined kernel: ~26 % per wave, ~41 % per SIMD with two
+// waves at random phase; profiles/r01_prefill_pmc.md).  K runs one tile ahead of V in LDS:
+//   iteration t reads  K[(t+1)&1] (QK of tile t+1)  and  V[t&1] (PV of tile t),
+//   and stores         K(t+2) -> K[t&1],  V(t+1) -> V[(t+1)&1]   before the single barrier.
+// --------------------------------------------------------------------------------------------
+template <typename T, int HD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void prefill_pipe_kernel(vattn_attn_params p) {
+    using X = Tr<T>;
+    using V8 = typename X::v8;
+    using S = PfSmem<HD>;
+    constexpr int NT = 64 * WAVES;
+    constexpr int BM = 32 * WAVES;
+    constexpr int KK = HD / 16;
+    constexpr int DB = HD / 32;
+    constexpr int CPR = HD / 8;
+    constexpr int PASSES = (PF_BN * CPR) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ksm0 = smem;                          // K[0], K[1]
+    char* const vsm0 = smem + 2 * S::kTileBytes;      // V[0], V[1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+    const int b = blockIdx.z;
+    const int h = blockIdx.y;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+    const int hk = h / (p.h / p.h_k);
+    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+    const int Sq = p.seqlen_q;
+    const bool causal = p.is_causal != 0;
+    const int off = Lk - Sq;
+    const int q_wg0 = qb * BM;
+    const int qw0 = q_wg0 + wave * 32;
+    const int my_q = qw0 + l31;
+
+    int n_end = Lk;
+    if (causal) n_end = min(Lk, q_wg0 + BM + off);
+    if (n_end < 0) n_end = 0;
+    const int nt = (n_end + PF_BN - 1) / PF_BN;
+    // tiles [0, t_live) hold at least one visible (row, key) pair for THIS wave (wave-uniform)
+    int t_live = nt;
+    if (causal) {
+        const int last_key = qw0 + 31 + off;
+        t_live = last_key < 0 ? 0 : min(nt, last_key / PF_BN + 1);
+    }
+
+    const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
+    const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
+    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
+
+    V8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+        qf[kk] = as_v8<V8>(v);
+    }
+    f32x16 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; i++) o[i] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.softmax_scale * kLog2e;
+
+    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
+    unsigned koff[PASSES], voff[PASSES], klds[PASSES], vlds[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int idx = ps * NT + tid;
+        const int row = idx / CPR, c = idx % CPR;
+        koff[ps] = (unsigned)row * k_rs_bytes + (unsigned)c * 16u;
+        voff[ps] = (unsigned)row * v_rs_bytes + (unsigned)c * 16u;
+        klds[ps] = (unsigned)(row * S::kRowBytes + ((c ^ (row & 15)) << 4));                 // XOR-swizzled K image
+        vlds[ps] = (unsigned)((c >> 2) * S::kVSubBytes + row * 64 + ((c & 3) << 4));         // [d/32][key][32 d] V image
+    }
+    const T* kbase_u = uniform_ptr(kbase);
+    const T* vbase_u = uniform_ptr(vbase);
+    auto tile_rsrc = [&](const T* base, int64_t row_stride, unsigned rs_bytes, int t) {
+        int rem = Lk - t * PF_BN;
+        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
+        return make_rsrc(base + (int64_t)t * PF_BN * row_stride, (unsigned)rem * rs_bytes);
+    };
+    uint4 kreg[PASSES], vreg[PASSES];
+    auto load_k = [&](int t) {
+        const __amdgpu_buffer_rsrc_t r = tile_rsrc(kbase_u, p.k_row_stride, k_rs_bytes, t);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) kreg[ps] = buf_load16(r, koff[ps]);
+    };
+    auto load_v = [&](int t) {
+        const __amdgpu_buffer_rsrc_t r = tile_rsrc(vbase_u, p.v_row_stride, v_rs_bytes, t);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) vreg[ps] = buf_load16(r, voff[ps]);
+    };
+    auto store_k = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) *(uint4*)(ksm0 + buf * S::kTileBytes + klds[ps]) = kreg[ps];
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) *(uint4*)(vsm0 + buf * S::kTileBytes + vlds[ps]) = vreg[ps];
+    };
+    auto kfrag = [&](const char* ksm, int kb, int kk) -> V8 {
+        return *(const V8*)(ksm + (kb * 32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
+    };
+
+    // ---- prologue: K(0), K(1), V(0) into LDS; S_cur = QK(0) ----
+    load_k(0);
+    store_k(0);
+    load_k(1);
+    store_k(1);
+    load_v(0);
+    store_v(0);
+    __syncthreads();
+    f32x16 sc0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 sc1 = sc0;      // S_cur: key blocks 0 and 1 of the current tile
+    if (t_live > 0) {
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            sc0 = X::mfma32(kfrag(ksm0, 0, kk), qf[kk], sc0);
+            sc1 = X::mfma32(kfrag(ksm0, 1, kk), qf[kk], sc1);
+        }
+    }
+
+    for (int t = 0; t < nt; t++) {
+        load_k(t + 2);      // in flight across the whole iteration (out of range past the end: zeros, no access)
+        load_v(t + 1);
+        if (t < t_live) {
+            const int n0 = t * PF_BN;
+            // diagonal / ragged tiles: mask S_cur in place first (rare; keeps the main block branch-free)
+            if ((n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off))) {
+                const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = n0 + 8 * (r >> 2) + 4 * g + (r & 3);
+                    if (key > lim) sc0[r] = -INFINITY;
+                    if (key + 32 > lim) sc1[r] = -INFINITY;
+                }
+            }
+            // ---- main block: S_nxt = K(t+1).Q^T on the matrix pipe  ||  softmax(S_cur) on the VALU ----
+            const char* ksm = ksm0 + ((t + 1) & 1) * S::kTileBytes;
+            f32x16 sn0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 sn1 = sn0;
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                sn0 = X::mfma32(kfrag(ksm, 0, kk), qf[kk], sn0);
+                sn1 = X::mfma32(kfrag(ksm, 1, kk), qf[kk], sn1);
+            }
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
+            mloc = fmaxf(mloc, swap_halves(mloc));
+            const float m_new = fmaxf(m_run, mloc);
+            const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
+            const float alpha = fast_exp2(m_run * sc - msub);
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc0[r] = fast_exp2(__builtin_fmaf(sc0[r], sc, -msub));
+                sc1[r] = fast_exp2(__builtin_fmaf(sc1[r], sc, -msub));
+                psum += sc0[r] + sc1[r];
+            }
+            // keep the exponentials in THIS block (hipcc otherwise sinks them below the rescale branch, away from
+            // the MFMAs they are meant to hide behind): psum is made opaque here, which pins all 32 of them
+            asm volatile("" : "+v"(psum));
+            l_run = l_run * alpha + psum;
+            // interleave: one MFMA, one K-fragment read, a slice of the softmax VALU (0x8 MFMA, 0x100 DS read, 0x2 VALU)
+#pragma unroll
+            for (int i = 0; i < 2 * KK; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+            }
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int i = 0; i < DB; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+            }
+            // ---- O^T += V^T(t) . P^T ----
+            const char* vsm = vsm0 + (t & 1) * S::kTileBytes;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    V8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) pf[j] = X::cvt(kb == 0 ? sc0[8 * u + j] : sc1[8 * u + j]);
+                    const int krow0 = kb * 32 + 16 * u;
+#pragma unroll
+                    for (int db = 0; db < DB; db++) {
+                        const int i16 = lane & 15, dh = (lane >> 4) & 1;
+                        const char* a1 = vsm + db * S::kVSubBytes + (krow0 + 4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
+                        o[db] = X::mfma32(join_tr<V8>(lo, hi), pf, o[db]);
+                    }
+                }
+            sc0 = sn0;
+            sc1 = sn1;
+        }
+        store_k(t & 1);            // K(t+2): the buffer held K(t), whose QK finished in iteration t-1 on every wave
+        store_v((t + 1) & 1);      // V(t+1): the buffer held V(t-1), last read in iteration t-1
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + swap_halves(l_run);
+    const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+    if (my_q < Sq) {
+        T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int tq = 0; tq < 4; tq++) {
+                typename X::v4 w;
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][4 * tq + e] * inv);
+                *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+            }
+        if (p.softmax_lse && g == 0) {
+            const float lse = (l_tot == 0.f) ? INFINITY : (m_run * p.softmax_scale + __logf(l_tot));
+            p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
         }
     }
 }
@@ -812,7 +1082,16 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
         if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, 128>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
     } else {
         const int tiling = (p->variant >> 1) & 3;
-        if (tiling == 1) launch_prefill<T, 8, 1>(p, st, use_tr);
+        if (tiling == 3) {
+            constexpr int W = 8;
+            const int nqb = (p->seqlen_q + 32 * W - 1) / (32 * W);
+            static const bool once = [] {
+                (void)hipFuncSetAttribute((const void*)prefill_pipe_kernel<T, 128, W>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+                return true;
+            }();
+            (void)once;
+            hipLaunchKernelGGL((prefill_pipe_kernel<T, 128, W>), dim3(nqb, p->h, p->b), dim3(64 * W), PfSmem<128>::kTotal, st, *p);
+        } else if (tiling == 1) launch_prefill<T, 8, 1>(p, st, use_tr);
         else if (tiling == 2) launch_prefill<T, 4, 2>(p, st, use_tr);
         else launch_prefill<T, 4, 1>(p, st, use_tr);
     }
