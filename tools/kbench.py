@@ -83,7 +83,7 @@ def decode(variant):
         vn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=torch.float16)
         cl = torch.full((B,), ctx - 1, dtype=torch.int32, device=DEV)
         idx = torch.arange(B, dtype=torch.int32, device=DEV) % slots
-        for splits in (0,):
+        for splits in SPLITS:
             p, keep = params(q, kc, vc, cl, idx, kn, vn, splits=splits, variant=variant)
             ms = time_ms(p, 3, 20)
             by = B * 2.0 * ctx * Hkv * 128 * 2 + B * Hq * 128 * 2 * 2
@@ -93,9 +93,12 @@ def decode(variant):
 
 
 ONLY = None
+SPLITS = (0,)
 
 if __name__ == "__main__":
     variant = 0
+    if "--splits" in sys.argv:
+        SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
     if "--only" in sys.argv:
         ONLY = sys.argv[sys.argv.index("--only") + 1]
     if "--variant" in sys.argv:
@@ -103,8 +106,8 @@ if __name__ == "__main__":
     what = [a for a in sys.argv[1:] if a in ("prefill", "decode")] or ["prefill", "decode"]
     torch.zeros(1, device=DEV)
     if "prefill" in what:
-        for v in ([variant] if "--variant" in sys.argv else [0, 2, 6]):
-            print("-- prefill variant %d (tiling %s) --" % (v, {0: "4 waves x 32 rows", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined"}[(v >> 1) & 3]))
+        for v in ([variant] if "--variant" in sys.argv else [0, 8, 6]):
+            print("-- prefill variant %d (tiling %s) --" % (v, {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined", 4: "4 waves x 32 rows"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
         decode(variant)

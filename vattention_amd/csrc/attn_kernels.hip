@@ -691,7 +691,7 @@ constexpr int DC_BN = 32;     // keys per wave tile
 
 // workspace layout: float o_accum[splits][b][h][d]; float lse_accum[splits][b][h]  (log2 domain, scaled)
 template <typename T, int HD, bool USE_TR>
-__global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks) {
+__global__ __launch_bounds__(64 * DC_WAVES, 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
@@ -721,6 +721,12 @@ __global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params
     const int tiles_per_split = (ntiles_total + num_splits - 1) / num_splits;
     const int tile_begin = split * tiles_per_split;
     const int tile_end = min(ntiles_total, tile_begin + tiles_per_split);
+
+    // Fused append (seqlen_knew == 1): the new K/V row sits at key index Lk-1.  Every workgroup that reads the tile
+    // holding it substitutes the row from k_new/v_new in registers; the gb == 0 workgroup also stores it into the
+    // cache (flash_attn_interface.py:1168-1176: append, then attend).  No inter-workgroup ordering is needed.
+    const int new_key = fused_append ? Lk - 1 : -1;
+    const int new_tile = fused_append ? new_key / DC_BN : -1;
 
     const int row_head = gb * 16 + l15;                 // query head within the group handled by this lane's column
     const bool row_valid = row_head < G;
@@ -769,6 +775,31 @@ __global__ __launch_bounds__(64 * DC_WAVES) void decode_kernel(vattn_attn_params
             for (int kk = 0; kk < KK; kk++) kreg[kb][kk] = buf_load16(kr, koff[kb] + 64u * kk);
 #pragma unroll
         for (int ps = 0; ps < VPASS; ps++) vreg[ps] = buf_load16(vr, voff[ps]);
+        if (tile == new_tile) {      // wave-uniform, at most once per workgroup
+            const T* kn = (const T*)p.k_new + (int64_t)b * p.knew_batch_stride + (int64_t)hk * p.knew_head_stride;
+            const T* vn = (const T*)p.v_new + (int64_t)b * p.vnew_batch_stride + (int64_t)hk * p.vnew_head_stride;
+            T* kc = (T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride + (int64_t)new_key * p.k_row_stride;
+            T* vc = (T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride + (int64_t)new_key * p.v_row_stride;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+                if (k0 + 16 * kb + l15 == new_key) {
+#pragma unroll
+                    for (int kk = 0; kk < KK; kk++) {
+                        const uint4 v = *(const uint4*)(kn + 32 * kk + 8 * g4);
+                        kreg[kb][kk] = v;
+                        if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(kc + 32 * kk + 8 * g4) = v;
+                    }
+                }
+#pragma unroll
+            for (int ps = 0; ps < VPASS; ps++) {
+                const int idx = ps * 64 + lane;
+                if (k0 + idx / CPR == new_key) {
+                    const uint4 v = *(const uint4*)(vn + (idx % CPR) * 8);
+                    vreg[ps] = v;
+                    if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(vc + (idx % CPR) * 8) = v;
+                }
+            }
+        }
     };
 
     int tile = __builtin_amdgcn_readfirstlane(tile_begin + wave);
@@ -1034,18 +1065,35 @@ int fail(int code, const char* msg) {
     return code;
 }
 
+// Split count for the decode form.  The kernel is built for 3 workgroups per CU (<= 168 VGPRs, 33 KiB LDS), i.e.
+// 768 resident workgroups on 256 CUs; like the reference's heuristic (flash_api.cpp:258-323) pick the smallest
+// split count whose last "round" of workgroups is nearly full, but against THIS chip's residency.
 int pick_splits(const vattn_attn_params* p, int gblocks) {
     if (p->num_splits > 0) return p->num_splits > 128 ? 128 : p->num_splits;
-    // enough workgroups to cover 256 CUs ~3x; never more splits than 8-tile chunks of the cache view
     const long wg = (long)p->b * p->h_k * gblocks;
+    const long slots = 768;
     const int max_len = p->seqlen_k + p->seqlen_knew;
     const int tiles = (max_len + DC_BN - 1) / DC_BN;
-    long s = (768 + wg - 1) / wg;
-    const long cap = tiles / 8 > 0 ? tiles / 8 : 1;
-    if (s > cap) s = cap;
-    if (s > 128) s = 128;
-    if (s < 1) s = 1;
-    return (int)s;
+    long cap = tiles / 4;                       // at least one 32-key tile per wave and split
+    if (cap < 1) cap = 1;
+    if (cap > 128) cap = 128;
+    if (wg * 10 >= slots * 6) return 1;      // the batch alone (nearly) fills the chip: splitting only adds combine work
+    // otherwise: fill whole rounds of resident workgroups exactly (measured on MI355X, tools/kbench.py --splits:
+    // 16 x 4 heads @32k: 12 splits = 768 workgroups 71.4 % of HBM peak vs 63.9-68.8 % for 4/6/8/16/24)
+    double best = 0.0;
+    long pick = 1;
+    for (long s = 1; s <= cap; s++) {
+        const double waves = (double)(wg * s) / slots;
+        const double eff = waves / (double)((wg * s + slots - 1) / slots);
+        if (eff > best + 1e-9) { best = eff; pick = s; }
+    }
+    return (int)pick;
+}
+
+void launch_append(const vattn_attn_params* p, hipStream_t st) {
+    const int total = p->seqlen_knew * p->h_k * (p->d / 8);
+    dim3 grid((total + 255) / 256, p->b), block(256);
+    hipLaunchKernelGGL(append_kv_kernel, grid, block, 0, st, *p);
 }
 
 template <typename T, int WAVES, int QC> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
@@ -1075,13 +1123,18 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
         if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
         dim3 grid(splits, p->h_k * gblocks, p->b), block(64 * DC_WAVES);
         const size_t smem = (size_t)DC_WAVES * 16 * 128 * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
+        const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
+        if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
         if (use_tr)
-            hipLaunchKernelGGL((decode_kernel<T, 128, true>), grid, block, smem, st, *p, splits, gblocks);
+            hipLaunchKernelGGL((decode_kernel<T, 128, true>), grid, block, smem, st, *p, splits, gblocks, fused_append);
         else
-            hipLaunchKernelGGL((decode_kernel<T, 128, false>), grid, block, smem, st, *p, splits, gblocks);
+            hipLaunchKernelGGL((decode_kernel<T, 128, false>), grid, block, smem, st, *p, splits, gblocks, fused_append);
         if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, 128>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
     } else {
-        const int tiling = (p->variant >> 1) & 3;
+        if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
+        // 0 = default (8 waves x 32 rows: best or within noise on 6 of 7 measured shapes, profiles/r01_kbench.md);
+        // 1 = same, explicit; 2 = 4 waves x 64 rows; 3 = software-pipelined 8-wave; 4 = 4 waves x 32 rows
+        const int tiling = (p->variant >> 1) & 7;
         if (tiling == 3) {
             constexpr int W = 8;
             const int nqb = (p->seqlen_q + 32 * W - 1) / (32 * W);
@@ -1091,9 +1144,9 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
             }();
             (void)once;
             hipLaunchKernelGGL((prefill_pipe_kernel<T, 128, W>), dim3(nqb, p->h, p->b), dim3(64 * W), PfSmem<128>::kTotal, st, *p);
-        } else if (tiling == 1) launch_prefill<T, 8, 1>(p, st, use_tr);
-        else if (tiling == 2) launch_prefill<T, 4, 2>(p, st, use_tr);
-        else launch_prefill<T, 4, 1>(p, st, use_tr);
+        } else if (tiling == 2) launch_prefill<T, 4, 2>(p, st, use_tr);
+        else if (tiling == 4) launch_prefill<T, 4, 1>(p, st, use_tr);
+        else launch_prefill<T, 8, 1>(p, st, use_tr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
@@ -1144,11 +1197,7 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
     int rc = validate(p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (p->k_new && p->seqlen_knew > 0) {
-        const int total = p->seqlen_knew * p->h_k * (p->d / 8);
-        dim3 grid((total + 255) / 256, p->b), block(256);
-        hipLaunchKernelGGL(append_kv_kernel, grid, block, 0, st, *p);
-    }
+    if (p->k_new && p->seqlen_knew > 0 && !p->cache_seqlens) return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");
     if (p->dtype == VATTN_DTYPE_F16) return launch_attn_t<_Float16>(p, st, false);
     return launch_attn_t<__bf16>(p, st, false);
 }
