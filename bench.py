@@ -177,6 +177,18 @@ def main():
     dc_ms = op_ms.get("attn_decode", 0.0) / max(1, launches_dc)
     dc_gbs = bytes_dc / (dc_ms * 1e-3) / 1e9 if dc_ms > 0 else 0.0
 
+    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs, read side doubled per the gfx950 note in MI355X_MICROARCH.md); null for shapes that were not profiled
+    traffic_pf = traffic_dc = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if a.model == "yi-6b" and a.ctx == 32768 and not a.chunk:
+            traffic_pf = tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"]
+        if a.model == "yi-6b" and a.ctx == 32768 and a.batch == 16:
+            traffic_dc = tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+
     if rank == 0:
         out = {
             "metric": "prefill+decode tokens/sec (attention + KV-memory hot path)",
@@ -200,11 +212,11 @@ def main():
                 "parallelism": "replicas x%d (no collective on the path)" % world if world > 1 else "single GPU",
             },
             "roofline": {"kernel": "prefill_kernel (causal prefill attention)", "bound": "mfma", "achieved": round(pf_tflops, 2),
-                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pf_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pf_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic_pf,
                          "ms_per_launch": round(pf_ms, 4), "flops_per_launch": flops_per_launch},
             "roofline_decode": {"kernel": "decode_kernel+combine (split-KV decode, batch %d)" % a.batch, "bound": "hbm",
                                 "achieved": round(dc_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(dc_gbs / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(dc_ms, 4),
+                                "frac": round(dc_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_dc, "ms_per_launch": round(dc_ms, 4),
                                 "bytes_per_launch": bytes_dc},
             "kv_hbm_util": {"live_over_mapped_mean": round(sum(kv_util) / max(1, len(kv_util)), 4),
                             "live_over_mapped_min": round(min(kv_util), 4) if kv_util else None,
