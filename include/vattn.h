@@ -135,6 +135,9 @@ int64_t vattn_state_dump(vattn_t* m, uint64_t* out, uint64_t cap);
 /* page map rows (slot, byte offset, layer, k page-id, v page-id) in key order; returns rows. */
 int64_t vattn_pagemap_dump(vattn_t* m, uint64_t* out, uint64_t cap_rows);
 int vattn_get_stats(vattn_t* m, vattn_stats* out);
+/* O(max_batch_size) summary: out = [pool pages, sum of mapped page-groups, sum of page-groups needed by the
+ * current lengths, active slots]. */
+int vattn_get_counts(vattn_t* m, uint64_t out[4]);
 const char* vattn_last_error(const vattn_t* m);
 /* HIP VMM granularity probe for a device: 0 on success. */
 int vattn_hip_granularity(int device, uint64_t* min_gran, uint64_t* rec_gran);

@@ -1,0 +1,61 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every function include/*.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(vattn_[a-z_0-9]+)\s*\(", src))
+    # function-pointer fields / typedef'd structs are not exports
+    return {n for n in names if not n.endswith("_ops") and n not in ("vattn_config", "vattn_layout", "vattn_stats")}
+
+
+def test_library_exports_every_declared_symbol():
+    from vattention_amd import _lib
+    lib = _lib.lib()
+    missing = []
+    for header in ("vattn.h", "vattn_kernels.h"):
+        names = _declared(header)
+        assert len(names) >= 6
+        for n in sorted(names):
+            try:
+                getattr(lib, n)
+            except AttributeError:
+                missing.append(n)
+    assert not missing, "declared but not exported: %s" % missing
+
+
+def test_params_struct_matches_header_size():
+    """ctypes mirror of vattn_attn_params must have the C layout (checked against a compiled sizeof)."""
+    import subprocess
+    import tempfile
+    from vattention_amd import kernels as K
+    src = '#include "%s/include/vattn_kernels.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu %%zu %%zu", sizeof(vattn_attn_params), offsetof(vattn_attn_params, b), offsetof(vattn_attn_params, softmax_scale));return 0;}\n' % ROOT
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", c, "-o", exe])
+        size, off_b, off_sc = [int(x) for x in subprocess.check_output([exe]).decode().split()]
+    assert ctypes.sizeof(K.AttnParams) == size
+    assert K.AttnParams.b.offset == off_b and K.AttnParams.softmax_scale.offset == off_sc
+
+
+def test_no_gpu_calls_fail_loudly():
+    """Without a device the product refuses to run instead of falling back."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vattention_amd.cache_ops import cache_flat
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    q = torch.zeros(1, 1, 2, 128, dtype=torch.float16)
+    kc = torch.zeros(1, 8, 2, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        flash_attn_with_kvcache(q, kc, kc, cache_seqlens=4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        cache_flat(kc[0], kc[0], kc[0], kc[0], "auto")

@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
         "vattn_state_dump": (i64, [vp, C.POINTER(u64), u64]),
         "vattn_pagemap_dump": (i64, [vp, C.POINTER(u64), u64]),
         "vattn_get_stats": (i32, [vp, C.POINTER(VattnStats)]),
+        "vattn_get_counts": (i32, [vp, C.POINTER(u64)]),
         "vattn_last_error": (C.c_char_p, [vp]),
         "vattn_hip_granularity": (i32, [i32, C.POINTER(u64), C.POINTER(u64)]),
     }

@@ -59,6 +59,7 @@ void vattn_destroy(vattn_t* m) {
 int64_t vattn_state_dump(vattn_t* m, uint64_t* out, uint64_t cap) { return m->pm->state_dump(out, cap); }
 int64_t vattn_pagemap_dump(vattn_t* m, uint64_t* out, uint64_t cap_rows) { return m->pm->pagemap_dump(out, cap_rows); }
 int vattn_get_stats(vattn_t* m, vattn_stats* out) { m->pm->stats(out); return VATTN_OK; }
+int vattn_get_counts(vattn_t* m, uint64_t out[4]) { m->pm->counts(out); return VATTN_OK; }
 const char* vattn_last_error(const vattn_t* m) { return m ? m->pm->last_error() : "null handle"; }
 
 int vattn_hip_granularity(int device, uint64_t* mn, uint64_t* rec) {

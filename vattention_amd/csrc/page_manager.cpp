@@ -473,6 +473,17 @@ int64_t PageManager::pagemap_dump(uint64_t* out, uint64_t cap_rows) {
     return (int64_t)n;
 }
 
+void PageManager::counts(uint64_t out[4]) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    out[0] = pool_.size();
+    out[1] = out[2] = out[3] = 0;
+    for (uint32_t r = 0; r < cfg_.max_batch_size; r++) {
+        out[1] += mapped_pages_[r];
+        out[2] += tokens_to_pages(lens_[r]);
+        out[3] += lens_[r] != 0;
+    }
+}
+
 void PageManager::stats(vattn_stats* out) {
     std::lock_guard<std::mutex> e(exec_mu_);
     *out = st_;

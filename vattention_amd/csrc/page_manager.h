@@ -57,6 +57,7 @@ public:
     int64_t state_dump(uint64_t* out, uint64_t cap);
     int64_t pagemap_dump(uint64_t* out, uint64_t cap_rows);
     void stats(vattn_stats* out);
+    void counts(uint64_t out[4]);
     const char* last_error() const { return last_error_.c_str(); }
 
 private:

@@ -134,6 +134,11 @@ class PageManager:
         n = self._lib.vattn_pagemap_dump(self._h, buf, rows)
         return [list(buf[5 * i:5 * i + 5]) for i in range(max(0, n))]
 
+    def counts(self) -> dict:
+        buf = (C.c_uint64 * 4)()
+        self._lib.vattn_get_counts(self._h, buf)
+        return {"pool_pages": int(buf[0]), "mapped_groups": int(buf[1]), "needed_groups": int(buf[2]), "active_slots": int(buf[3])}
+
     def stats(self) -> dict:
         s = L.VattnStats()
         self._lib.vattn_get_stats(self._h, C.byref(s))

@@ -138,6 +138,8 @@ class HotPathRunner:
         # (tools/vmm_probe.cpp, profiles/r01_vmm_probe.md), so this is what lets page mapping — on the
         # mapper thread or in step_async's synchronous part — overlap the forward pass.
         self.stream = torch.cuda.Stream(device=self.device)
+        from . import vattention as _va
+        self._tpp = _va.layout()["tokens_per_page"]
 
     def _qkv(self, T: int):
         # synthetic N(0,1) activations, one set per token count (the transformer body is out of scope)
@@ -182,13 +184,14 @@ class HotPathRunner:
 
     def _sample_util(self):
         from . import vattention
-        st = vattention.state()
-        lay = vattention.layout()
-        mapped_tokens = sum(st["mapped"]) * lay["tokens_per_page"]
+        c = vattention.counts()                      # O(max_batch_size), no pool dump
+        tpp = self._tpp
+        mapped_tokens = c["mapped_groups"] * tpp
         live = sum(self.engine.curr_seq_lens)
         if mapped_tokens:
             self.stats.kv_util_samples.append(live / mapped_tokens)
-        reserved_tokens = (st["pool"] // (2 * self.L) if not self.engine.vattn_mega_cache else st["pool"] // 2) * lay["tokens_per_page"] + mapped_tokens
+        pages_per_group = 2 if self.engine.vattn_mega_cache else 2 * self.L
+        reserved_tokens = (c["pool_pages"] // pages_per_group) * tpp + mapped_tokens
         if reserved_tokens:
             self.stats.mapped_over_reserved.append(mapped_tokens / reserved_tokens)
 
@@ -217,6 +220,79 @@ class HotPathRunner:
             self.run_iteration(mds)
             running = [s for s in running if not s.is_finished()]
         return self.stats
+
+    def run_dynamic_trace(self, num_requests: int, seed: int = 42, max_tokens: int = 32768, watermark: float = 0.01) -> dict:
+        """Capacity / fragmentation stress in the shape of the reference's dynamic trace
+        (scripts/benchmark_e2e_dynamic_trace.py:7-60: 256 requests, arxiv-summarisation lengths, vLLM scheduler,
+        max_batch_size 256).  The trace CSV is reference data that does not travel; lengths are drawn from shifted
+        log-normals fitted to its marginals (prefill min 4097 / p50 7958 / p75 13186 / max 31805, decode min 105 / p50 332 /
+        p75 482; scripts/artifact_asplos25/traces/arxiv_sample.csv), total capped at max_tokens.  Arrivals are closed-loop
+        (every request is waiting at t=0): without the transformer body an open-loop qps=4 would leave the GPU idle.
+        Admission is the reference's count-based rule (vattention_block_space_manager.py:36-66):
+        free - promised - needed >= watermark."""
+        import random
+        from . import vattention
+        rng = random.Random(seed)
+        lay = vattention.layout()
+        tpp = lay["tokens_per_page"]
+        pages = lambda n: (n + tpp - 1) // tpp
+        reqs = []
+        for i in range(num_requests):
+            pre = min(31805, int(4097 + rng.lognormvariate(math.log(3861), 1.27)))
+            dec = int(105 + rng.lognormvariate(math.log(227), 0.75))
+            tot = min(max_tokens, pre + dec)
+            pre = min(pre, tot - 1)
+            reqs.append(Sequence(i, pre, tot))
+        waiting, running = list(reqs), []
+        B = self.cache_cfg.max_batch_size
+        total_groups = None
+        out = {"peak_running": 0, "util_at_peak": [], "iters": 0, "preempted": 0}
+        vm0 = vattention.stats()
+        import time as _t
+        t0 = _t.perf_counter()
+        while waiting or running:
+            free = vattention.num_free_kvblocks()
+            if free >= (1 << 63):
+                free -= 1 << 64
+            if total_groups is None:
+                total_groups = free
+            wm = int(watermark * total_groups)
+            promised = sum(pages(s.total_len) - pages(max(s.get_len(), 1)) for s in running)
+            admitted = None
+            if waiting and len(running) < B:
+                s = waiting[0]
+                if free - promised - pages(s.total_len) >= wm:
+                    admitted = waiting.pop(0)
+                    running.append(admitted)
+            if admitted is not None:       # vLLM scheduler: prefills are prioritised, one whole prompt per iteration
+                mds = [SequenceMetadata(admitted, admitted.prompt_len, True)]
+            else:
+                mds = [SequenceMetadata(s, 0, False) for s in running]
+            self.run_iteration(mds)
+            out["iters"] += 1
+            running = [s for s in running if not s.is_finished()]
+            if len(running) > out["peak_running"]:
+                out["peak_running"] = len(running)
+            if self.stats.kv_util_samples and len(running) >= min(B, num_requests) * 3 // 4:
+                out["util_at_peak"].append(self.stats.kv_util_samples[-1])
+        torch.cuda.synchronize()
+        out["seconds"] = _t.perf_counter() - t0
+        vm1 = vattention.stats()
+        u = self.stats.kv_util_samples
+        out.update({
+            "requests": num_requests, "tokens": self.stats.prefill_tokens + self.stats.decode_tokens,
+            "tokens_per_s": (self.stats.prefill_tokens + self.stats.decode_tokens) / out["seconds"],
+            "kv_live_over_mapped_mean": sum(u) / max(1, len(u)),
+            "kv_live_over_mapped_at_high_concurrency": (sum(out["util_at_peak"]) / len(out["util_at_peak"])) if out["util_at_peak"] else None,
+            "mapped_over_pool_max": max(self.stats.mapped_over_reserved) if self.stats.mapped_over_reserved else None,
+            "tokens_per_page": tpp,
+            "map_calls": vm1["map_calls"] - vm0["map_calls"], "unmap_calls": vm1["unmap_calls"] - vm0["unmap_calls"],
+            "sync_map_ms": (vm1["sync_ns"] - vm0["sync_ns"]) / 1e6, "async_map_ms": (vm1["async_ns"] - vm0["async_ns"]) / 1e6,
+            "join_wait_ms": (vm1["join_wait_ns"] - vm0["join_wait_ns"]) / 1e6,
+            "tlb_flushes": vm1["tlb_flushes"] - vm0["tlb_flushes"], "tlb_flush_ms": (vm1["tlb_flush_ns"] - vm0["tlb_flush_ns"]) / 1e6,
+        })
+        out.pop("util_at_peak")
+        return out
 
     def close(self):
         self.engine.cleanup_kvcache()

@@ -143,6 +143,10 @@ def stats() -> dict:
     return _require().stats()
 
 
+def counts() -> dict:
+    return _require().counts()
+
+
 def layout() -> dict:
     pm = _require()
     lay = pm.layout
