@@ -69,6 +69,11 @@ typedef struct vattn_backend_ops {
      * profiles/r01_vmm_probe.md); the manager therefore calls this once after every batch that unmapped
      * anything, before the batch is reported complete.  May be NULL (no-op). */
     int (*tlb_flush)(void* ctx);
+    /* Wait until every kernel already queued on the device has finished.  Called once per batch before its first
+     * unmap: the engine frees a slot right after *launching* the iteration that still reads its pages, and on
+     * ROCm 7.2 hipMemUnmap only waits for blocking streams (profiles/r01_vmm_sync_probe_raw.txt) — with compute on
+     * a non-blocking stream an unmap could pull a page from under a running kernel (GPU memory fault).  May be NULL. */
+    int (*quiesce)(void* ctx);
 } vattn_backend_ops;
 
 typedef struct vattn_layout {       /* element-unit description of every returned tensor */
@@ -91,6 +96,7 @@ typedef struct vattn_stats {
     uint64_t create_ns;
     uint64_t pages_mapped_now;            /* currently mapped physical pages */
     uint64_t tlb_flushes, tlb_flush_ns;
+    uint64_t quiesce_calls, quiesce_ns;
 } vattn_stats;
 
 typedef struct vattn_handle vattn_t;

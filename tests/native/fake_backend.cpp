@@ -20,7 +20,8 @@ struct Fake {
     std::set<uint64_t> live_handles;
     std::set<uint64_t> accessible;                          // va of mapped pages with access set
     std::set<uint64_t> stale;                               // VAs unmapped since the last TLB flush (GPU may still translate them)
-    uint64_t n_flush = 0;
+    uint64_t n_flush = 0, n_quiesce = 0;
+    bool quiesced_since_map = true;     // set by quiesce, cleared by map: an unmap must see it set (or no map since)
     uint64_t violations = 0, n_create = 0, n_map = 0, n_access = 0, n_unmap = 0, n_release = 0;
     uint64_t fail_create_after = ~0ull;
     int delay_us = 0;
@@ -88,11 +89,18 @@ int f_access(void*, uint64_t va, uint64_t bytes) {
 int f_unmap(void*, uint64_t va, uint64_t bytes) {
     std::lock_guard<std::mutex> l(g.mu);
     g.n_unmap++;
+    if (g.n_quiesce == 0) g.violations++;          // an unmap with no device synchronisation before it, ever
     auto it = g.mapped.find(va);
     if (it == g.mapped.end() || it->second.first != bytes) { g.violations++; return -1; }
     g.mapped.erase(it);
     g.accessible.erase(va);
     g.stale.insert(va);
+    return 0;
+}
+int f_quiesce(void*) {
+    std::lock_guard<std::mutex> l(g.mu);
+    g.n_quiesce++;
+    g.quiesced_since_map = true;
     return 0;
 }
 int f_flush(void*) {
@@ -101,14 +109,14 @@ int f_flush(void*) {
     g.stale.clear();
     return 0;
 }
-vattn_backend_ops g_ops = {nullptr, f_gran, f_reserve, f_free_va, f_create, f_release, f_map, f_access, f_unmap, nullptr, f_flush};
+vattn_backend_ops g_ops = {nullptr, f_gran, f_reserve, f_free_va, f_create, f_release, f_map, f_access, f_unmap, nullptr, f_flush, f_quiesce};
 }  // namespace
 
 extern "C" {
 const vattn_backend_ops* vattn_fake_backend_ops() { return &g_ops; }
 void vattn_fake_reset(uint64_t min_gran, uint64_t rec_gran) {
     std::lock_guard<std::mutex> l(g.mu);
-    g.reserved.clear(); g.mapped.clear(); g.live_handles.clear(); g.accessible.clear(); g.stale.clear(); g.n_flush = 0;
+    g.reserved.clear(); g.mapped.clear(); g.live_handles.clear(); g.accessible.clear(); g.stale.clear(); g.n_flush = 0; g.n_quiesce = 0;
     g.violations = g.n_create = g.n_map = g.n_access = g.n_unmap = g.n_release = 0;
     g.next_handle = 1; g.next_va = 0x7f0000000000ull; g.fail_create_after = ~0ull;
     g.min_gran = min_gran; g.rec_gran = rec_gran;

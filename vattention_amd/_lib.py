@@ -27,7 +27,7 @@ class VattnLayout(C.Structure):
 class VattnStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("handles_created", "handles_released", "map_calls", "access_calls",
                                            "unmap_calls", "sync_batches", "async_batches", "sync_ns", "async_ns",
-                                           "join_wait_ns", "create_ns", "pages_mapped_now", "tlb_flushes", "tlb_flush_ns")]
+                                           "join_wait_ns", "create_ns", "pages_mapped_now", "tlb_flushes", "tlb_flush_ns", "quiesce_calls", "quiesce_ns")]
 
 
 VATTN_OK, VATTN_ERR_INVALID, VATTN_ERR_OOM, VATTN_ERR_DRIVER, VATTN_ERR_POOL_EMPTY = 0, -1, -2, -3, -4

@@ -107,6 +107,11 @@ static int h_tlb_flush(void* c) {
     return 0;
 }
 
+static int h_quiesce(void*) {
+    hipError_t e = hipDeviceSynchronize();
+    return e == hipSuccess ? 0 : hip_fail("hipDeviceSynchronize", e);
+}
+
 // Fills `ops` with the HIP VMM table for `device`; the context object lives for the process.
 int make_hip_backend(int device, vattn_backend_ops* ops) {
     // A HIP context must exist on the calling thread ("initialize PyTorch first", cudaInternal.h:20-25);
@@ -134,6 +139,7 @@ int make_hip_backend(int device, vattn_backend_ops* ops) {
     ops->unmap = h_unmap;
     ops->thread_init = h_thread_init;
     ops->tlb_flush = h_tlb_flush;
+    ops->quiesce = h_quiesce;
     return 0;
 }
 

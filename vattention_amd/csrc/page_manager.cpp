@@ -14,6 +14,10 @@ namespace {
 constexpr uint64_t kEagerNumSteps = 10;    // vattention.cu:484
 constexpr uint64_t kEagerNumKvBlocks = 2;  // vattention.cu:485
 constexpr uint64_t kPrecreateSlice = 16;   // handles created per idle slice of the mapper thread
+// hipMemCreate is O(live handles) on ROCm 7.2 (9 us at 5 k handles, 106 us at 20 k, 382 us at 50 k, 931 us at 100 k:
+// profiles/r01_vmm_scale_probe.txt), so materialising a whole pool up front is quadratic.  Only this many handles at
+// the top of the LIFO are created ahead of demand; the rest are created by the map that first needs them.
+constexpr uint64_t kPrecreateAhead = 4096;
 
 inline uint64_t now_ns() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
@@ -273,6 +277,7 @@ int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInt
         {
             std::lock_guard<std::mutex> q(q_mu_);
             precreate_left_.store(num_pages_);
+            precreate_floor_ = num_pages_ > kPrecreateAhead ? num_pages_ - kPrecreateAhead : 0;
         }
         q_cv_.notify_all();
     }
@@ -553,6 +558,13 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async) {   // e
             runs.emplace_back(op.tensor, op.offset, page);
         } else {
             if (flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; break; }
+            if (!unmapped && be_.quiesce) {
+                // first unmap of the batch: kernels launched earlier may still read the pages being reclaimed
+                const uint64_t q0 = now_ns();
+                if (be_.quiesce(be_.ctx) != 0) { async_error_msg_ = "device synchronisation before unmap failed"; rc = VATTN_ERR_DRIVER; break; }
+                st_.quiesce_calls++;
+                st_.quiesce_ns += now_ns() - q0;
+            }
             if (be_.unmap(be_.ctx, bases_[op.tensor] + op.offset, page) != 0) {
                 async_error_msg_ = "hipMemUnmap failed";
                 rc = VATTN_ERR_DRIVER;
@@ -645,7 +657,7 @@ void PageManager::mapper_main() {
             for (uint64_t i = 0; i < kPrecreateSlice; i++) {
                 const uint64_t left = precreate_left_.load();
                 if (left == 0) break;
-                if (left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) { precreate_left_.store(0); break; }
+                if (left <= precreate_floor_ || left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) { precreate_left_.store(0); break; }
                 precreate_left_.store(left - 1);
             }
         }

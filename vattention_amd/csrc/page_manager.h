@@ -106,6 +106,7 @@ private:
     std::vector<uint8_t> created_;
     std::atomic<uint64_t> precreate_left_{0};   // ids [0, precreate_left_) still to be looked at, top down
     std::atomic<uint64_t> join_wait_ns_{0};
+    uint64_t precreate_floor_ = 0;              // ids below this are created on first use only
     std::mutex exec_mu_;                         // serialises driver calls
     std::mutex q_mu_;
     std::condition_variable q_cv_, done_cv_;

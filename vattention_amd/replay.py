@@ -107,6 +107,7 @@ class ReplayStats:
     decode_tokens: int = 0
     kv_util_samples: List[float] = field(default_factory=list)     # live-token bytes / mapped bytes
     mapped_over_reserved: List[float] = field(default_factory=list)
+    kv_needed_samples: List[tuple] = field(default_factory=list)   # (live / needed-page tokens, active slots)
 
 
 class HotPathRunner:
@@ -190,6 +191,10 @@ class HotPathRunner:
         live = sum(self.engine.curr_seq_lens)
         if mapped_tokens:
             self.stats.kv_util_samples.append(live / mapped_tokens)
+        if c["needed_groups"]:
+            # internal fragmentation only: pages a LIVE sequence needs vs the tokens it holds (pages kept mapped under
+            # finished slots by deferred reclamation are cache, reclaimable on demand, not fragmentation)
+            self.stats.kv_needed_samples.append((live / (c["needed_groups"] * tpp), c["active_slots"]))
         pages_per_group = 2 if self.engine.vattn_mega_cache else 2 * self.L
         reserved_tokens = (c["pool_pages"] // pages_per_group) * tpp + mapped_tokens
         if reserved_tokens:
@@ -285,6 +290,9 @@ class HotPathRunner:
             "kv_live_over_mapped_mean": sum(u) / max(1, len(u)),
             "kv_live_over_mapped_at_high_concurrency": (sum(out["util_at_peak"]) / len(out["util_at_peak"])) if out["util_at_peak"] else None,
             "mapped_over_pool_max": max(self.stats.mapped_over_reserved) if self.stats.mapped_over_reserved else None,
+            "kv_live_over_needed_mean": (sum(x for x, _ in self.stats.kv_needed_samples) / max(1, len(self.stats.kv_needed_samples))),
+            "kv_live_over_needed_at_peak": min((x for x, a in self.stats.kv_needed_samples if a >= 0.9 * out["peak_running"]), default=None),
+            "slack_tokens_per_seq_at_peak_max": max(((1 - x) * 1.0 for x, a in self.stats.kv_needed_samples if a >= 0.9 * out["peak_running"]), default=None),
             "tokens_per_page": tpp,
             "map_calls": vm1["map_calls"] - vm0["map_calls"], "unmap_calls": vm1["unmap_calls"] - vm0["unmap_calls"],
             "sync_map_ms": (vm1["sync_ns"] - vm0["sync_ns"]) / 1e6, "async_map_ms": (vm1["async_ns"] - vm0["async_ns"]) / 1e6,
