@@ -234,6 +234,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
             qf[qc][kk] = as_v8<V8>(v);
         }
     }
+    // Retire the Q loads HERE and make that visible to hipcc's wait-count pass: otherwise it keeps a conservative
+    // "Q may still be in flight" state around the loop and puts a vmcnt wait in front of the first MFMA of every
+    // tile, which also drains the K/V prefetch issued a moment earlier (vmcnt(0) = 0x0F70: expcnt/lgkmcnt untouched).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+    for (int qc = 0; qc < QC; qc++)
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) asm volatile("" : "+v"(qf[qc][kk]));
 
     f32x16 o[DB][QC];
 #pragma unroll
@@ -245,7 +253,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
     for (int qc = 0; qc < QC; qc++) { m_run[qc] = -INFINITY; l_run[qc] = 0.f; }
     const float sc = p.softmax_scale * kLog2e;
 
-    uint4 kreg[PASSES], vreg[PASSES];
+    // two register sets: the loads of tile t+2 are issued while tile t is computed and are only consumed (stored to
+    // LDS) at the end of iteration t+1 -> a two-iteration latency budget instead of one (L2/MALL latency under load
+    // is about one tile time)
+    uint4 kregA[PASSES], vregA[PASSES], kregB[PASSES], vregB[PASSES];
     const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
     // per-thread byte offsets inside a tile (row-major rows of the cache, 16-byte chunk c)
     unsigned koff[PASSES], voff[PASSES];
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
     }
     const T* kbase_u = uniform_ptr(kbase);
     const T* vbase_u = uniform_ptr(vbase);
-    auto stage_load = [&](int t) {
+    auto stage_load = [&](int t, uint4 (&kreg)[PASSES], uint4 (&vreg)[PASSES]) {
         // descriptor rebased per tile: rows at or beyond Lk fall outside num_records -> zeros, no access
         int rem = Lk - t * PF_BN;
         rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
             vreg[ps] = buf_load16(vr, voff[ps]);
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int buf, const uint4 (&kreg)[PASSES], const uint4 (&vreg)[PASSES]) {
         char* ksm = smem + buf * S::kBufBytes;
         char* vsm = ksm + S::kTileBytes;
 #pragma unroll
@@ -285,14 +296,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
     };
 
     if (nt > 0) {
-        stage_load(0);
-        stage_write(0);
+        stage_load(0, kregA, vregA);
+        stage_write(0, kregA, vregA);
+        stage_load(1, kregB, vregB);
     }
     __syncthreads();
 
-    for (int t = 0; t < nt; t++) {
+    auto tile_body = [&](int t, uint4 (&kld)[PASSES], uint4 (&vld)[PASSES], const uint4 (&kwr)[PASSES], const uint4 (&vwr)[PASSES]) {
         const int buf = t & 1;
-        if (VATTN_ABLATE != 4) stage_load(t + 1);     // in flight across the whole compute phase (past the last tile: all lanes out of range)
+        if (VATTN_ABLATE != 4) stage_load(t + 2, kld, vld);     // two tiles ahead (past the last tile: all lanes out of range)
 
         const int n0 = t * PF_BN;
         // wave-uniform tile classification
@@ -420,8 +432,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
                     }
                 }
         }
-        if (VATTN_ABLATE != 4) stage_write(buf ^ 1);   // buffer last read in iteration t-1; every wave passed that barrier
+        if (VATTN_ABLATE != 4) stage_write(buf ^ 1, kwr, vwr);   // tile t+1 (issued one iteration ago) into the buffer last read in iteration t-1
         if (VATTN_ABLATE != 5 && VATTN_ABLATE != 4) __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 2) {
+        tile_body(t, kregA, vregA, kregB, vregB);
+        if (t + 1 < nt) tile_body(t + 1, kregB, vregB, kregA, vregA);
     }
 
     // ---- epilogue: O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
