@@ -63,7 +63,7 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
         assert torch.equal(kgi.cpu(), kc1) and torch.equal(vgi.cpu(), vc1)     # in-place append, bit-exact, nothing else touched
 
 
-@pytest.mark.parametrize("variant", [0, 1, 8, 4, 6], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8_pipelined"])
+@pytest.mark.parametrize("variant", [0, 1, 8, 4, 6, 16, 10], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8_pipelined", "w8q1_mfma_rowsum", "w8_staggered"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("n,c,Hq,Hkv", [
     (128, 0, 8, 2), (1, 5, 4, 4), (200, 0, 4, 1), (77, 333, 8, 4), (512, 1000, 4, 2), (130, 62, 2, 2), (64, 64, 4, 2),

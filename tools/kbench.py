@@ -107,7 +107,7 @@ if __name__ == "__main__":
     torch.zeros(1, device=DEV)
     if "prefill" in what:
         for v in ([variant] if "--variant" in sys.argv else [0, 8, 6]):
-            print("-- prefill variant %d (tiling %s) --" % (v, {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined", 4: "4 waves x 32 rows"}[(v >> 1) & 7]))
+            print("-- prefill variant %d (tiling %s) --" % (v, {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined", 4: "4 waves x 32 rows", 5: "8 waves, phase-staggered halves"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
         decode(variant)

@@ -110,11 +110,11 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
             with self.get_timer(OperationMetrics.ATTN_KV_CACHE_SAVE, layer_id):
                 cache_flat(k, v, k_rows[c_len:], v_rows[c_len:], "auto")
             with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id):
-                o = flash_attn_with_kvcache(q, k_rows.unsqueeze(0), v_rows.unsqueeze(0),
-                                            cache_seqlens=self.current_total_len_device_lst[i],
-                                            causal=True, softmax_scale=softmax_scale)
-            with self.get_timer(OperationMetrics.ATTN_OUTPUT_RESHAPE, layer_id):
-                output[tok:tok + q_len].copy_(o.view(q_len, Hq * D))
+                # the kernel writes straight into this sequence's rows of `output` (no [q_len, Hq*D] copy afterwards)
+                flash_attn_with_kvcache(q, k_rows.unsqueeze(0), v_rows.unsqueeze(0),
+                                        cache_seqlens=self.current_total_len_device_lst[i],
+                                        causal=True, softmax_scale=softmax_scale,
+                                        out=output[tok:tok + q_len].view(1, q_len, Hq, D))
             tok += q_len
         if self.decode_batch_size == 0:
             return output
@@ -124,10 +124,9 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
             dk = key[tok:tok + nb].view(nb, 1, Hkv, D)
             dv = value[tok:tok + nb].view(nb, 1, Hkv, D)
         with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id):
-            o = flash_attn_with_kvcache(dq, k_all[:, :self.max_cache_len], v_all[:, :self.max_cache_len], dk, dv,
-                                        cache_seqlens=self.decode_cache_lens, block_table=None,
-                                        softmax_scale=softmax_scale, causal=True,
-                                        cache_batch_idx=self.batch_index_gen)
-        with self.get_timer(OperationMetrics.ATTN_OUTPUT_RESHAPE, layer_id):
-            output[tok:tok + nb].copy_(o.view(nb, Hq * D))
+            flash_attn_with_kvcache(dq, k_all[:, :self.max_cache_len], v_all[:, :self.max_cache_len], dk, dv,
+                                    cache_seqlens=self.decode_cache_lens, block_table=None,
+                                    softmax_scale=softmax_scale, causal=True,
+                                    cache_batch_idx=self.batch_index_gen,
+                                    out=output[tok:tok + nb].view(nb, 1, Hq, D))
         return output

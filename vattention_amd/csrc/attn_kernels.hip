@@ -169,6 +169,10 @@ constexpr int PF_BN = 64;              // keys per tile
 #ifndef VATTN_ABLATE
 #define VATTN_ABLATE 0
 #endif
+#ifndef VATTN_ABLATE_MASK
+#define VATTN_ABLATE_MASK (VATTN_ABLATE ? (1 << VATTN_ABLATE) : 0)
+#endif
+#define ABL(k) ((VATTN_ABLATE_MASK >> (k)) & 1)
 
 template <int HD> struct PfSmem {
     static constexpr int kRowBytes = HD * 2;
@@ -181,7 +185,9 @@ template <int HD> struct PfSmem {
 // WAVES waves per workgroup, each owning QC blocks of 32 query rows (BM = 32*QC*WAVES rows per workgroup).
 // QC = 2 halves the LDS fragment traffic per flop (each K / V^T fragment read feeds two MFMAs) at the price
 // of a 512-register budget (one wave per SIMD).
-template <typename T, int HD, bool USE_TR, int WAVES, int QC>
+// MSUM: the softmax denominator is accumulated by the matrix pipe (one extra MFMA per 16 keys with an all-ones A
+// fragment, no LDS read) instead of 32 dependent v_add per tile: the kernel is VALU/issue-bound, the matrix pipe has slack.
+template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
 __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC == 2 ? 1 : 2)) void prefill_kernel(vattn_attn_params p) {
     using X = Tr<T>;
     using V8 = typename X::v8;
@@ -249,8 +255,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
 #pragma unroll
         for (int qc = 0; qc < QC; qc++) o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float m_run[QC], l_run[QC];   // running max of raw scores (same in both half-lanes); lane-local partial sums
+    f32x16 lacc[QC];              // MSUM: every row of this accumulator holds the query's running denominator
+    V8 ones;
 #pragma unroll
-    for (int qc = 0; qc < QC; qc++) { m_run[qc] = -INFINITY; l_run[qc] = 0.f; }
+    for (int j = 0; j < 8; j++) ones[j] = X::cvt(1.0f);
+#pragma unroll
+    for (int qc = 0; qc < QC; qc++) {
+        m_run[qc] = -INFINITY;
+        l_run[qc] = 0.f;
+        lacc[qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
     const float sc = p.softmax_scale * kLog2e;
 
     // two register sets: the loads of tile t+2 are issued while tile t is computed and are only consumed (stored to
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
 
     auto tile_body = [&](int t, uint4 (&kld)[PASSES], uint4 (&vld)[PASSES], const uint4 (&kwr)[PASSES], const uint4 (&vwr)[PASSES]) {
         const int buf = t & 1;
-        if (VATTN_ABLATE != 4) stage_load(t + 2, kld, vld);     // two tiles ahead (past the last tile: all lanes out of range)
+        if (!ABL(4)) stage_load(t + 2, kld, vld);     // two tiles ahead (past the last tile: all lanes out of range)
 
         const int n0 = t * PF_BN;
         // wave-uniform tile classification
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
             // accumulate latency of one chain is covered by the other chain's issue slot; the K fragments of
             // step kk+1 are read from LDS while the MFMAs of step kk run (explicit two-deep register ring)
             auto kfrag = [&](int kb, int kk) -> V8 {
-                if (VATTN_ABLATE == 3) return qf[0][(kk + kb) % KK];
+                if (ABL(3)) return qf[0][(kk + kb) % KK];
                 return *(const V8*)(ksm + (kb * 32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
             };
             V8 a_cur[2], a_nxt[2];
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
             float alpha[QC];
 #pragma unroll
             for (int qc = 0; qc < QC; qc++) {
-                if (VATTN_ABLATE == 6) { alpha[qc] = 1.f; continue; }
+                if (ABL(6)) { alpha[qc] = 1.f; continue; }
                 if (need_mask) {
                     const int my_q = qw0 + 32 * qc + l31;
                     const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;     // last visible key for this query
@@ -382,11 +396,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         float e;
-                        if (VATTN_ABLATE == 1) e = s[kb][qc][r] * sc; else e = fast_exp2(__builtin_fmaf(s[kb][qc][r], sc, -msub));
+                        if (ABL(1)) e = s[kb][qc][r] * sc; else e = fast_exp2(__builtin_fmaf(s[kb][qc][r], sc, -msub));
                         s[kb][qc][r] = e;
-                        psum += e;
+                        if (!MSUM) psum += e;
                     }
-                l_run[qc] = l_run[qc] * alpha[qc] + psum;
+                if (!MSUM) l_run[qc] = l_run[qc] * alpha[qc] + psum;
                 // O only needs rescaling when some row's running max actually moved (rare after the first
                 // tiles); the test is exact (alpha == 1 otherwise) and wave-uniform
                 if (__builtin_amdgcn_ballot_w64(alpha[qc] != 1.0f) != 0) {
@@ -394,6 +408,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
                     for (int i = 0; i < DB; i++)
 #pragma unroll
                         for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha[qc];
+                    if (MSUM) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) lacc[qc][r] *= alpha[qc];
+                    }
                 }
             }
 
@@ -408,10 +426,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
 #pragma unroll
                         for (int j = 0; j < 8; j++) pf[qc][j] = X::cvt(s[kb][qc][8 * u + j]);
                     const int krow0 = kb * 32 + 16 * u;
+                    if (MSUM) {
+#pragma unroll
+                        for (int qc = 0; qc < QC; qc++) lacc[qc] = X::mfma32(ones, pf[qc], lacc[qc]);
+                    }
 #pragma unroll
                     for (int db = 0; db < DB; db++) {
                         V8 a;
-                        if (VATTN_ABLATE == 2) {
+                        if (ABL(2)) {
                             a = qf[0][(db + u + 2 * kb) % KK];
                         } else if constexpr (USE_TR) {
                             const int i16 = lane & 15, dh = (lane >> 4) & 1;
@@ -432,8 +454,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
                     }
                 }
         }
-        if (VATTN_ABLATE != 4) stage_write(buf ^ 1, kwr, vwr);   // tile t+1 (issued one iteration ago) into the buffer last read in iteration t-1
-        if (VATTN_ABLATE != 5 && VATTN_ABLATE != 4) __syncthreads();
+        if (!ABL(4)) stage_write(buf ^ 1, kwr, vwr);   // tile t+1 (issued one iteration ago) into the buffer last read in iteration t-1
+        if (!ABL(5) && !ABL(4)) __syncthreads();
     };
     for (int t = 0; t < nt; t += 2) {
         tile_body(t, kregA, vregA, kregB, vregB);
@@ -444,7 +466,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
 #pragma unroll
     for (int qc = 0; qc < QC; qc++) {
         const int my_q = qw0 + 32 * qc + l31;
-        const float l_tot = l_run[qc] + swap_halves(l_run[qc]);
+        const float l_tot = MSUM ? lacc[qc][0] : (l_run[qc] + swap_halves(l_run[qc]));
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
         if (my_q < Sq) {
             T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
@@ -462,6 +484,226 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
                 const float lse = (l_tot == 0.f) ? INFINITY : (m_run[qc] * p.softmax_scale + __logf(l_tot));
                 p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
             }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Phase-staggered prefill (8 waves, 32 query rows each).  In the plain kernel all waves of a workgroup are
+// phase-locked by the per-tile barrier: the two waves that share a SIMD run their QK^T MFMAs at the same
+// time, then their softmax VALU at the same time, then PV — the matrix pipe and the VALU never overlap.
+// Here a tile has TWO barrier-separated intervals and the two halves of the workgroup (waves 0-3 / 4-7,
+// one wave of each half per SIMD) are offset by half a tile:
+//     interval 1 of tile t:  half 0  S=QK(t), softmax(t)      |  half 1  PV(t-1)
+//     interval 2 of tile t:  half 0  PV(t)                    |  half 1  S=QK(t), softmax(t)
+// so on every SIMD one wave's softmax (VALU) always runs beside the other wave's PV (matrix pipe).
+// LDS: K(t) in K[t&1] (read in both intervals of tile t), V(t) in V[t&1] (read in interval 2 of t and interval 1
+// of t+1); the data of tile t+1 is stored by every wave during interval 2 of tile t.
+// --------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(512, 2) void prefill_stag_kernel(vattn_attn_params p) {
+    using X = Tr<T>;
+    using V8 = typename X::v8;
+    using S = PfSmem<HD>;
+    constexpr int WAVES = 8, NT = 64 * WAVES, BM = 32 * WAVES;
+    constexpr int KK = HD / 16, DB = HD / 32, CPR = HD / 8;
+    constexpr int PASSES = (PF_BN * CPR) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ksm0 = smem;
+    char* const vsm0 = smem + 2 * S::kTileBytes;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2;
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+    const int b = blockIdx.z;
+    const int h = blockIdx.y;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+    const int hk = h / (p.h / p.h_k);
+    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+    const int Sq = p.seqlen_q;
+    const bool causal = p.is_causal != 0;
+    const int off = Lk - Sq;
+    const int q_wg0 = qb * BM;
+    const int qw0 = q_wg0 + wave * 32;
+    const int my_q = qw0 + l31;
+
+    int n_end = Lk;
+    if (causal) n_end = min(Lk, q_wg0 + BM + off);
+    if (n_end < 0) n_end = 0;
+    const int nt = (n_end + PF_BN - 1) / PF_BN;
+    int t_live = nt;      // tiles [0, t_live) hold at least one visible (row, key) pair for this wave
+    if (causal) {
+        const int last_key = qw0 + 31 + off;
+        t_live = last_key < 0 ? 0 : min(nt, last_key / PF_BN + 1);
+    }
+
+    const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
+    const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
+    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
+
+    V8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+        qf[kk] = as_v8<V8>(v);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) asm volatile("" : "+v"(qf[kk]));
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; i++) o[i] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f, alpha = 1.f;
+    f32x16 s0, s1;     // S^T / P^T of the wave's current tile (key blocks 0 and 1)
+    const float sc = p.softmax_scale * kLog2e;
+
+    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
+    unsigned koff[PASSES], voff[PASSES], klds[PASSES], vlds[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int idx = ps * NT + tid;
+        const int row = idx / CPR, c = idx % CPR;
+        koff[ps] = (unsigned)row * k_rs_bytes + (unsigned)c * 16u;
+        voff[ps] = (unsigned)row * v_rs_bytes + (unsigned)c * 16u;
+        klds[ps] = (unsigned)(row * S::kRowBytes + ((c ^ (row & 15)) << 4));
+        vlds[ps] = (unsigned)((c >> 2) * S::kVSubBytes + row * 64 + ((c & 3) << 4));
+    }
+    const T* kbase_u = uniform_ptr(kbase);
+    const T* vbase_u = uniform_ptr(vbase);
+    uint4 kreg[PASSES], vreg[PASSES];
+    auto issue_loads = [&](int t) {
+        int rem = Lk - t * PF_BN;
+        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
+        const __amdgpu_buffer_rsrc_t kr = make_rsrc(kbase_u + (int64_t)t * PF_BN * p.k_row_stride, (unsigned)rem * k_rs_bytes);
+        const __amdgpu_buffer_rsrc_t vr = make_rsrc(vbase_u + (int64_t)t * PF_BN * p.v_row_stride, (unsigned)rem * v_rs_bytes);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            kreg[ps] = buf_load16(kr, koff[ps]);
+            vreg[ps] = buf_load16(vr, voff[ps]);
+        }
+    };
+    auto write_tile = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            *(uint4*)(ksm0 + buf * S::kTileBytes + klds[ps]) = kreg[ps];
+            *(uint4*)(vsm0 + buf * S::kTileBytes + vlds[ps]) = vreg[ps];
+        }
+    };
+    auto qk_softmax = [&](int t) {
+        if (t >= t_live) return;
+        const char* ksm = ksm0 + (t & 1) * S::kTileBytes;
+        const int n0 = t * PF_BN;
+        s0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        s1 = s0;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            const V8 a0 = *(const V8*)(ksm + l31 * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
+            const V8 a1 = *(const V8*)(ksm + (32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
+            s0 = X::mfma32(a0, qf[kk], s0);
+            s1 = X::mfma32(a1, qf[kk], s1);
+        }
+        if ((n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off))) {
+            const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = n0 + 8 * (r >> 2) + 4 * g + (r & 3);
+                if (key > lim) s0[r] = -INFINITY;
+                if (key + 32 > lim) s1[r] = -INFINITY;
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+        mloc = fmaxf(mloc, swap_halves(mloc));
+        const float m_new = fmaxf(m_run, mloc);
+        const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
+        alpha = fast_exp2(m_run * sc - msub);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            s0[r] = fast_exp2(__builtin_fmaf(s0[r], sc, -msub));
+            s1[r] = fast_exp2(__builtin_fmaf(s1[r], sc, -msub));
+            psum += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + psum;
+    };
+    auto pv = [&](int t) {
+        if (t >= t_live) return;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int i = 0; i < DB; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+        }
+        const char* vsm = vsm0 + (t & 1) * S::kTileBytes;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                V8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; j++) pf[j] = X::cvt(kb == 0 ? s0[8 * u + j] : s1[8 * u + j]);
+                const int krow0 = kb * 32 + 16 * u;
+#pragma unroll
+                for (int db = 0; db < DB; db++) {
+                    const int i16 = lane & 15, dh = (lane >> 4) & 1;
+                    const char* a1 = vsm + db * S::kVSubBytes + (krow0 + 4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
+                    o[db] = X::mfma32(join_tr<V8>(lo, hi), pf, o[db]);
+                }
+            }
+    };
+
+    issue_loads(0);
+    write_tile(0);
+    __syncthreads();                                   // A_0
+    if (half == 0) {
+        for (int t = 0; t < nt; t++) {
+            issue_loads(t + 1);
+            qk_softmax(t);                             // interval 1 of tile t
+            __syncthreads();                           // B_t
+            pv(t);                                     // interval 2 of tile t
+            write_tile((t + 1) & 1);
+            __syncthreads();                           // A_{t+1}
+        }
+        __syncthreads();                               // B_nt (half 1 finishes PV(nt-1))
+    } else {
+        issue_loads(1);
+        __syncthreads();                               // B_0 (nothing to do in interval 1 of tile 0)
+        for (int t = 0; t < nt; t++) {
+            qk_softmax(t);                             // interval 2 of tile t
+            write_tile((t + 1) & 1);
+            __syncthreads();                           // A_{t+1}
+            issue_loads(t + 2);
+            pv(t);                                     // interval 1 of tile t+1
+            __syncthreads();                           // B_{t+1}
+        }
+    }
+
+    const float l_tot = l_run + swap_halves(l_run);
+    const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+    if (my_q < Sq) {
+        T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int tq = 0; tq < 4; tq++) {
+                typename X::v4 w;
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][4 * tq + e] * inv);
+                *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+            }
+        if (p.softmax_lse && g == 0) {
+            const float lse = (l_tot == 0.f) ? INFINITY : (m_run * p.softmax_scale + __logf(l_tot));
+            p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
         }
     }
 }
@@ -1112,21 +1354,21 @@ void launch_append(const vattn_attn_params* p, hipStream_t st) {
     hipLaunchKernelGGL(append_kv_kernel, grid, block, 0, st, *p);
 }
 
-template <typename T, int WAVES, int QC> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
+template <typename T, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
     constexpr int BM = 32 * QC * WAVES;
     const int nqb = (p->seqlen_q + BM - 1) / BM;
     dim3 grid(nqb, p->h, p->b), block(64 * WAVES);
     const size_t smem = PfSmem<128>::kTotal;
     static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
-        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, true, WAVES, QC>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, false, WAVES, QC>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, false, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
         return true;
     }();
     (void)attr_once;
     if (use_tr)
-        hipLaunchKernelGGL((prefill_kernel<T, 128, true, WAVES, QC>), grid, block, smem, st, *p);
+        hipLaunchKernelGGL((prefill_kernel<T, 128, true, WAVES, QC, MSUM>), grid, block, smem, st, *p);
     else
-        hipLaunchKernelGGL((prefill_kernel<T, 128, false, WAVES, QC>), grid, block, smem, st, *p);
+        hipLaunchKernelGGL((prefill_kernel<T, 128, false, WAVES, QC, MSUM>), grid, block, smem, st, *p);
 }
 
 template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
@@ -1151,7 +1393,15 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
         // 0 = default (8 waves x 32 rows: best or within noise on 6 of 7 measured shapes, profiles/r01_kbench.md);
         // 1 = same, explicit; 2 = 4 waves x 64 rows; 3 = software-pipelined 8-wave; 4 = 4 waves x 32 rows
         const int tiling = (p->variant >> 1) & 7;
-        if (tiling == 3) {
+        if (tiling == 5) {
+            const int nqb = (p->seqlen_q + 255) / 256;
+            static const bool once5 = [] {
+                (void)hipFuncSetAttribute((const void*)prefill_stag_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+                return true;
+            }();
+            (void)once5;
+            hipLaunchKernelGGL((prefill_stag_kernel<T, 128>), dim3(nqb, p->h, p->b), dim3(512), PfSmem<128>::kTotal, st, *p);
+        } else if (tiling == 3) {
             constexpr int W = 8;
             const int nqb = (p->seqlen_q + 32 * W - 1) / (32 * W);
             static const bool once = [] {
@@ -1160,9 +1410,10 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
             }();
             (void)once;
             hipLaunchKernelGGL((prefill_pipe_kernel<T, 128, W>), dim3(nqb, p->h, p->b), dim3(64 * W), PfSmem<128>::kTotal, st, *p);
-        } else if (tiling == 2) launch_prefill<T, 4, 2>(p, st, use_tr);
-        else if (tiling == 4) launch_prefill<T, 4, 1>(p, st, use_tr);
-        else launch_prefill<T, 8, 1>(p, st, use_tr);
+        } else if (tiling == 2) launch_prefill<T, 4, 2, false>(p, st, use_tr);
+        else if (tiling == 4) launch_prefill<T, 4, 1, false>(p, st, use_tr);
+        else if (p->variant & 16) launch_prefill<T, 8, 1, true>(p, st, use_tr);      // denominator on the matrix pipe
+        else launch_prefill<T, 8, 1, false>(p, st, use_tr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));

@@ -45,7 +45,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             cache_batch_idx: Optional[torch.Tensor] = None, cache_leftpad=None, block_table=None,
                             softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                             rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
-                            _variant=0):
+                            out=None, _variant=0):
     if rotary_cos is not None or rotary_sin is not None:
         raise NotImplementedError("rotary embedding inside flash_attn_with_kvcache is not used by the vAttention path")
     if block_table is not None:
@@ -89,7 +89,13 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
         if Sn > Sk:
             raise RuntimeError(APPEND_ERR)
         assert k.shape == (B, Sn, Hkv, D) and v.shape == (B, Sn, Hkv, D)
-    out = torch.empty_like(q)
+    if out is None:        # `out` mirrors the optional out_ of the reference's C++ entry point (flash_api.cpp:1303)
+        out = torch.empty_like(q)
+    else:
+        if out.dtype != q.dtype:
+            raise RuntimeError("Output must have the same dtype as inputs")
+        if out.shape != q.shape or out.stride(-1) != 1:
+            raise RuntimeError("Output tensor must have the shape of q and a contiguous last dimension")
     lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev) if return_softmax_lse else None
 
     p = K.AttnParams()
