@@ -200,6 +200,8 @@ def replay(impl, ops: List[list], full: bool = False) -> List[dict]:
             ret = _apply(impl, op)
         except RuntimeError as e:           # pybind maps std::runtime_error -> RuntimeError
             err = str(e)
+        except ValueError as e:             # explicit argument errors (reference: assert / undefined behaviour)
+            err = "ValueError: " + str(e)
         snap = impl.snapshot(full)
         rec = {"ret": ret, "err": err}
         rec.update(snap)

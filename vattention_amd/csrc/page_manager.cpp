@@ -377,6 +377,11 @@ int PageManager::map_common_pages(uint64_t num_tokens) {   // vattention.cu:325-
     const uint64_t nblocks = tokens_to_pages(num_tokens);
     if (nblocks == 0) return VATTN_OK;
     if (!kvblocks_available(nblocks)) return fail(VATTN_ERR_OOM, "***** OOM on demand: not enough free pages to continue *****");
+    // The reference has no bound here (no is_valid_offset in map_common_pages_in_batch, vattention.cu:325-373): a slot that
+    // already holds max_pages_per_req pages would be mapped INTO THE NEXT SLOT's range (or past the reservation).  Refuse.
+    for (uint32_t r = 0; r < cfg_.max_batch_size; r++)
+        if (mapped_pages_[r] + nblocks > max_pages_per_req_)
+            return fail(VATTN_ERR_INVALID, "map_common_pages: a slot would exceed max_pages_per_req");
     int err = VATTN_OK;
     for (uint64_t c = 0; c < nblocks && !err; c++) {
         const uint32_t nl = cfg_.megacache ? 1 : cfg_.num_layers;
