@@ -97,6 +97,32 @@ def test_prefill_chunk_parity(n, c, Hq, Hkv, dtype, variant):
     _check(out, ref64, ref32, dtype, "prefill n=%d c=%d" % (n, c))
 
 
+@pytest.mark.parametrize("Hq,Hkv", [(8, 1), (8, 2), (8, 4), (8, 8), (6, 3), (16, 16), (12, 4)])
+def test_prefill_workgroup_orders(Hq, Hkv):
+    """The three workgroup->(batch, head, query block) mappings (variant bits 5-6; XCD-grouped default, its fallback for
+    kv-head counts that do not divide the 8 XCDs) cover every (b, h, block) exactly once: parity with the oracle on a ragged
+    batch with several query blocks, and bit-identical outputs across mappings."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(Hq * 31 + Hkv)
+    B, n, D, ctx = 3, 600, 128, 1400
+    q = torch.randn(B, n, Hq, D).half()
+    kc = torch.randn(4, ctx, Hkv, D).half()
+    vc = torch.randn(4, ctx, Hkv, D).half()
+    cl = torch.tensor([n + 700, n, n + 129], dtype=torch.int32)
+    idx = torch.tensor([2, 0, 3], dtype=torch.int32)
+    ref64 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+    ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
+    outs = []
+    for variant in (32, 64, 0, 96):
+        out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
+                                      causal=True, _variant=variant)
+        torch.cuda.synchronize()
+        _check(out, ref64, ref32, torch.float16, "order variant %d" % variant)
+        outs.append(out.cpu())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_prefill_non_causal_and_seqlen_q_gt_k():
     from vattention_amd.flash_attn import flash_attn_func, flash_attn_with_kvcache
     torch.manual_seed(5)

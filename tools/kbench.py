@@ -103,11 +103,14 @@ if __name__ == "__main__":
         ONLY = sys.argv[sys.argv.index("--only") + 1]
     if "--variant" in sys.argv:
         variant = int(sys.argv[sys.argv.index("--variant") + 1])
+    VARIANTS = [variant] if "--variant" in sys.argv else [0, 8, 6]
+    if "--variants" in sys.argv:
+        VARIANTS = [int(x) for x in sys.argv[sys.argv.index("--variants") + 1].split(",")]
     what = [a for a in sys.argv[1:] if a in ("prefill", "decode")] or ["prefill", "decode"]
     torch.zeros(1, device=DEV)
     if "prefill" in what:
-        for v in ([variant] if "--variant" in sys.argv else [0, 8, 6]):
-            print("-- prefill variant %d (tiling %s) --" % (v, {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined", 4: "4 waves x 32 rows", 5: "8 waves, phase-staggered halves"}[(v >> 1) & 7]))
+        for v in VARIANTS:
+            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3], {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined", 4: "4 waves x 32 rows", 5: "8 waves, phase-staggered halves"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
         decode(variant)

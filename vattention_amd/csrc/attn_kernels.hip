@@ -188,7 +188,7 @@ template <int HD> struct PfSmem {
 // MSUM: the softmax denominator is accumulated by the matrix pipe (one extra MFMA per 16 keys with an all-ones A
 // fragment, no LDS read) instead of 32 dependent v_add per tile: the kernel is VALU/issue-bound, the matrix pipe has slack.
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC == 2 ? 1 : 2)) void prefill_kernel(vattn_attn_params p) {
+__global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC == 2 ? 1 : 2)) void prefill_kernel(vattn_attn_params p, int order, int nqb) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     using S = PfSmem<HD>;
@@ -206,9 +206,35 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
     const int l31 = lane & 31;
     const int g = lane >> 5;
 
-    const int b = blockIdx.z;
-    const int h = blockIdx.y;
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;      // heaviest (last) query blocks first
+    // Workgroup -> (batch entry, head, query block).  The dispatcher hands consecutive workgroup ids to consecutive
+    // XCDs (id & 7), each with its own L2, and starts them in id order.  order 2 (default) makes every XCD stream ONE kv
+    // head (its L2 then holds a single K/V stream that the G query heads x neighbouring query blocks running there share)
+    // and walks the query blocks heaviest-first across ALL heads, so the workgroups running at any time have near-equal
+    // lengths and move down K/V in step.  order 1: heaviest-first across heads without the XCD grouping.
+    // order 0: grid (query block, head, batch) - block-major per head.
+    int b, h, qb;
+    if (order == 0) {
+        b = blockIdx.z; h = blockIdx.y; qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+    } else {
+        const int L = blockIdx.x;
+        const int G = p.h / p.h_k;
+        if (order == 2) {
+            const int per = 8 / p.h_k;                         // XCDs per kv head (launch guarantees 8 % h_k == 0)
+            const int xcd = L & 7;
+            int t = (L >> 3) * per + xcd / p.h_k;
+            const int g = t % G; t /= G;
+            b = t % p.b;
+            const int qbr = t / p.b;
+            if (qbr >= nqb) return;
+            h = (xcd % p.h_k) * G + g;
+            qb = nqb - 1 - qbr;
+        } else {
+            h = L % p.h;
+            const int t = L / p.h;
+            b = t % p.b;
+            qb = nqb - 1 - t / p.b;
+        }
+    }
     const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
     // loaded values are wave-uniform; readfirstlane makes that provable (descriptors must live in SGPRs)
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
@@ -1357,7 +1383,18 @@ void launch_append(const vattn_attn_params* p, hipStream_t st) {
 template <typename T, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
     constexpr int BM = 32 * QC * WAVES;
     const int nqb = (p->seqlen_q + BM - 1) / BM;
+    // variant bits 5-6: workgroup order (see the kernel): 0 = default (XCD-grouped when the kv heads divide the 8 XCDs),
+    // 1 = block-major per head (3-D grid), 2 = heaviest-first across heads, 3 = XCD-grouped
+    int order = (p->variant >> 5) & 3;
+    order = order == 0 ? 2 : order - 1;
+    if (order == 2 && !(p->h_k <= 8 && 8 % p->h_k == 0)) order = 1;
     dim3 grid(nqb, p->h, p->b), block(64 * WAVES);
+    if (order == 1) grid = dim3((unsigned)(nqb * p->h * p->b));
+    if (order == 2) {
+        const int per = 8 / p->h_k;
+        const long items = (long)nqb * p->b * (p->h / p->h_k);   // per kv head
+        grid = dim3((unsigned)(8 * ((items + per - 1) / per)));
+    }
     const size_t smem = PfSmem<128>::kTotal;
     static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
@@ -1366,9 +1403,9 @@ template <typename T, int WAVES, int QC, bool MSUM> void launch_prefill(const va
     }();
     (void)attr_once;
     if (use_tr)
-        hipLaunchKernelGGL((prefill_kernel<T, 128, true, WAVES, QC, MSUM>), grid, block, smem, st, *p);
+        hipLaunchKernelGGL((prefill_kernel<T, 128, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
     else
-        hipLaunchKernelGGL((prefill_kernel<T, 128, false, WAVES, QC, MSUM>), grid, block, smem, st, *p);
+        hipLaunchKernelGGL((prefill_kernel<T, 128, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
 }
 
 template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
