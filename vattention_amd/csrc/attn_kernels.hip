@@ -1429,7 +1429,11 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
         if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
         // 0 = default (8 waves x 32 rows: best or within noise on 6 of 7 measured shapes, profiles/r01_kbench.md);
         // 1 = same, explicit; 2 = 4 waves x 64 rows; 3 = software-pipelined 8-wave; 4 = 4 waves x 32 rows
-        const int tiling = (p->variant >> 1) & 7;
+        int tiling = (p->variant >> 1) & 7;
+        // default: 8-wave workgroups (256 query rows) unless they leave CUs idle or single-occupied with causal work of very
+        // unequal length: at <= one 8-wave workgroup per CU the 4-wave tiling (128 rows, two workgroups per CU) measures +19-22 %
+        // (Llama-70B/TP8 8k prompt 552 -> 676 TFLOP/s, 2k prompt 500 -> 594), above that the 8-wave tiling wins by 1-7 %
+        if (tiling == 0 && (long)((p->seqlen_q + 255) / 256) * p->h * p->b <= 256) tiling = 4;
         if (tiling == 5) {
             const int nqb = (p->seqlen_q + 255) / 256;
             static const bool once5 = [] {
