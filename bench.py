@@ -95,12 +95,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # VATTN_BENCH_BACKEND=gloo is a test hook: it lets the N>1 code path run where the ranks outnumber the GPUs (ranks then
+    # share devices and the timing reduction runs on CPU tensors); the driver's runs use the default, RCCL
+    backend = os.environ.get("VATTN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vattention_amd import vattention
     from vattention_amd.attention.timers import drain_op_timers, enable_op_timers
@@ -150,10 +159,10 @@ def main():
     kv_map = runner.stats.mapped_over_reserved
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tk = torch.tensor([tokens], dtype=torch.float64, device=dev)
+        tk = torch.tensor([tokens], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         tokens = int(tk.item())
 
