@@ -123,6 +123,49 @@ def test_prefill_workgroup_orders(Hq, Hkv):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("Hq,Hkv", [(71, 1), (8, 2), (4, 4)], ids=["falcon7b_mqa", "gqa4", "mha"])
+def test_head_dim_64(Hq, Hkv, dtype):
+    """d = 64 (Falcon-7B: 71 query heads on ONE kv head): decode with fused append (auto / 1 / 3 splits) and chunked
+    causal prefill over several query blocks, default and 4-wave tilings, both fragment-read paths."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(Hq)
+    D, ctx, slots = 64, 1500, 4
+    kc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    vc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    # ---- decode ----
+    B = 3
+    q = torch.randn(B, 1, Hq, D).to(dtype)
+    kn = torch.randn(B, 1, Hkv, D).to(dtype)
+    vn = torch.randn(B, 1, Hkv, D).to(dtype)
+    idx = torch.tensor([2, 0, 3], dtype=torch.int32)
+    cl = torch.tensor([1, 1037, 64], dtype=torch.int32)
+    kc1, vc1 = kc.clone(), vc.clone()
+    ref64 = flash_attn_with_kvcache_ref(q, kc1, vc1, kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+    kc2, vc2 = kc.clone(), vc.clone()
+    ref32 = flash_attn_with_kvcache_ref(q, kc2, vc2, kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
+    for splits in (0, 1, 3):
+        for variant in (0, 1):
+            kgi, vgi = kc.to(DEV), vc.to(DEV)
+            out = flash_attn_with_kvcache(q.to(DEV), kgi, vgi, kn.to(DEV), vn.to(DEV), cache_seqlens=cl.to(DEV),
+                                          cache_batch_idx=idx.to(DEV), causal=True, num_splits=splits, _variant=variant)
+            torch.cuda.synchronize()
+            _check(out, ref64, ref32, dtype, "d64 decode splits=%d variant=%d" % (splits, variant))
+            assert torch.equal(kgi.cpu(), kc1) and torch.equal(vgi.cpu(), vc1)
+    # ---- chunked causal prefill: 300 new rows on top of 0 / 555 cached, ragged batch ----
+    n = 300
+    qp = torch.randn(2, n, Hq, D).to(dtype)
+    clp = torch.tensor([n, n + 555], dtype=torch.int32)
+    idxp = torch.tensor([1, 3], dtype=torch.int32)
+    r64 = flash_attn_with_kvcache_ref(qp, kc, vc, cache_seqlens=clp, cache_batch_idx=idxp, causal=True)
+    r32 = flash_attn_with_kvcache_ref(qp, kc, vc, cache_seqlens=clp, cache_batch_idx=idxp, causal=True, math="f32")
+    for variant in (0, 1, 2, 8, 9, 32, 64):
+        out = flash_attn_with_kvcache(qp.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=clp.to(DEV), cache_batch_idx=idxp.to(DEV),
+                                      causal=True, _variant=variant)
+        torch.cuda.synchronize()
+        _check(out, r64, r32, dtype, "d64 prefill variant=%d" % variant)
+
+
 def test_prefill_non_causal_and_seqlen_q_gt_k():
     from vattention_amd.flash_attn import flash_attn_func, flash_attn_with_kvcache
     torch.manual_seed(5)

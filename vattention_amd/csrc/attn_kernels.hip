@@ -188,7 +188,7 @@ template <int HD> struct PfSmem {
 // MSUM: the softmax denominator is accumulated by the matrix pipe (one extra MFMA per 16 keys with an all-ones A
 // fragment, no LDS read) instead of 32 dependent v_add per tile: the kernel is VALU/issue-bound, the matrix pipe has slack.
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC == 2 ? 1 : 2)) void prefill_kernel(vattn_attn_params p, int order, int nqb) {
+__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     using S = PfSmem<HD>;
@@ -198,6 +198,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
     constexpr int DB = HD / 32;        // 32-wide d blocks of O^T
     constexpr int CPR = HD / 8;        // 16-byte chunks per K/V row
     constexpr int PASSES = (PF_BN * CPR) / NT;
+    constexpr int SWZ = CPR < 16 ? CPR - 1 : 15;   // K-tile swizzle mask
+    static_assert(PASSES >= 1 && (PF_BN * CPR) % NT == 0, "tile does not divide over the workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
             const int row = idx / CPR;
             const int c = idx % CPR;
             // K: row-major, 16-byte chunk index XOR-swizzled with (row & 15) -> conflict-free ds_read_b128
-            *(uint4*)(ksm + row * S::kRowBytes + ((c ^ (row & 15)) << 4)) = kreg[ps];
+            // (d = 64: 8 chunks per row, swizzle with row & 7)
+            *(uint4*)(ksm + row * S::kRowBytes + ((c ^ (row & SWZ)) << 4)) = kreg[ps];
             // V: [d/32][key][32 d] sub-tiles (64-byte rows) for the transpose reads
             *(uint4*)(vsm + (c >> 2) * S::kVSubBytes + row * 64 + ((c & 3) << 4)) = vreg[ps];
         }
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES * QC >= 8 && QC == 2) ? 1 : (QC 
             // step kk+1 are read from LDS while the MFMAs of step kk run (explicit two-deep register ring)
             auto kfrag = [&](int kb, int kk) -> V8 {
                 if (ABL(3)) return qf[0][(kk + kb) % KK];
-                return *(const V8*)(ksm + (kb * 32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
+                return *(const V8*)(ksm + (kb * 32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & SWZ)) << 4));
             };
             V8 a_cur[2], a_nxt[2];
             a_cur[0] = kfrag(0, 0);
@@ -975,7 +978,7 @@ constexpr int DC_BN = 32;     // keys per wave tile
 
 // workspace layout: float o_accum[splits][b][h][d]; float lse_accum[splits][b][h]  (log2 domain, scaled)
 template <typename T, int HD, bool USE_TR>
-__global__ __launch_bounds__(64 * DC_WAVES, 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append) {
+__global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
@@ -1219,7 +1222,7 @@ __global__ __launch_bounds__(64 * DC_WAVES, 3) void decode_kernel(vattn_attn_par
 // (b, h): the split weights are computed once (lanes over splits), then every thread owns one d and
 // streams its partials with independent loads.
 template <typename T, int HD>
-__global__ __launch_bounds__(HD) void combine_kernel(vattn_attn_params p, int num_splits) {
+__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits) {   // 128 threads: one per split weight, first HD also one per output column
     __shared__ float wsm[128];
     __shared__ float red[4];
     const int bh = blockIdx.x;                       // b * h + head
@@ -1245,11 +1248,13 @@ __global__ __launch_bounds__(HD) void combine_kernel(vattn_attn_params p, int nu
     __syncthreads();
     const float wsum = red[2] + red[3];
     const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
-    const float* src = oacc + (int64_t)bh * HD + tid;
-    float acc = 0.f;
+    if (tid < HD) {
+        const float* src = oacc + (int64_t)bh * HD + tid;
+        float acc = 0.f;
 #pragma unroll 8
-    for (int s = 0; s < num_splits; s++) acc += wsm[s] * src[(int64_t)s * sstride * HD];
-    ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
+        for (int s = 0; s < num_splits; s++) acc += wsm[s] * src[(int64_t)s * sstride * HD];
+        ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
+    }
     if (p.softmax_lse && tid == 0)
         p.softmax_lse[bh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
 }
@@ -1380,7 +1385,7 @@ void launch_append(const vattn_attn_params* p, hipStream_t st) {
     hipLaunchKernelGGL(append_kv_kernel, grid, block, 0, st, *p);
 }
 
-template <typename T, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
+template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
     constexpr int BM = 32 * QC * WAVES;
     const int nqb = (p->seqlen_q + BM - 1) / BM;
     // variant bits 5-6: workgroup order (see the kernel): 0 = default (XCD-grouped when the kv heads divide the 8 XCDs),
@@ -1395,20 +1400,20 @@ template <typename T, int WAVES, int QC, bool MSUM> void launch_prefill(const va
         const long items = (long)nqb * p->b * (p->h / p->h_k);   // per kv head
         grid = dim3((unsigned)(8 * ((items + per - 1) / per)));
     }
-    const size_t smem = PfSmem<128>::kTotal;
+    const size_t smem = PfSmem<HD>::kTotal;
     static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
-        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, 128, false, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
+        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, false, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
         return true;
     }();
     (void)attr_once;
     if (use_tr)
-        hipLaunchKernelGGL((prefill_kernel<T, 128, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
+        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
     else
-        hipLaunchKernelGGL((prefill_kernel<T, 128, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
+        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
 }
 
-template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
+template <typename T, int HD> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
     (void)time_only_main;
     const bool use_tr = (p->variant & 1) == 0;
     if (p->seqlen_q == 1) {
@@ -1417,14 +1422,14 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
         const int splits = pick_splits(p, gblocks);
         if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
         dim3 grid(splits, p->h_k * gblocks, p->b), block(64 * DC_WAVES);
-        const size_t smem = (size_t)DC_WAVES * 16 * 128 * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
+        const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
         const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
         if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
         if (use_tr)
-            hipLaunchKernelGGL((decode_kernel<T, 128, true>), grid, block, smem, st, *p, splits, gblocks, fused_append);
+            hipLaunchKernelGGL((decode_kernel<T, HD, true>), grid, block, smem, st, *p, splits, gblocks, fused_append);
         else
-            hipLaunchKernelGGL((decode_kernel<T, 128, false>), grid, block, smem, st, *p, splits, gblocks, fused_append);
-        if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, 128>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
+            hipLaunchKernelGGL((decode_kernel<T, HD, false>), grid, block, smem, st, *p, splits, gblocks, fused_append);
+        if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
     } else {
         if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
         // 0 = default (8 waves x 32 rows: best or within noise on 6 of 7 measured shapes, profiles/r01_kbench.md);
@@ -1434,27 +1439,38 @@ template <typename T> int launch_attn_t(const vattn_attn_params* p, hipStream_t 
         // unequal length: at <= one 8-wave workgroup per CU the 4-wave tiling (128 rows, two workgroups per CU) measures +19-22 %
         // (Llama-70B/TP8 8k prompt 552 -> 676 TFLOP/s, 2k prompt 500 -> 594), above that the 8-wave tiling wins by 1-7 %
         if (tiling == 0 && (long)((p->seqlen_q + 255) / 256) * p->h * p->b <= 256) tiling = 4;
-        if (tiling == 5) {
-            const int nqb = (p->seqlen_q + 255) / 256;
-            static const bool once5 = [] {
-                (void)hipFuncSetAttribute((const void*)prefill_stag_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-                return true;
-            }();
-            (void)once5;
-            hipLaunchKernelGGL((prefill_stag_kernel<T, 128>), dim3(nqb, p->h, p->b), dim3(512), PfSmem<128>::kTotal, st, *p);
-        } else if (tiling == 3) {
-            constexpr int W = 8;
-            const int nqb = (p->seqlen_q + 32 * W - 1) / (32 * W);
-            static const bool once = [] {
-                (void)hipFuncSetAttribute((const void*)prefill_pipe_kernel<T, 128, W>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-                return true;
-            }();
-            (void)once;
-            hipLaunchKernelGGL((prefill_pipe_kernel<T, 128, W>), dim3(nqb, p->h, p->b), dim3(64 * W), PfSmem<128>::kTotal, st, *p);
-        } else if (tiling == 2) launch_prefill<T, 4, 2, false>(p, st, use_tr);
-        else if (tiling == 4) launch_prefill<T, 4, 1, false>(p, st, use_tr);
-        else if (p->variant & 16) launch_prefill<T, 8, 1, true>(p, st, use_tr);      // denominator on the matrix pipe
-        else launch_prefill<T, 8, 1, false>(p, st, use_tr);
+        // the experimental structures (2 = 64-row waves, 3 = software-pipelined, 5 = phase-staggered) exist for d = 128 only
+        if (HD != 128 && (tiling == 5 || tiling == 3 || tiling == 2)) tiling = 1;
+        bool launched = false;
+        if constexpr (HD == 128) {
+            if (tiling == 5) {
+                const int nqb = (p->seqlen_q + 255) / 256;
+                static const bool once5 = [] {
+                    (void)hipFuncSetAttribute((const void*)prefill_stag_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+                    return true;
+                }();
+                (void)once5;
+                hipLaunchKernelGGL((prefill_stag_kernel<T, 128>), dim3(nqb, p->h, p->b), dim3(512), PfSmem<128>::kTotal, st, *p);
+                launched = true;
+            } else if (tiling == 3) {
+                constexpr int W = 8;
+                const int nqb = (p->seqlen_q + 32 * W - 1) / (32 * W);
+                static const bool once = [] {
+                    (void)hipFuncSetAttribute((const void*)prefill_pipe_kernel<T, 128, W>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+                    return true;
+                }();
+                (void)once;
+                hipLaunchKernelGGL((prefill_pipe_kernel<T, 128, W>), dim3(nqb, p->h, p->b), dim3(64 * W), PfSmem<128>::kTotal, st, *p);
+                launched = true;
+            } else if (tiling == 2) {
+                launch_prefill<T, 128, 4, 2, false>(p, st, use_tr);
+                launched = true;
+            }
+        }
+        if (launched) {
+        } else if (tiling == 4) launch_prefill<T, HD, 4, 1, false>(p, st, use_tr);
+        else if ((p->variant & 16) && HD == 128) launch_prefill<T, HD == 128 ? 128 : HD, 8, 1, HD == 128>(p, st, use_tr);      // denominator on the matrix pipe
+        else launch_prefill<T, HD, 8, 1, false>(p, st, use_tr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
@@ -1465,7 +1481,8 @@ int validate(const vattn_attn_params* p) {
     if (!p || !p->q || !p->out || !p->k_cache || !p->v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
     if (p->dtype != VATTN_DTYPE_F16 && p->dtype != VATTN_DTYPE_BF16)
         return fail(VATTN_K_ERR_UNSUPPORTED, "FlashAttention only support fp16 and bf16 data type");      // flash_api.cpp:1325-1326
-    if (p->d != 128) return fail(VATTN_K_ERR_UNSUPPORTED, "this build supports head dimension 128 only");
+    // d = 256 instantiates but spills (O^T alone is 128 accumulator registers per wave): not shipped until it has its own tiling
+    if (p->d != 64 && p->d != 128) return fail(VATTN_K_ERR_UNSUPPORTED, "this build supports head dimensions 64 and 128");
     if (p->b <= 0) return fail(VATTN_K_ERR_INVALID, "batch size must be postive");                       // flash_api.cpp:1353
     if (p->h_k <= 0 || p->h % p->h_k != 0)
         return fail(VATTN_K_ERR_INVALID, "Number of heads in key/value must divide number of heads in query");   // :1355
@@ -1506,8 +1523,11 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (p->k_new && p->seqlen_knew > 0 && !p->cache_seqlens) return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");
-    if (p->dtype == VATTN_DTYPE_F16) return launch_attn_t<_Float16>(p, st, false);
-    return launch_attn_t<__bf16>(p, st, false);
+    const bool f16 = p->dtype == VATTN_DTYPE_F16;
+    switch (p->d) {
+        case 64: return f16 ? launch_attn_t<_Float16, 64>(p, st, false) : launch_attn_t<__bf16, 64>(p, st, false);
+        default: return f16 ? launch_attn_t<_Float16, 128>(p, st, false) : launch_attn_t<__bf16, 128>(p, st, false);
+    }
 }
 
 int vattn_cache_flat(const void* key, const void* value, void* k_cache, void* v_cache, int64_t num_tokens,
