@@ -23,6 +23,9 @@ MODELS = {
     "llama-3-8b": (32, 32, 8, 128),
     "yi-34b": (60, 56, 8, 128),
     "llama-3-70b": (80, 64, 8, 128),
+    "falcon-7b": (32, 71, 1, 64),          # multi-query, head size 64
+    "mistral-7b": (32, 32, 8, 128),
+    "qwen-72b": (80, 64, 64, 128),         # MHA
 }
 
 
