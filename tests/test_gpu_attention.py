@@ -63,7 +63,7 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
         assert torch.equal(kgi.cpu(), kc1) and torch.equal(vgi.cpu(), vc1)     # in-place append, bit-exact, nothing else touched
 
 
-@pytest.mark.parametrize("variant", [0, 1, 8, 4, 6, 16, 10], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8_pipelined", "w8q1_mfma_rowsum", "w8_staggered"])
+@pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("n,c,Hq,Hkv", [
     (128, 0, 8, 2), (1, 5, 4, 4), (200, 0, 4, 1), (77, 333, 8, 4), (512, 1000, 4, 2), (130, 62, 2, 2), (64, 64, 4, 2),
@@ -113,7 +113,7 @@ def test_prefill_workgroup_orders(Hq, Hkv):
     ref64 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
     ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     outs = []
-    for variant in (32, 64, 0, 96):
+    for variant in (32, 64, 0, 96, 12):
         out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
                                       causal=True, _variant=variant)
         torch.cuda.synchronize()

@@ -60,6 +60,9 @@ def prefill(variant):
         q = torch.randn(1, n, Hq, 128, device=DEV, dtype=torch.float16)
         kc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
         vc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        scale = float(os.environ.get("KBENCH_DATA_SCALE", "1"))     # 0 = zero-filled inputs (data-dependent power: clocks rise)
+        if scale != 1.0:
+            q, kc, vc = q * scale, kc * scale, vc * scale
         cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
         p, keep = params(q, kc, vc, cl, variant=variant)
         ms = time_ms(p, 1, 3 if n > 10000 else 10)
@@ -103,14 +106,14 @@ if __name__ == "__main__":
         ONLY = sys.argv[sys.argv.index("--only") + 1]
     if "--variant" in sys.argv:
         variant = int(sys.argv[sys.argv.index("--variant") + 1])
-    VARIANTS = [variant] if "--variant" in sys.argv else [0, 8, 6]
+    VARIANTS = [variant] if "--variant" in sys.argv else [0, 8, 12]
     if "--variants" in sys.argv:
         VARIANTS = [int(x) for x in sys.argv[sys.argv.index("--variants") + 1].split(",")]
     what = [a for a in sys.argv[1:] if a in ("prefill", "decode")] or ["prefill", "decode"]
     torch.zeros(1, device=DEV)
     if "prefill" in what:
         for v in VARIANTS:
-            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3], {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, software-pipelined", 4: "4 waves x 32 rows", 5: "8 waves, phase-staggered halves"}[(v >> 1) & 7]))
+            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3], {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
         decode(variant)

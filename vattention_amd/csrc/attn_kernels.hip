@@ -182,6 +182,39 @@ template <int HD> struct PfSmem {
     static constexpr int kVSubBytes = PF_BN * 64;               // one [64 keys][32 d] sub-tile
 };
 
+// Workgroup -> (batch entry, head, query block).  The dispatcher hands consecutive workgroup ids to consecutive XCDs
+// (id & 7), each with its own L2, and starts them in id order.  order 2 (default) makes every XCD stream ONE kv head (its
+// L2 then holds a single K/V stream that the G query heads x neighbouring query blocks running there share) and walks the
+// query blocks heaviest-first across ALL heads, so the workgroups running at any time have near-equal lengths and move
+// down K/V in step.  order 1: heaviest-first across heads without the XCD grouping.  order 0: grid (query block, head,
+// batch) - block-major per head (its tail is one head's heaviest blocks: 20-40 % slower on whole-prompt shapes).
+// Returns false for the padding workgroups of the 1-D grids.
+__device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order, int nqb, int& b, int& h, int& qb) {
+    if (order == 0) {
+        b = blockIdx.z; h = blockIdx.y; qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+        return true;
+    }
+    const int L = blockIdx.x;
+    const int G = p.h / p.h_k;
+    if (order == 2) {
+        const int per = 8 / p.h_k;                         // XCDs per kv head (launch guarantees 8 % h_k == 0)
+        const int xcd = L & 7;
+        int t = (L >> 3) * per + xcd / p.h_k;
+        const int g = t % G; t /= G;
+        b = t % p.b;
+        const int qbr = t / p.b;
+        if (qbr >= nqb) return false;
+        h = (xcd % p.h_k) * G + g;
+        qb = nqb - 1 - qbr;
+        return true;
+    }
+    h = L % p.h;
+    const int t = L / p.h;
+    b = t % p.b;
+    qb = nqb - 1 - t / p.b;
+    return t / p.b < nqb;
+}
+
 // WAVES waves per workgroup, each owning QC blocks of 32 query rows (BM = 32*QC*WAVES rows per workgroup).
 // QC = 2 halves the LDS fragment traffic per flop (each K / V^T fragment read feeds two MFMAs) at the price
 // of a 512-register budget (one wave per SIMD).
@@ -208,35 +241,8 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
     const int l31 = lane & 31;
     const int g = lane >> 5;
 
-    // Workgroup -> (batch entry, head, query block).  The dispatcher hands consecutive workgroup ids to consecutive
-    // XCDs (id & 7), each with its own L2, and starts them in id order.  order 2 (default) makes every XCD stream ONE kv
-    // head (its L2 then holds a single K/V stream that the G query heads x neighbouring query blocks running there share)
-    // and walks the query blocks heaviest-first across ALL heads, so the workgroups running at any time have near-equal
-    // lengths and move down K/V in step.  order 1: heaviest-first across heads without the XCD grouping.
-    // order 0: grid (query block, head, batch) - block-major per head.
     int b, h, qb;
-    if (order == 0) {
-        b = blockIdx.z; h = blockIdx.y; qb = (int)gridDim.x - 1 - (int)blockIdx.x;
-    } else {
-        const int L = blockIdx.x;
-        const int G = p.h / p.h_k;
-        if (order == 2) {
-            const int per = 8 / p.h_k;                         // XCDs per kv head (launch guarantees 8 % h_k == 0)
-            const int xcd = L & 7;
-            int t = (L >> 3) * per + xcd / p.h_k;
-            const int g = t % G; t /= G;
-            b = t % p.b;
-            const int qbr = t / p.b;
-            if (qbr >= nqb) return;
-            h = (xcd % p.h_k) * G + g;
-            qb = nqb - 1 - qbr;
-        } else {
-            h = L % p.h;
-            const int t = L / p.h;
-            b = t % p.b;
-            qb = nqb - 1 - t / p.b;
-        }
-    }
+    if (!wg_to_work(p, order, nqb, b, h, qb)) return;
     const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
     // loaded values are wave-uniform; readfirstlane makes that provable (descriptors must live in SGPRs)
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
@@ -518,244 +524,31 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
 }
 
 // --------------------------------------------------------------------------------------------
-// Phase-staggered prefill (8 waves, 32 query rows each).  In the plain kernel all waves of a workgroup are
-// phase-locked by the per-tile barrier: the two waves that share a SIMD run their QK^T MFMAs at the same
-// time, then their softmax VALU at the same time, then PV — the matrix pipe and the VALU never overlap.
-// Here a tile has TWO barrier-separated intervals and the two halves of the workgroup (waves 0-3 / 4-7,
-// one wave of each half per SIMD) are offset by half a tile:
-//     interval 1 of tile t:  half 0  S=QK(t), softmax(t)      |  half 1  PV(t-1)
-//     interval 2 of tile t:  half 0  PV(t)                    |  half 1  S=QK(t), softmax(t)
-// so on every SIMD one wave's softmax (VALU) always runs beside the other wave's PV (matrix pipe).
-// LDS: K(t) in K[t&1] (read in both intervals of tile t), V(t) in V[t&1] (read in interval 2 of t and interval 1
-// of t+1); the data of tile t+1 is stored by every wave during interval 2 of tile t.
+// Interleaved, software-pipelined prefill (8 waves x 32 query rows, d = 128): S(t+1) = K(t+1).Q^T is accumulated while
+// the softmax of tile t is evaluated, then P(t).V(t); K runs one tile ahead of V in LDS (iteration t reads K[(t+1)&1] and
+// V[t&1] and stores K(t+2) -> K[t&1], V(t+1) -> V[(t+1)&1] before its single barrier).  The ISSUE ORDER is written out by
+// hand instead of left to the scheduler: the loop body is a sequence of 32 groups, each
+//     { one MFMA ; the LDS fragment read(s) for the MFMA two groups ahead ; a 3-6 instruction slice of VALU work }
+// closed by a scheduling barrier, so every MFMA is followed by independent VALU of the SAME wave.  Measured on gfx950
+// (tools/mfma_overlap_probe.cpp, tools/attn_skeleton_probe.cpp): VALU issued by the wave that owns the running MFMA
+// hides almost completely (16 MFMA + 64 VALU: +5 %), VALU issued by the OTHER wave of the SIMD costs the matrix pipe
+// about half its issue time.  VALU placement per tile (138 instructions for 32 MFMAs):
+//     QK(t+1) MFMAs 0-15 : exp2 / row-sum / f16 pack of P(t) values 0-19          (ten pairs, ~4.4 per MFMA)
+//     PV(t)   MFMAs 0-7  : P(t) values 20-31                                       (six pairs, ~5.3 per MFMA)
+//     PV(t)   MFMAs 8-15 : running max of S(t+1) (v_max3 chain), then m / alpha    (~3 per MFMA)
+// so the row max never sits on the critical path between two matrix phases.
 // --------------------------------------------------------------------------------------------
-template <typename T, int HD>
-__global__ __launch_bounds__(512, 2) void prefill_stag_kernel(vattn_attn_params p) {
+#ifndef ILV_AHEAD
+#define ILV_AHEAD 2
+#endif
+template <typename T>
+__global__ __launch_bounds__(512, 2) void prefill_ilv_kernel(vattn_attn_params p, int order, int nqb) {
     using X = Tr<T>;
     using V8 = typename X::v8;
+    constexpr int HD = 128;
     using S = PfSmem<HD>;
     constexpr int WAVES = 8, NT = 64 * WAVES, BM = 32 * WAVES;
     constexpr int KK = HD / 16, DB = HD / 32, CPR = HD / 8;
-    constexpr int PASSES = (PF_BN * CPR) / NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ksm0 = smem;
-    char* const vsm0 = smem + 2 * S::kTileBytes;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2;
-    const int l31 = lane & 31;
-    const int g = lane >> 5;
-    const int b = blockIdx.z;
-    const int h = blockIdx.y;
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
-    const int hk = h / (p.h / p.h_k);
-    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
-    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
-    const int Sq = p.seqlen_q;
-    const bool causal = p.is_causal != 0;
-    const int off = Lk - Sq;
-    const int q_wg0 = qb * BM;
-    const int qw0 = q_wg0 + wave * 32;
-    const int my_q = qw0 + l31;
-
-    int n_end = Lk;
-    if (causal) n_end = min(Lk, q_wg0 + BM + off);
-    if (n_end < 0) n_end = 0;
-    const int nt = (n_end + PF_BN - 1) / PF_BN;
-    int t_live = nt;      // tiles [0, t_live) hold at least one visible (row, key) pair for this wave
-    if (causal) {
-        const int last_key = qw0 + 31 + off;
-        t_live = last_key < 0 ? 0 : min(nt, last_key / PF_BN + 1);
-    }
-
-    const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
-    const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
-    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
-
-    V8 qf[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
-        qf[kk] = as_v8<V8>(v);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) asm volatile("" : "+v"(qf[kk]));
-
-    f32x16 o[DB];
-#pragma unroll
-    for (int i = 0; i < DB; i++) o[i] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f, alpha = 1.f;
-    f32x16 s0, s1;     // S^T / P^T of the wave's current tile (key blocks 0 and 1)
-    const float sc = p.softmax_scale * kLog2e;
-
-    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
-    unsigned koff[PASSES], voff[PASSES], klds[PASSES], vlds[PASSES];
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ps++) {
-        const int idx = ps * NT + tid;
-        const int row = idx / CPR, c = idx % CPR;
-        koff[ps] = (unsigned)row * k_rs_bytes + (unsigned)c * 16u;
-        voff[ps] = (unsigned)row * v_rs_bytes + (unsigned)c * 16u;
-        klds[ps] = (unsigned)(row * S::kRowBytes + ((c ^ (row & 15)) << 4));
-        vlds[ps] = (unsigned)((c >> 2) * S::kVSubBytes + row * 64 + ((c & 3) << 4));
-    }
-    const T* kbase_u = uniform_ptr(kbase);
-    const T* vbase_u = uniform_ptr(vbase);
-    uint4 kreg[PASSES], vreg[PASSES];
-    auto issue_loads = [&](int t) {
-        int rem = Lk - t * PF_BN;
-        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
-        const __amdgpu_buffer_rsrc_t kr = make_rsrc(kbase_u + (int64_t)t * PF_BN * p.k_row_stride, (unsigned)rem * k_rs_bytes);
-        const __amdgpu_buffer_rsrc_t vr = make_rsrc(vbase_u + (int64_t)t * PF_BN * p.v_row_stride, (unsigned)rem * v_rs_bytes);
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ps++) {
-            kreg[ps] = buf_load16(kr, koff[ps]);
-            vreg[ps] = buf_load16(vr, voff[ps]);
-        }
-    };
-    auto write_tile = [&](int buf) {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ps++) {
-            *(uint4*)(ksm0 + buf * S::kTileBytes + klds[ps]) = kreg[ps];
-            *(uint4*)(vsm0 + buf * S::kTileBytes + vlds[ps]) = vreg[ps];
-        }
-    };
-    auto qk_softmax = [&](int t) {
-        if (t >= t_live) return;
-        const char* ksm = ksm0 + (t & 1) * S::kTileBytes;
-        const int n0 = t * PF_BN;
-        s0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        s1 = s0;
-#pragma unroll
-        for (int kk = 0; kk < KK; kk++) {
-            const V8 a0 = *(const V8*)(ksm + l31 * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
-            const V8 a1 = *(const V8*)(ksm + (32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
-            s0 = X::mfma32(a0, qf[kk], s0);
-            s1 = X::mfma32(a1, qf[kk], s1);
-        }
-        if ((n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off))) {
-            const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int key = n0 + 8 * (r >> 2) + 4 * g + (r & 3);
-                if (key > lim) s0[r] = -INFINITY;
-                if (key + 32 > lim) s1[r] = -INFINITY;
-            }
-        }
-        float mloc = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
-        mloc = fmaxf(mloc, swap_halves(mloc));
-        const float m_new = fmaxf(m_run, mloc);
-        const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
-        alpha = fast_exp2(m_run * sc - msub);
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            s0[r] = fast_exp2(__builtin_fmaf(s0[r], sc, -msub));
-            s1[r] = fast_exp2(__builtin_fmaf(s1[r], sc, -msub));
-            psum += s0[r] + s1[r];
-        }
-        l_run = l_run * alpha + psum;
-    };
-    auto pv = [&](int t) {
-        if (t >= t_live) return;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-            for (int i = 0; i < DB; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
-        }
-        const char* vsm = vsm0 + (t & 1) * S::kTileBytes;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                V8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; j++) pf[j] = X::cvt(kb == 0 ? s0[8 * u + j] : s1[8 * u + j]);
-                const int krow0 = kb * 32 + 16 * u;
-#pragma unroll
-                for (int db = 0; db < DB; db++) {
-                    const int i16 = lane & 15, dh = (lane >> 4) & 1;
-                    const char* a1 = vsm + db * S::kVSubBytes + (krow0 + 4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
-                    o[db] = X::mfma32(join_tr<V8>(lo, hi), pf, o[db]);
-                }
-            }
-    };
-
-    issue_loads(0);
-    write_tile(0);
-    __syncthreads();                                   // A_0
-    if (half == 0) {
-        for (int t = 0; t < nt; t++) {
-            issue_loads(t + 1);
-            qk_softmax(t);                             // interval 1 of tile t
-            __syncthreads();                           // B_t
-            pv(t);                                     // interval 2 of tile t
-            write_tile((t + 1) & 1);
-            __syncthreads();                           // A_{t+1}
-        }
-        __syncthreads();                               // B_nt (half 1 finishes PV(nt-1))
-    } else {
-        issue_loads(1);
-        __syncthreads();                               // B_0 (nothing to do in interval 1 of tile 0)
-        for (int t = 0; t < nt; t++) {
-            qk_softmax(t);                             // interval 2 of tile t
-            write_tile((t + 1) & 1);
-            __syncthreads();                           // A_{t+1}
-            issue_loads(t + 2);
-            pv(t);                                     // interval 1 of tile t+1
-            __syncthreads();                           // B_{t+1}
-        }
-    }
-
-    const float l_tot = l_run + swap_halves(l_run);
-    const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-    if (my_q < Sq) {
-        T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
-#pragma unroll
-        for (int db = 0; db < DB; db++)
-#pragma unroll
-            for (int tq = 0; tq < 4; tq++) {
-                typename X::v4 w;
-#pragma unroll
-                for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][4 * tq + e] * inv);
-                *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
-            }
-        if (p.softmax_lse && g == 0) {
-            const float lse = (l_tot == 0.f) ? INFINITY : (m_run * p.softmax_scale + __logf(l_tot));
-            p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// Software-pipelined prefill: while the VALU runs the softmax of tile t, the matrix pipe already
-// accumulates S^T of tile t+1 (both live in registers), then P(t).V(t) follows.  A wave's MFMA work
-// and its own softmax therefore overlap instead of alternating, which is what lifts the matrix-pipe
-// duty of a wave (measured on the non-pipelined kernel: ~26 % per wave, ~41 % per SIMD with two
-// waves at random phase; profiles/r01_prefill_pmc.md).  K runs one tile ahead of V in LDS:
-//   iteration t reads  K[(t+1)&1] (QK of tile t+1)  and  V[t&1] (PV of tile t),
-//   and stores         K(t+2) -> K[t&1],  V(t+1) -> V[(t+1)&1]   before the single barrier.
-// --------------------------------------------------------------------------------------------
-template <typename T, int HD, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void prefill_pipe_kernel(vattn_attn_params p) {
-    using X = Tr<T>;
-    using V8 = typename X::v8;
-    using S = PfSmem<HD>;
-    constexpr int NT = 64 * WAVES;
-    constexpr int BM = 32 * WAVES;
-    constexpr int KK = HD / 16;
-    constexpr int DB = HD / 32;
-    constexpr int CPR = HD / 8;
     constexpr int PASSES = (PF_BN * CPR) / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ksm0 = smem;                          // K[0], K[1]
@@ -766,9 +559,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void prefill_pipe_kernel(vattn_attn_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int g = lane >> 5;
-    const int b = blockIdx.z;
-    const int h = blockIdx.y;
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+    int b, h, qb;
+    if (!wg_to_work(p, order, nqb, b, h, qb)) return;
     const int hk = h / (p.h / p.h_k);
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
     const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
@@ -783,8 +575,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void prefill_pipe_kernel(vattn_attn_
     if (causal) n_end = min(Lk, q_wg0 + BM + off);
     if (n_end < 0) n_end = 0;
     const int nt = (n_end + PF_BN - 1) / PF_BN;
-    // tiles [0, t_live) hold at least one visible (row, key) pair for THIS wave (wave-uniform)
-    int t_live = nt;
+    int t_live = nt;      // tiles [0, t_live) hold at least one visible (row, key) pair for THIS wave (wave-uniform)
     if (causal) {
         const int last_key = qw0 + 31 + off;
         t_live = last_key < 0 ? 0 : min(nt, last_key / PF_BN + 1);
@@ -801,6 +592,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void prefill_pipe_kernel(vattn_attn_
         if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
         qf[kk] = as_v8<V8>(v);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // retire the Q loads here (see prefill_kernel)
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) asm volatile("" : "+v"(qf[kk]));
+
     f32x16 o[DB];
 #pragma unroll
     for (int i = 0; i < DB; i++) o[i] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -844,11 +639,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void prefill_pipe_kernel(vattn_attn_
 #pragma unroll
         for (int ps = 0; ps < PASSES; ps++) *(uint4*)(vsm0 + buf * S::kTileBytes + vlds[ps]) = vreg[ps];
     };
-    auto kfrag = [&](const char* ksm, int kb, int kk) -> V8 {
-        return *(const V8*)(ksm + (kb * 32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & 15)) << 4));
+    // K fragment of S^T MFMA i (k-step i>>1, key block i&1); V^T fragment of PV MFMA j (P group j>>2, d block j&3)
+    const unsigned kfrag_row = (unsigned)(l31 * S::kRowBytes);
+    auto kfrag = [&](const char* ksm, int i) -> V8 {
+        const int kk = i >> 1, kb = i & 1;
+        return *(const V8*)(ksm + kb * 32 * S::kRowBytes + kfrag_row + (((2 * kk + g) ^ (l31 & 15)) << 4));
+    };
+    const int i16 = lane & 15, dh = (lane >> 4) & 1;
+    const unsigned vfrag_lane = (unsigned)((4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2);
+    auto vfrag = [&](const char* vsm, int j) -> V8 {
+        const int pg = j >> 2, db = j & 3;
+        const int krow0 = (pg >> 1) * 32 + 16 * (pg & 1);
+        const char* a1 = vsm + db * S::kVSubBytes + krow0 * 64 + vfrag_lane;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
+        return join_tr<V8>(lo, hi);
+    };
+    auto mask_tile = [&](int tt, f32x16& x0, f32x16& x1) {
+        const int n0 = tt * PF_BN;
+        if ((n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off))) {
+            const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = n0 + 8 * (r >> 2) + 4 * g + (r & 3);
+                if (key > lim) x0[r] = -INFINITY;
+                if (key + 32 > lim) x1[r] = -INFINITY;
+            }
+        }
     };
 
-    // ---- prologue: K(0), K(1), V(0) into LDS; S_cur = QK(0) ----
+    // ---- prologue: K(0), K(1), V(0) into LDS; S(0); its row max ----
     load_k(0);
     store_k(0);
     load_k(1);
@@ -857,90 +677,104 @@ __global__ __launch_bounds__(64 * WAVES, 2) void prefill_pipe_kernel(vattn_attn_
     store_v(0);
     __syncthreads();
     f32x16 sc0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 sc1 = sc0;      // S_cur: key blocks 0 and 1 of the current tile
+    f32x16 sc1 = sc0;      // S(t): key blocks 0 and 1 of the current tile
+    float msub = 0.f, alpha = 1.f;   // softmax shift of the current tile, rescale factor it implies for O and l
     if (t_live > 0) {
 #pragma unroll
-        for (int kk = 0; kk < KK; kk++) {
-            sc0 = X::mfma32(kfrag(ksm0, 0, kk), qf[kk], sc0);
-            sc1 = X::mfma32(kfrag(ksm0, 1, kk), qf[kk], sc1);
+        for (int i = 0; i < 2 * KK; i++) {
+            if (i & 1) sc1 = X::mfma32(kfrag(ksm0, i), qf[i >> 1], sc1);
+            else sc0 = X::mfma32(kfrag(ksm0, i), qf[i >> 1], sc0);
         }
+        mask_tile(0, sc0, sc1);
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
+        mloc = fmaxf(mloc, swap_halves(mloc));
+        m_run = mloc;
+        msub = (m_run == -INFINITY) ? 0.f : m_run * sc;
     }
 
     for (int t = 0; t < nt; t++) {
         load_k(t + 2);      // in flight across the whole iteration (out of range past the end: zeros, no access)
         load_v(t + 1);
         if (t < t_live) {
-            const int n0 = t * PF_BN;
-            // diagonal / ragged tiles: mask S_cur in place first (rare; keeps the main block branch-free)
-            if ((n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off))) {
-                const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int key = n0 + 8 * (r >> 2) + 4 * g + (r & 3);
-                    if (key > lim) sc0[r] = -INFINITY;
-                    if (key + 32 > lim) sc1[r] = -INFINITY;
-                }
-            }
-            // ---- main block: S_nxt = K(t+1).Q^T on the matrix pipe  ||  softmax(S_cur) on the VALU ----
-            const char* ksm = ksm0 + ((t + 1) & 1) * S::kTileBytes;
-            f32x16 sn0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 sn1 = sn0;
-#pragma unroll
-            for (int kk = 0; kk < KK; kk++) {
-                sn0 = X::mfma32(kfrag(ksm, 0, kk), qf[kk], sn0);
-                sn1 = X::mfma32(kfrag(ksm, 1, kk), qf[kk], sn1);
-            }
-            float mloc = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
-            mloc = fmaxf(mloc, swap_halves(mloc));
-            const float m_new = fmaxf(m_run, mloc);
-            const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
-            const float alpha = fast_exp2(m_run * sc - msub);
-            m_run = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc0[r] = fast_exp2(__builtin_fmaf(sc0[r], sc, -msub));
-                sc1[r] = fast_exp2(__builtin_fmaf(sc1[r], sc, -msub));
-                psum += sc0[r] + sc1[r];
-            }
-            // keep the exponentials in THIS block (hipcc otherwise sinks them below the rescale branch, away from
-            // the MFMAs they are meant to hide behind): psum is made opaque here, which pins all 32 of them
-            asm volatile("" : "+v"(psum));
-            l_run = l_run * alpha + psum;
-            // interleave: one MFMA, one K-fragment read, a slice of the softmax VALU (0x8 MFMA, 0x100 DS read, 0x2 VALU)
-#pragma unroll
-            for (int i = 0; i < 2 * KK; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
-            }
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // rare after the first tiles; exact
 #pragma unroll
                 for (int i = 0; i < DB; i++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) o[i][r] *= alpha;
             }
-            // ---- O^T += V^T(t) . P^T ----
+            const char* ksm = ksm0 + ((t + 1) & 1) * S::kTileBytes;
             const char* vsm = vsm0 + (t & 1) * S::kTileBytes;
+            f32x16 sn0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 sn1 = sn0;
+            V8 pf[4];            // P(t) in the PV B-operand layout: group pg <-> keys of S^T registers 8u..8u+7 of key block kb, pg = 2kb+u
+            float psum = 0.f;
+            // P pair pr (0..15): key block pr>>3, S^T registers 2*(pr&7), +1  ->  pf[pr>>2] elements 2*(pr&3), +1
+            auto exp_pair = [&](int pr) {
+                const int kb = pr >> 3, r0 = 2 * (pr & 7);
+                const float e0 = fast_exp2(__builtin_fmaf(kb ? sc1[r0] : sc0[r0], sc, -msub));
+                const float e1 = fast_exp2(__builtin_fmaf(kb ? sc1[r0 + 1] : sc0[r0 + 1], sc, -msub));
+                psum += e0;
+                psum += e1;
+                pf[pr >> 2][2 * (pr & 3)] = X::cvt(e0);
+                pf[pr >> 2][2 * (pr & 3) + 1] = X::cvt(e1);
+            };
+            constexpr int AH = ILV_AHEAD;      // fragment reads run AH groups ahead of the MFMA that consumes them
+            V8 kf[2 * KK];
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++)
+            for (int i = 0; i < AH; i++) kf[i] = kfrag(ksm, i);
+            __builtin_amdgcn_sched_barrier(0);
+            V8 vf[16];
+            // ---- S(t+1) = K(t+1).Q^T   ||   P(t) pairs 0-9 ----
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    V8 pf;
+            for (int i = 0; i < 2 * KK; i++) {
+                if (i + AH < 2 * KK) kf[i + AH] = kfrag(ksm, i + AH);
+                else vf[i + AH - 2 * KK] = vfrag(vsm, i + AH - 2 * KK);     // the last AH groups prefetch the first V^T fragments
+                if (i & 1) sn1 = X::mfma32(kf[i], qf[i >> 1], sn1);
+                else sn0 = X::mfma32(kf[i], qf[i >> 1], sn0);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) pf[j] = X::cvt(kb == 0 ? sc0[8 * u + j] : sc1[8 * u + j]);
-                    const int krow0 = kb * 32 + 16 * u;
+                for (int pr = (i * 10 + 15) / 16; pr < ((i + 1) * 10 + 15) / 16; pr++) exp_pair(pr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- O^T += V^T(t).P(t)^T, first half   ||   P(t) pairs 10-15 ----
 #pragma unroll
-                    for (int db = 0; db < DB; db++) {
-                        const int i16 = lane & 15, dh = (lane >> 4) & 1;
-                        const char* a1 = vsm + db * S::kVSubBytes + (krow0 + 4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
-                        o[db] = X::mfma32(join_tr<V8>(lo, hi), pf, o[db]);
-                    }
+            for (int j = 0; j < 8; j++) {
+                vf[j + AH] = vfrag(vsm, j + AH);
+                o[j & 3] = X::mfma32(vf[j], pf[j >> 2], o[j & 3]);
+#pragma unroll
+                for (int pr = 10 + (j * 6 + 7) / 8; pr < 10 + ((j + 1) * 6 + 7) / 8; pr++) exp_pair(pr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            l_run = l_run * alpha + psum;
+            // ---- second half   ||   row max of S(t+1) (raw: a diagonal / ragged next tile is redone below) ----
+            // NOTE no control flow between the groups of one iteration: hipcc sinks the VALU slices of a block into a
+            // later block when their results are only used there, across scheduling barriers
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 8; j < 16; j++) {
+                if (j + AH < 16) vf[j + AH] = vfrag(vsm, j + AH);
+                o[j & 3] = X::mfma32(vf[j], pf[j >> 2], o[j & 3]);
+                {
+                    const int q = j - 8;      // S(t+1) registers 2q, 2q+1 of both key blocks
+                    mx = fmaxf(fmaxf(mx, sn0[2 * q]), sn0[2 * q + 1]);
+                    mx = fmaxf(fmaxf(mx, sn1[2 * q]), sn1[2 * q + 1]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool has_next = t + 1 < t_live;
+            const int n1 = (t + 1) * PF_BN;
+            if (has_next && ((n1 + PF_BN > Lk) || (causal && (n1 + PF_BN - 1 > qw0 + off)))) {     // wave-uniform, rare
+                mask_tile(t + 1, sn0, sn1);
+                mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaxf(sn0[r], sn1[r]));
+            }
+            mx = fmaxf(mx, swap_halves(mx));
+            const float m_new = has_next ? fmaxf(m_run, mx) : m_run;
+            msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
+            alpha = fast_exp2(m_run * sc - msub);
+            m_run = m_new;
             sc0 = sn0;
             sc1 = sn1;
         }
@@ -1385,21 +1219,28 @@ void launch_append(const vattn_attn_params* p, hipStream_t st) {
     hipLaunchKernelGGL(append_kv_kernel, grid, block, 0, st, *p);
 }
 
-template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
-    constexpr int BM = 32 * QC * WAVES;
-    const int nqb = (p->seqlen_q + BM - 1) / BM;
-    // variant bits 5-6: workgroup order (see the kernel): 0 = default (XCD-grouped when the kv heads divide the 8 XCDs),
-    // 1 = block-major per head (3-D grid), 2 = heaviest-first across heads, 3 = XCD-grouped
+// variant bits 5-6: workgroup order (wg_to_work): 0 = default (XCD-grouped when the kv heads divide the 8 XCDs),
+// 1 = block-major per head (3-D grid), 2 = heaviest-first across heads, 3 = XCD-grouped
+dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out) {
     int order = (p->variant >> 5) & 3;
     order = order == 0 ? 2 : order - 1;
     if (order == 2 && !(p->h_k <= 8 && 8 % p->h_k == 0)) order = 1;
-    dim3 grid(nqb, p->h, p->b), block(64 * WAVES);
+    dim3 grid(nqb, p->h, p->b);
     if (order == 1) grid = dim3((unsigned)(nqb * p->h * p->b));
     if (order == 2) {
         const int per = 8 / p->h_k;
         const long items = (long)nqb * p->b * (p->h / p->h_k);   // per kv head
         grid = dim3((unsigned)(8 * ((items + per - 1) / per)));
     }
+    *order_out = order;
+    return grid;
+}
+
+template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
+    constexpr int BM = 32 * QC * WAVES;
+    const int nqb = (p->seqlen_q + BM - 1) / BM;
+    int order;
+    const dim3 grid = prefill_grid(p, nqb, &order), block(64 * WAVES);
     const size_t smem = PfSmem<HD>::kTotal;
     static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
@@ -1432,38 +1273,31 @@ template <typename T, int HD> int launch_attn_t(const vattn_attn_params* p, hipS
         if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
     } else {
         if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
-        // 0 = default (8 waves x 32 rows: best or within noise on 6 of 7 measured shapes, profiles/r01_kbench.md);
-        // 1 = same, explicit; 2 = 4 waves x 64 rows; 3 = software-pipelined 8-wave; 4 = 4 waves x 32 rows
+        // 0 = default (8 waves x 32 rows unless the grid is small, below); 1 = 8 waves x 32 rows, explicit; 2 = 4 waves x 64 rows;
+        // 4 = 4 waves x 32 rows; 6 = 8 waves, hand-interleaved MFMA/VALU groups (software-pipelined)
         int tiling = (p->variant >> 1) & 7;
         // default: 8-wave workgroups (256 query rows) unless they leave CUs idle or single-occupied with causal work of very
         // unequal length: at <= one 8-wave workgroup per CU the 4-wave tiling (128 rows, two workgroups per CU) measures +19-22 %
         // (Llama-70B/TP8 8k prompt 552 -> 676 TFLOP/s, 2k prompt 500 -> 594), above that the 8-wave tiling wins by 1-7 %
         if (tiling == 0 && (long)((p->seqlen_q + 255) / 256) * p->h * p->b <= 256) tiling = 4;
-        // the experimental structures (2 = 64-row waves, 3 = software-pipelined, 5 = phase-staggered) exist for d = 128 only
-        if (HD != 128 && (tiling == 5 || tiling == 3 || tiling == 2)) tiling = 1;
+        // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
+        // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
+        if (tiling == 3 || tiling == 5 || (HD != 128 && (tiling == 2 || tiling == 6))) tiling = 1;
         bool launched = false;
         if constexpr (HD == 128) {
-            if (tiling == 5) {
-                const int nqb = (p->seqlen_q + 255) / 256;
-                static const bool once5 = [] {
-                    (void)hipFuncSetAttribute((const void*)prefill_stag_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-                    return true;
-                }();
-                (void)once5;
-                hipLaunchKernelGGL((prefill_stag_kernel<T, 128>), dim3(nqb, p->h, p->b), dim3(512), PfSmem<128>::kTotal, st, *p);
-                launched = true;
-            } else if (tiling == 3) {
-                constexpr int W = 8;
-                const int nqb = (p->seqlen_q + 32 * W - 1) / (32 * W);
-                static const bool once = [] {
-                    (void)hipFuncSetAttribute((const void*)prefill_pipe_kernel<T, 128, W>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-                    return true;
-                }();
-                (void)once;
-                hipLaunchKernelGGL((prefill_pipe_kernel<T, 128, W>), dim3(nqb, p->h, p->b), dim3(64 * W), PfSmem<128>::kTotal, st, *p);
-                launched = true;
-            } else if (tiling == 2) {
+            if (tiling == 2) {
                 launch_prefill<T, 128, 4, 2, false>(p, st, use_tr);
+                launched = true;
+            } else if (tiling == 6) {
+                const int nqb = (p->seqlen_q + 255) / 256;
+                static const bool once6 = [] {
+                    (void)hipFuncSetAttribute((const void*)prefill_ilv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+                    return true;
+                }();
+                (void)once6;
+                int order;
+                const dim3 grid = prefill_grid(p, nqb, &order);
+                hipLaunchKernelGGL((prefill_ilv_kernel<T>), grid, dim3(512), PfSmem<128>::kTotal, st, *p, order, nqb);
                 launched = true;
             }
         }
