@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Hybrid batch (one prefill chunk + a decode batch in the same iteration, Sarathi scheduler): does running the two
+attention kernels on two HIP streams overlap the matrix-bound prefill with the HBM-bound decode on MI355X?
+Times, per layer: prefill alone, decode alone, both serial on one stream, both on two non-blocking streams
+(prefill tilings: default / 4-wave).  usage: python tools/hybrid_probe.py"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from tools.kbench import params  # noqa: E402
+from vattention_amd import kernels as K  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def launch(p, stream):
+    rc = K.klib().vattn_flash_attn_with_kvcache(C.byref(p), C.c_void_p(stream.cuda_stream))
+    if rc != 0:
+        raise RuntimeError(K.last_error())
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    torch.zeros(1, device=DEV)
+    s_main = torch.cuda.current_stream()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cases = [("llama8b chunk1k@15k + B64@16k", 32, 8, 1024, 15360, 64, 16384),
+             ("llama8b chunk512@8k + B128@8k", 32, 8, 512, 7680, 128, 8192),
+             ("llama8b chunk2k@30k + B32@32k", 32, 8, 2048, 30720, 32, 32768),
+             ("yi6b chunk4k@28k + B16@32k", 32, 4, 4096, 28672, 16, 32768),
+             ("llama70b/tp8 chunk2k@30k + B64@32k", 8, 1, 2048, 30720, 64, 32768)]
+    for name, Hq, Hkv, n, c, B, ctx in cases:
+        torch.manual_seed(0)
+        q = torch.randn(1, n, Hq, 128, device=DEV, dtype=torch.float16)
+        kc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        vc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
+        qd = torch.randn(B, 1, Hq, 128, device=DEV, dtype=torch.float16)
+        kd = torch.randn(B, ctx, Hkv, 128, device=DEV, dtype=torch.float16)
+        vd = torch.randn(B, ctx, Hkv, 128, device=DEV, dtype=torch.float16)
+        kn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=torch.float16)
+        vn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=torch.float16)
+        cld = torch.full((B,), ctx - 1, dtype=torch.int32, device=DEV)
+        idx = torch.arange(B, dtype=torch.int32, device=DEV)
+        pd, keepd = params(qd, kd, vd, cld, idx, kn, vn)
+        print("== %s" % name)
+        for variant, vname in ((0, "default tiling"), (8, "4-wave tiling")):
+            pp, keepp = params(q, kc, vc, cl, variant=variant)
+            t_p = timeit(lambda: launch(pp, s_main))
+            t_d = timeit(lambda: launch(pd, s_main))
+            t_ser = timeit(lambda: (launch(pp, s_main), launch(pd, s_main)))
+
+            def both():
+                s1.wait_stream(s_main)
+                s2.wait_stream(s_main)
+                launch(pp, s1)
+                launch(pd, s2)
+                s_main.wait_stream(s1)
+                s_main.wait_stream(s2)
+
+            t_par = timeit(both)
+
+            def both_rev():
+                s1.wait_stream(s_main)
+                s2.wait_stream(s_main)
+                launch(pd, s2)
+                launch(pp, s1)
+                s_main.wait_stream(s1)
+                s_main.wait_stream(s2)
+
+            t_par2 = timeit(both_rev)
+            print("  %-15s prefill %.3f ms  decode %.3f ms  serial %.3f ms  two streams %.3f / %.3f ms (decode first)  -> %.2fx of serial, ideal max() %.3f" % (
+                vname, t_p, t_d, t_ser, t_par, t_par2, t_ser / min(t_par, t_par2), max(t_p, t_d)))
+            del keepp
+        del keepd, kd, vd
+
+
+if __name__ == "__main__":
+    main()
