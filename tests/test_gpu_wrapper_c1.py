@@ -68,3 +68,47 @@ def test_c1_chunked_prefill_equals_unchunked():
     ref = flash_attn_with_kvcache_ref(Q[:, 3584:], K[:4096].unsqueeze(0).clone(), V[:4096].unsqueeze(0).clone(), cache_seqlens=4096,
                                       causal=True, softmax_scale=128 ** -0.5)
     assert (chunked[:, 3584:].double() - ref).abs().max().item() < 3e-3
+
+
+def test_hybrid_batches_two_streams_match_serial():
+    """Sarathi-style hybrid iterations (one prefill chunk + the running decodes): the two-stream backend (fa_streams, also
+    reached as fa_pod) must produce bit-identical attention outputs and cache contents to the serial fa_vattn backend."""
+    import torch
+    from vattention_amd.replay import CacheConfig, HotPathRunner, ModelConfig, ParallelConfig, Sequence, SequenceMetadata
+
+    def run(backend):
+        model = ModelConfig(name="tiny", num_layers=2, num_q_heads=8, num_kv_heads=2, head_size=128, dtype=torch.float16,
+                            max_model_len=4096, attention_backend=backend)
+        cache = CacheConfig(page_size=2 << 20, max_batch_size=4, memory_for_gpu=2 << 30)
+        r = HotPathRunner(model, ParallelConfig(1, 1), cache, device="cuda:0", seed=7)
+        r.sample_kv_util = False
+        outs = []
+
+        def step(mds):      # the runner computes on its own non-blocking stream: join before reading on the default stream
+            out = r.run_iteration(mds)
+            torch.cuda.synchronize()
+            outs.append(out.float().cpu())
+        try:
+            seqs = [Sequence(0, 700, 760), Sequence(1, 300, 340), Sequence(2, 1500, 1530)]
+            # prefill 0 and 1 whole, then chunk sequence 2 while 0 and 1 decode (hybrid iterations)
+            for s in seqs[:2]:
+                step([SequenceMetadata(s, s.prompt_len, True)])
+            while not seqs[2].prompt_done:
+                mds = [SequenceMetadata(seqs[2], 512, True)] + [SequenceMetadata(s, 0, False) for s in seqs[:2]]
+                step(mds)
+            for _ in range(3):
+                step([SequenceMetadata(s, 0, False) for s in seqs])
+            torch.cuda.synchronize()
+            k0 = r.engine.gpu_cache[1][0][:3, :1600].float().cpu()
+            v0 = r.engine.gpu_cache[1][1][:3, :1600].float().cpu()
+        finally:
+            r.close()
+        return outs, k0, v0
+
+    a, ka, va = run("fa_vattn")
+    for backend in ("fa_streams", "fa_pod"):
+        b, kb, vb = run(backend)
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        assert torch.equal(ka, kb) and torch.equal(va, vb)

@@ -60,3 +60,28 @@ def test_reference_wrapper_imports_against_dropins():
     finally:
         sys.modules.clear()
         sys.modules.update(saved)
+
+
+def test_backend_registry_resolves_native_and_hybrid_backends():
+    """attention/__init__.py:36-201 mirror: the fa_vattn family resolves to the native wrapper, fa_streams / fa_pod to the
+    two-stream hybrid wrapper, CUDA-library backends fail by name (no silent substitution)."""
+    import pytest
+    from vattention_amd import attention as A
+    prev = A.ATTENTION_BACKEND
+    try:
+        for name in ("fa_vattn", "FA_VATTN_SYNC", "fa_vattn_megacache"):
+            A.set_attention_backend(name)
+            assert type(A.get_attention_wrapper()).__name__ == "VAttentionFlashAttentionWrapper"
+            assert A.is_vattention_backend() and not A.is_vLLM_backend()
+        for name in ("fa_streams", "fa_pod", "fa_pod_megacache"):
+            A.set_attention_backend(name)
+            assert type(A.get_attention_wrapper()).__name__ == "VAttentionFlashAttentionStreamsWrapper"
+            assert A.is_vattention_backend()
+        for name in ("fi_vattn", "fa3_vattn", "fa_paged"):
+            A.set_attention_backend(name)
+            with pytest.raises(NotImplementedError):
+                A.get_attention_wrapper()
+        with pytest.raises(ValueError):
+            A.set_attention_backend("no_such_backend")
+    finally:
+        A.ATTENTION_BACKEND = prev

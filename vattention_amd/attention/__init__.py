@@ -2,7 +2,7 @@
 
 Every backend name of the reference is known; the names that select the `fa_vattn` family resolve to
 the MI355X-native wrapper.  Backends that exist in the reference only to wrap *other* CUDA libraries
-(FlashInfer, FA3, paged baselines, POD/streams variants — SURVEY §2.1 row 6, §8f) raise
+(FlashInfer, FA3, paged baselines — SURVEY §2.1 row 6) raise
 NotImplementedError by name instead of silently mapping to something else.
 """
 from __future__ import annotations
@@ -12,6 +12,7 @@ from typing import Union
 
 from .base_attention_wrapper import BaseAttentionWrapper  # noqa: F401
 from .no_op_attention_wrapper import NoOpAttentionWrapper
+from .vattention_flashattention_streams_wrapper import VAttentionFlashAttentionStreamsWrapper
 from .vattention_flashattention_wrapper import VAttentionFlashAttentionWrapper
 
 
@@ -62,6 +63,10 @@ _VLLM = {"FA_PAGED", "FI_PAGED", "FI_UNPAGED", "FI_SERIAL_PAGED"}
 _NATIVE = {AttentionBackend.FA_VATTN, AttentionBackend.FA_VATTN_SYNC, AttentionBackend.FA_VATTN_MEGACACHE,
            AttentionBackend.FA_VATTN_MEGACACHE_SYNC}
 
+# hybrid-batch backends: prefill || decode on two HIP streams (the reference's FA_STREAMS; its fused-kernel FA_POD maps here too)
+_NATIVE_HYBRID = {AttentionBackend.FA_STREAMS, AttentionBackend.FA_POD, AttentionBackend.FA_STREAMS_MEGACACHE,
+                  AttentionBackend.FA_POD_MEGACACHE}
+
 ATTENTION_BACKEND = AttentionBackend.NO_OP
 
 
@@ -86,9 +91,11 @@ def get_attention_wrapper():
         return NoOpAttentionWrapper.get_instance()
     if ATTENTION_BACKEND in _NATIVE:
         return VAttentionFlashAttentionWrapper.get_instance()
+    if ATTENTION_BACKEND in _NATIVE_HYBRID:
+        return VAttentionFlashAttentionStreamsWrapper.get_instance()
     raise NotImplementedError(
         f"attention backend {ATTENTION_BACKEND.value} wraps a CUDA-only library in the reference and has no "
-        "MI355X-native counterpart here; use FA_VATTN / FA_VATTN_SYNC / FA_VATTN_MEGACACHE[_SYNC]")
+        "MI355X-native counterpart here; use FA_VATTN / FA_VATTN_SYNC / FA_VATTN_MEGACACHE[_SYNC] / FA_STREAMS / FA_POD[_MEGACACHE]")
 
 
 def is_vattention_backend() -> bool:

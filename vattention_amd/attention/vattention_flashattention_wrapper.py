@@ -95,9 +95,17 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         assert self.is_metadata_initialized, "Metadata is not initialized."
         if self.is_profiling_iteration:
             return torch.zeros_like(query)       # memory-profiling pass: no attention (model_runner.py:192-201)
+        output = torch.empty_like(query)
+        tok = self._forward_prefills(query, key, value, kv_cache, softmax_scale, layer_id, output)
+        if self.decode_batch_size:
+            self._forward_decodes(query, key, value, kv_cache, softmax_scale, layer_id, output, tok)
+        return output
+
+    def _forward_prefills(self, query, key, value, kv_cache, softmax_scale, layer_id, output) -> int:
+        """Every prefill chunk of the iteration: cache_flat + causal attention against the cache prefix, written straight into
+        the chunk's rows of `output`.  Returns the number of tokens consumed (the decode rows start there)."""
         Hq, Hkv, D = self.num_q_heads, self.num_kv_heads, self.head_dim
         k_all, v_all = kv_cache
-        output = torch.empty_like(query)
         tok = 0
         for i, (c_len, q_len) in enumerate(zip(self.prefill_cache_lens, self.prefill_query_lens)):
             slot = self._batch_index_host[i]
@@ -116,8 +124,12 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                         causal=True, softmax_scale=softmax_scale,
                                         out=output[tok:tok + q_len].view(1, q_len, Hq, D))
             tok += q_len
-        if self.decode_batch_size == 0:
-            return output
+        return tok
+
+    def _forward_decodes(self, query, key, value, kv_cache, softmax_scale, layer_id, output, tok: int) -> None:
+        """ONE batched decode call: new K/V appended in-kernel at cache_seqlens of the slots named by cache_batch_idx."""
+        Hq, Hkv, D = self.num_q_heads, self.num_kv_heads, self.head_dim
+        k_all, v_all = kv_cache
         nb = self.decode_batch_size
         with self.get_timer(OperationMetrics.ATTN_INPUT_RESHAPE, layer_id):
             dq = query[tok:tok + nb].view(nb, 1, Hq, D)
@@ -129,4 +141,3 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                     softmax_scale=softmax_scale, causal=True,
                                     cache_batch_idx=self.batch_index_gen,
                                     out=output[tok:tok + nb].view(nb, 1, Hq, D))
-        return output

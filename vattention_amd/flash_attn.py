@@ -26,7 +26,8 @@ _workspaces = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one scratch buffer per (device, stream): split-KV partials of calls on different streams must not share storage
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
