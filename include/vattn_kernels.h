@@ -54,7 +54,7 @@ typedef struct vattn_attn_params {
     const int32_t* cache_seqlens;     /* int32[b] on device, or NULL: every sequence uses seqlen_k      */
     const int32_t* cache_batch_idx;   /* int32[b] on device, or NULL: identity                          */
     float* softmax_lse;               /* optional float[b, h, seqlen_q] (natural log), or NULL          */
-    /* split-KV workspace (decode form); sized by vattn_attn_workspace_bytes, may be NULL if 0 */
+    /* split-KV workspace; sized by vattn_attn_workspace_bytes, may be NULL if that returns 0 */
     void* workspace;
     int32_t b, seqlen_q, seqlen_k, seqlen_knew, h, h_k, d;
     int32_t is_causal;                /* bottom-right aligned; ignored when seqlen_q == 1               */
@@ -62,9 +62,12 @@ typedef struct vattn_attn_params {
     int32_t num_splits;               /* 0 = heuristic                                                  */
     float softmax_scale;
     int32_t variant;                  /* 0 = default; debug variants select alternative operand paths   */
+    int32_t max_seqlen_k_hint;        /* host-side upper bound of cache_seqlens[b] + seqlen_knew, or 0: unknown (seqlen_k is
+                                         only the cache tensor's row count); used to size the prefill KV split            */
 } vattn_attn_params;
 
-/* Bytes of split-KV workspace the call will need (0 for the prefill form). */
+/* Bytes of split-KV workspace the call will need: the decode form's partials, or the prefill form's when its grid
+ * would underfill the chip and the key range is split across workgroups (0 otherwise). */
 size_t vattn_attn_workspace_bytes(const vattn_attn_params* p);
 
 /* flash_attn_with_kvcache: appends k_new/v_new (if given) and attends; prefill form (seqlen_q > 1,

@@ -166,6 +166,54 @@ def test_head_dim_64(Hq, Hkv, dtype):
         _check(out, r64, r32, dtype, "d64 prefill variant=%d" % variant)
 
 
+@pytest.mark.parametrize("variant", [0, 2, 8, 1], ids=["default", "w8", "w4", "plain_reads"])
+@pytest.mark.parametrize("causal", [True, False], ids=["causal", "full"])
+def test_prefill_kv_split(causal, variant):
+    """KV-split prefill (the key range of a work item divided over workgroups, fp32 partials merged by combine_kernel):
+    forced split counts incl. more splits than tiles (empty shares), ragged batch through cache_batch_idx, LSE output."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(99)
+    B, n, Hq, Hkv, D, ctx = 2, 300, 8, 2, 128, 1500
+    q = torch.randn(B, n, Hq, D).half()
+    kc = torch.randn(3, ctx, Hkv, D).half()
+    vc = torch.randn(3, ctx, Hkv, D).half()
+    cl = torch.tensor([n + 900, n + 70], dtype=torch.int32)
+    idx = torch.tensor([2, 0], dtype=torch.int32)
+    ref64, lse64 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=causal, return_lse=True)
+    ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=causal, math="f32")
+    base = None
+    for splits in (1, 2, 3, 5, 16):
+        out, lse = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
+                                           causal=causal, num_splits=splits, return_softmax_lse=True, _variant=variant)
+        torch.cuda.synchronize()
+        _check(out, ref64, ref32, torch.float16, "kv-split prefill splits=%d" % splits)
+        assert torch.allclose(lse.double().cpu(), lse64.double(), atol=2e-3, rtol=1e-3), "lse splits=%d" % splits
+        if base is None:
+            base = out.float().cpu()
+        else:      # splitting only regroups the fp32 accumulation
+            assert (out.float().cpu() - base).abs().max().item() <= 2e-3
+
+
+def test_prefill_kv_split_heuristic_engages():
+    """A tensor-parallel-shard shape (8 query heads, one kv head, 2k chunk on a 30k prefix) must take the split path when the
+    caller passes the host-side length (workspace query > 0) and stay single-pass without it; results agree."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    import vattention_amd.flash_attn as FA
+    torch.manual_seed(5)
+    n, c, Hq, Hkv, D = 512, 6144, 8, 1, 128
+    q = torch.randn(1, n, Hq, D, device=DEV).half()
+    kc = torch.randn(1, 16384, Hkv, D, device=DEV).half()
+    vc = torch.randn(1, 16384, Hkv, D, device=DEV).half()
+    cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
+    FA._workspaces.clear()
+    a = flash_attn_with_kvcache(q, kc, vc, cache_seqlens=cl, causal=True)
+    assert not FA._workspaces, "no host-side length: single pass, no workspace"
+    b = flash_attn_with_kvcache(q, kc, vc, cache_seqlens=cl, causal=True, _max_seqlen_k=c + n)
+    torch.cuda.synchronize()
+    assert FA._workspaces, "host-side length known: the key range is split"
+    assert (a.float() - b.float()).abs().max().item() <= 2e-3
+
+
 def test_prefill_non_causal_and_seqlen_q_gt_k():
     from vattention_amd.flash_attn import flash_attn_func, flash_attn_with_kvcache
     torch.manual_seed(5)

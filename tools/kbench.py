@@ -33,6 +33,7 @@ def params(q, kc, vc, cl, idx=None, kn=None, vn=None, causal=True, splits=0, var
     p.b, p.seqlen_q, p.h, p.d = q.shape[0], q.shape[1], q.shape[2], q.shape[3]
     p.seqlen_k, p.h_k = kc.shape[1], kc.shape[2]
     p.is_causal, p.dtype, p.num_splits, p.softmax_scale, p.variant = int(causal), 0, splits, q.shape[3] ** -0.5, variant
+    p.max_seqlen_k_hint = kc.shape[1]        # the benchmark caches are exactly as long as the sequences
     keep = [out, q, kc, vc, cl, idx, kn, vn]
     need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
     if need:
@@ -53,7 +54,10 @@ def prefill(variant):
     print("== prefill (causal chunk n against c cached), fp16, D=128 ==")
     for name, Hq, Hkv, n, c in [("yi6b whole", 32, 4, 32702, 0), ("yi6b chunk4k@28k", 32, 4, 4096, 28672), ("yi6b chunk4k@0", 32, 4, 4096, 0),
                                 ("llama8b 16k", 32, 8, 16384, 0), ("yi34b/tp2 chunk16k@112k", 28, 4, 16384, 114688),
-                                ("llama70b/tp8 8k", 8, 1, 8192, 0), ("small 2k", 32, 4, 2048, 0)]:
+                                ("llama70b/tp8 8k", 8, 1, 8192, 0), ("small 2k", 32, 4, 2048, 0),
+                                ("llama70b/tp8 chunk2k@30k", 8, 1, 2048, 30720), ("llama70b/tp8 chunk512@16k", 8, 1, 512, 15872),
+                                ("yi34b/tp2 chunk1k@64k", 28, 4, 1024, 64512), ("llama70b/tp8 4k", 8, 1, 4096, 0),
+                                ("llama70b/tp8 2k", 8, 1, 2048, 0), ("llama8b chunk512@8k", 32, 8, 512, 7680)]:
         if ONLY and ONLY not in name:
             continue
         torch.manual_seed(0)
@@ -64,7 +68,7 @@ def prefill(variant):
         if scale != 1.0:
             q, kc, vc = q * scale, kc * scale, vc * scale
         cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
-        p, keep = params(q, kc, vc, cl, variant=variant)
+        p, keep = params(q, kc, vc, cl, variant=variant, splits=PF_SPLITS)
         ms = time_ms(p, 1, 3 if n > 10000 else 10)
         fl = 4.0 * Hq * 128 * (n * c + n * (n + 1) / 2)
         print("  %-26s n=%6d c=%6d Hq=%2d Hkv=%d : %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)" % (name, n, c, Hq, Hkv, ms, fl / ms / 1e9, fl / ms / 1e9 / 25))
@@ -97,11 +101,14 @@ def decode(variant):
 
 ONLY = None
 SPLITS = (0,)
+PF_SPLITS = 0
 
 if __name__ == "__main__":
     variant = 0
     if "--splits" in sys.argv:
         SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
+    if "--pf-splits" in sys.argv:
+        PF_SPLITS = int(sys.argv[sys.argv.index("--pf-splits") + 1])
     if "--only" in sys.argv:
         ONLY = sys.argv[sys.argv.index("--only") + 1]
     if "--variant" in sys.argv:

@@ -122,7 +122,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                 flash_attn_with_kvcache(q, k_rows.unsqueeze(0), v_rows.unsqueeze(0),
                                         cache_seqlens=self.current_total_len_device_lst[i],
                                         causal=True, softmax_scale=softmax_scale,
-                                        out=output[tok:tok + q_len].view(1, q_len, Hq, D))
+                                        out=output[tok:tok + q_len].view(1, q_len, Hq, D), _max_seqlen_k=c_len + q_len)
             tok += q_len
         return tok
 

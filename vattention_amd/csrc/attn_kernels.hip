@@ -189,12 +189,20 @@ template <int HD> struct PfSmem {
 // down K/V in step.  order 1: heaviest-first across heads without the XCD grouping.  order 0: grid (query block, head,
 // batch) - block-major per head (its tail is one head's heaviest blocks: 20-40 % slower on whole-prompt shapes).
 // Returns false for the padding workgroups of the 1-D grids.
-__device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order, int nqb, int& b, int& h, int& qb) {
+// KV-split (nsplit > 1, 1-D grids only): the grid is nsplit times larger; every run of 8 consecutive base ids (one per XCD) is
+// repeated nsplit times, so the splits of a work item stay on its XCD and start together.
+__device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order, int nqb, int nsplit, int& b, int& h, int& qb, int& split) {
+    split = 0;
     if (order == 0) {
         b = blockIdx.z; h = blockIdx.y; qb = (int)gridDim.x - 1 - (int)blockIdx.x;
         return true;
     }
-    const int L = blockIdx.x;
+    int L = blockIdx.x;
+    if (nsplit > 1) {
+        const int grp = L >> 3;
+        split = grp % nsplit;
+        L = ((grp / nsplit) << 3) | (L & 7);
+    }
     const int G = p.h / p.h_k;
     if (order == 2) {
         const int per = 8 / p.h_k;                         // XCDs per kv head (launch guarantees 8 % h_k == 0)
@@ -221,7 +229,7 @@ __device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order
 // MSUM: the softmax denominator is accumulated by the matrix pipe (one extra MFMA per 16 keys with an all-ones A
 // fragment, no LDS read) instead of 32 dependent v_add per tile: the kernel is VALU/issue-bound, the matrix pipe has slack.
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb) {
+__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     using S = PfSmem<HD>;
@@ -241,8 +249,8 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
     const int l31 = lane & 31;
     const int g = lane >> 5;
 
-    int b, h, qb;
-    if (!wg_to_work(p, order, nqb, b, h, qb)) return;
+    int b, h, qb, split;
+    if (!wg_to_work(p, order, nqb, nsplit, b, h, qb, split)) return;
     const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
     // loaded values are wave-uniform; readfirstlane makes that provable (descriptors must live in SGPRs)
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
@@ -256,7 +264,15 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
     int n_end = Lk;
     if (causal) n_end = min(Lk, q_wg0 + BM + off);             // last key any row of this block may see, +1
     if (n_end < 0) n_end = 0;
-    const int nt = (n_end + PF_BN - 1) / PF_BN;
+    const int nt_all = (n_end + PF_BN - 1) / PF_BN;
+    // KV-split: this workgroup owns key tiles [tb, nt) of the block's nt_all (an even share; shares past the end are empty
+    // and fall through to the epilogue, which then publishes a zero partial with lse = -inf)
+    int tb = 0, nt = nt_all;
+    if (nsplit > 1) {
+        const int per = (nt_all + nsplit - 1) / nsplit;
+        tb = min(nt_all, split * per);
+        nt = min(nt_all, tb + per);
+    }
 
     const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
     const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
@@ -344,15 +360,15 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
         }
     };
 
-    if (nt > 0) {
-        stage_load(0, kregA, vregA);
+    if (nt > tb) {
+        stage_load(tb, kregA, vregA);
         stage_write(0, kregA, vregA);
-        stage_load(1, kregB, vregB);
+        stage_load(tb + 1, kregB, vregB);
     }
     __syncthreads();
 
     auto tile_body = [&](int t, uint4 (&kld)[PASSES], uint4 (&vld)[PASSES], const uint4 (&kwr)[PASSES], const uint4 (&vwr)[PASSES]) {
-        const int buf = t & 1;
+        const int buf = (t - tb) & 1;
         if (!ABL(4)) stage_load(t + 2, kld, vld);     // two tiles ahead (past the last tile: all lanes out of range)
 
         const int n0 = t * PF_BN;
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
         if (!ABL(4)) stage_write(buf ^ 1, kwr, vwr);   // tile t+1 (issued one iteration ago) into the buffer last read in iteration t-1
         if (!ABL(5) && !ABL(4)) __syncthreads();
     };
-    for (int t = 0; t < nt; t += 2) {
+    for (int t = tb; t < nt; t += 2) {
         tile_body(t, kregA, vregA, kregB, vregB);
         if (t + 1 < nt) tile_body(t + 1, kregB, vregB, kregA, vregA);
     }
@@ -503,7 +519,23 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
         const int my_q = qw0 + 32 * qc + l31;
         const float l_tot = MSUM ? lacc[qc][0] : (l_run[qc] + swap_halves(l_run[qc]));
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-        if (my_q < Sq) {
+        if (my_q < Sq && nsplit > 1) {
+            // KV-split: normalised fp32 partial + its log2-domain LSE; combine_kernel merges the nsplit partials of a row
+            // workspace: float o_part[nsplit][B][Sq][H][HD]; float lse_part[nsplit][B][Sq][H]
+            const int64_t row = (((int64_t)split * p.b + b) * Sq + my_q) * p.h + h;
+            float* opart = (float*)p.workspace + row * HD;
+            float* lpart = (float*)p.workspace + (int64_t)nsplit * p.b * Sq * p.h * HD;
+#pragma unroll
+            for (int db = 0; db < DB; db++)
+#pragma unroll
+                for (int tq = 0; tq < 4; tq++) {
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
+                    *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                }
+            if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_run[qc] * sc + __log2f(l_tot));
+        } else if (my_q < Sq) {
             T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
 #pragma unroll
             for (int db = 0; db < DB; db++)
@@ -559,8 +591,8 @@ __global__ __launch_bounds__(512, 2) void prefill_ilv_kernel(vattn_attn_params p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int g = lane >> 5;
-    int b, h, qb;
-    if (!wg_to_work(p, order, nqb, b, h, qb)) return;
+    int b, h, qb, split_unused;
+    if (!wg_to_work(p, order, nqb, 1, b, h, qb, split_unused)) return;
     const int hk = h / (p.h / p.h_k);
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
     const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
@@ -1052,20 +1084,23 @@ __global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel
     }
 }
 
-// LSE-weighted merge of the split partials (flash_fwd_kernel.h:1116-1297). One 128-thread block per
-// (b, h): the split weights are computed once (lanes over splits), then every thread owns one d and
-// streams its partials with independent loads.
+// LSE-weighted merge of the split partials (flash_fwd_kernel.h:1116-1297). One 128-thread block per output row
+// (b, q, h): the split weights are computed once (lanes over splits), then every thread owns one d and streams its
+// partials with independent loads.  Serves the decode form (sq = 1) and the KV-split prefill form.
+// workspace: float o_part[splits][b][sq][h][HD]; float lse_part[splits][b][sq][h]  (log2 domain)
 template <typename T, int HD>
-__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits) {   // 128 threads: one per split weight, first HD also one per output column
+__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits, int sq) {   // 128 threads: one per split weight, first HD also one per output column
     __shared__ float wsm[128];
     __shared__ float red[4];
-    const int bh = blockIdx.x;                       // b * h + head
-    const int b = bh / p.h, hh = bh % p.h;
+    const int64_t row = blockIdx.x;                  // (b * sq + q) * h + head
+    const int hh = (int)(row % p.h);
+    const int64_t bq = row / p.h;
+    const int q = (int)(bq % sq), b = (int)(bq / sq);
     const int tid = threadIdx.x;
     const float* oacc = (const float*)p.workspace;
-    const float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
-    const int64_t sstride = (int64_t)p.b * p.h;
-    const float my = (tid < num_splits) ? lacc[(int64_t)tid * sstride + bh] : -INFINITY;    // num_splits <= 128
+    const int64_t sstride = (int64_t)p.b * sq * p.h;
+    const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
+    const float my = (tid < num_splits) ? lacc[(int64_t)tid * sstride + row] : -INFINITY;    // num_splits <= 128
     float mx = my;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));
@@ -1083,14 +1118,57 @@ __global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int n
     const float wsum = red[2] + red[3];
     const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
     if (tid < HD) {
-        const float* src = oacc + (int64_t)bh * HD + tid;
+        const float* src = oacc + row * HD + tid;
         float acc = 0.f;
 #pragma unroll 8
         for (int s = 0; s < num_splits; s++) acc += wsm[s] * src[(int64_t)s * sstride * HD];
-        ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
+        ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)q * p.o_row_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
     }
     if (p.softmax_lse && tid == 0)
-        p.softmax_lse[bh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+        p.softmax_lse[((int64_t)b * p.h + hh) * sq + q] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+}
+
+// Same merge for the KV-split prefill form, where there are b * sq * h output rows (tens of thousands) and at most 16
+// partials each: one WAVE per row (4 rows per 256-thread block), lane l < splits holds partial l's LSE, the weights are
+// broadcast by readlane, every lane owns two adjacent d.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void combine_rows_kernel(vattn_attn_params p, int num_splits, int sq, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b * sq + q) * h + head
+    if (row >= rows) return;
+    const int hh = (int)(row % p.h);
+    const int64_t bq = row / p.h;
+    const int q = (int)(bq % sq), b = (int)(bq / sq);
+    const float* oacc = (const float*)p.workspace;
+    const int64_t sstride = rows;
+    const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
+    const float my = (lane < num_splits) ? lacc[(int64_t)lane * sstride + row] : -INFINITY;
+    float mx = my;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));      // splits <= 16 live in lanes 0..15
+    mx = __shfl(mx, 0, 64);
+    const float mxs = (mx == -INFINITY) ? 0.f : mx;
+    const float w = (lane < num_splits) ? fast_exp2(my - mxs) : 0.f;
+    float wsum = w;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) wsum += xor_shuffle(wsum, o);
+    wsum = __shfl(wsum, 0, 64);
+    const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+    if (2 * lane < HD) {
+        const float* src = oacc + row * HD + 2 * lane;
+        float a0 = 0.f, a1 = 0.f;
+        for (int s = 0; s < num_splits; s++) {
+            const float ws = __shfl(w, s, 64);
+            const float2 v = *(const float2*)(src + (int64_t)s * sstride * HD);
+            a0 += ws * v.x;
+            a1 += ws * v.y;
+        }
+        T* dst = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)q * p.o_row_stride + (int64_t)hh * p.o_head_stride + 2 * lane;
+        dst[0] = Tr<T>::cvt(a0 * inv);
+        dst[1] = Tr<T>::cvt(a1 * inv);
+    }
+    if (p.softmax_lse && lane == 0)
+        p.softmax_lse[((int64_t)b * p.h + hh) * sq + q] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
 }
 
 // ============================================================================================
@@ -1236,11 +1314,88 @@ dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out) {
     return grid;
 }
 
-template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr) {
+// Prefill plan: tiling and KV split, decided on the host from the shapes (used by the launch and by the workspace query).
+//  tiling  0/1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows, 4 = 4 waves x 32 rows, 6 = hand-interleaved 8-wave kernel.
+//  nsplit  > 1 when the grid would leave CUs idle (tensor-parallel shards with few heads, short chunks): every work item's
+//          key range is divided over nsplit workgroups, fp32 partials go through the workspace, combine_kernel merges them.
+struct PrefillPlan { int tiling; int nsplit; };
+PrefillPlan plan_prefill(const vattn_attn_params* p) {
+    PrefillPlan pl;
+    pl.tiling = (p->variant >> 1) & 7;
+    pl.nsplit = 1;
+    const bool auto_tiling = pl.tiling == 0;
+    // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
+    // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
+    if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6))) pl.tiling = 1;
+    if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
+    // keys an average query block sees; without a host-side length only the chunk itself is certain
+    const long lk = p->max_seqlen_k_hint > 0 ? p->max_seqlen_k_hint : p->seqlen_q;
+    const long keys = p->is_causal ? (lk - p->seqlen_q / 2) : lk;
+    const long tiles = keys > 0 ? (keys + PF_BN - 1) / PF_BN : 1;
+    auto cap_by_tiles = [&](long want) {                             // >= 8 tiles (512 keys) per split: below that the
+        if (want > 8) want = 8;                                      // partials cost more than they return
+        while (want > 1 && tiles / want < 8) want--;
+        return want < 1 ? 1 : (int)want;
+    };
+    // equal-length work items (a chunk on a long prefix): the split count whose last round of resident workgroups is
+    // fullest, smallest such count if one is (nearly) exact; unequal lengths (causal whole prompt): two rounds, so that the
+    // dispatcher's heaviest-first order can even them out
+    const bool uniform = !p->is_causal || lk >= 4L * p->seqlen_q;
+    auto pick = [&](long wg, long slots) {
+        const int cap = cap_by_tiles(8);
+        if (!uniform) return cap_by_tiles((2 * slots + wg - 1) / wg);
+        int best = 1;
+        double best_eff = 0.0;
+        for (int ns = 1; ns <= cap; ns++) {
+            const double rounds = (double)(wg * ns) / slots;
+            const double eff = rounds / (double)((wg * ns + slots - 1) / slots);
+            if (eff >= 0.95) return ns;
+            if (eff >= best_eff - 1e-9) { best_eff = eff; best = ns; }
+        }
+        return best;
+    };
+    const long wg8 = (long)((p->seqlen_q + 255) / 256) * p->h * p->b;     // 8-wave workgroups: one per CU
+    const long wg4 = (long)((p->seqlen_q + 127) / 128) * p->h * p->b;     // 4-wave workgroups: two per CU
+    if (p->num_splits > 0) {                                         // forced (tests, benchmarks)
+        if (auto_tiling && wg8 <= 256) pl.tiling = 4;
+        pl.nsplit = p->num_splits > 16 ? 16 : p->num_splits;
+        return pl;
+    }
+    if (!auto_tiling) {                                              // explicit tiling: split only an underfilled grid
+        const long slots = pl.tiling == 4 ? 512 : 256, wg = pl.tiling == 4 ? wg4 : wg8;
+        if (wg < slots) pl.nsplit = pick(wg, slots);
+        return pl;
+    }
+    // Default.  A grid of >= 256 eight-wave workgroups fills the chip: no split (above one workgroup per CU the 8-wave
+    // tiling wins by 1-7 %; at exactly one per CU, causal work of very unequal length, the 4-wave tiling measures +19-22 %:
+    // Llama-70B/TP8 8k prompt 552 -> 676 TFLOP/s, 2k prompt 500 -> 594).  Below that (tensor-parallel shards with few heads,
+    // short chunks on long prefixes) split the key range over 8-wave workgroups; if even 8 splits leave most CUs idle, take
+    // the 4-wave tiling.  Measured (tools/kbench.py --pf-splits, profiles/r01_kbench.txt): Llama-70B/TP8 2k chunk @ 30k
+    // 393 -> 901 TFLOP/s, 512 chunk @ 16k 105 -> 568, Yi-34B/TP2 1k chunk @ 64k 653 -> 850.
+    if (wg8 > 256) return pl;
+    if (wg8 == 256) { pl.tiling = 4; return pl; }
+    const int ns8 = pick(wg8, 256);
+    if (ns8 == 1) { pl.tiling = 4; return pl; }                      // cannot split (short prefix): more, smaller workgroups
+    if (wg8 * ns8 >= 192) { pl.nsplit = ns8; return pl; }
+    pl.tiling = 4;
+    pl.nsplit = pick(wg4, 512);
+    return pl;
+}
+
+template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr, int nsplit) {
     constexpr int BM = 32 * QC * WAVES;
     const int nqb = (p->seqlen_q + BM - 1) / BM;
     int order;
-    const dim3 grid = prefill_grid(p, nqb, &order), block(64 * WAVES);
+    dim3 grid = prefill_grid(p, nqb, &order);
+    const dim3 block(64 * WAVES);
+    if (nsplit > 1) {
+        if (order == 0) {      // the split lives in the 1-D orders
+            vattn_attn_params q = *p;
+            q.variant = (p->variant & ~(3 << 5)) | (2 << 5);
+            grid = prefill_grid(&q, nqb, &order);
+        }
+        grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
+    }
     const size_t smem = PfSmem<HD>::kTotal;
     static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
@@ -1249,9 +1404,13 @@ template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(
     }();
     (void)attr_once;
     if (use_tr)
-        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
+        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit);
     else
-        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb);
+        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit);
+    if (nsplit > 1) {
+        const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
+        hipLaunchKernelGGL((combine_rows_kernel<T, HD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, nsplit, p->seqlen_q, rows);
+    }
 }
 
 template <typename T, int HD> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
@@ -1270,25 +1429,17 @@ template <typename T, int HD> int launch_attn_t(const vattn_attn_params* p, hipS
             hipLaunchKernelGGL((decode_kernel<T, HD, true>), grid, block, smem, st, *p, splits, gblocks, fused_append);
         else
             hipLaunchKernelGGL((decode_kernel<T, HD, false>), grid, block, smem, st, *p, splits, gblocks, fused_append);
-        if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits);
+        if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits, 1);
     } else {
         if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
-        // 0 = default (8 waves x 32 rows unless the grid is small, below); 1 = 8 waves x 32 rows, explicit; 2 = 4 waves x 64 rows;
-        // 4 = 4 waves x 32 rows; 6 = 8 waves, hand-interleaved MFMA/VALU groups (software-pipelined)
-        int tiling = (p->variant >> 1) & 7;
-        // default: 8-wave workgroups (256 query rows) unless they leave CUs idle or single-occupied with causal work of very
-        // unequal length: at <= one 8-wave workgroup per CU the 4-wave tiling (128 rows, two workgroups per CU) measures +19-22 %
-        // (Llama-70B/TP8 8k prompt 552 -> 676 TFLOP/s, 2k prompt 500 -> 594), above that the 8-wave tiling wins by 1-7 %
-        if (tiling == 0 && (long)((p->seqlen_q + 255) / 256) * p->h * p->b <= 256) tiling = 4;
-        // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
-        // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
-        if (tiling == 3 || tiling == 5 || (HD != 128 && (tiling == 2 || tiling == 6))) tiling = 1;
+        const PrefillPlan pl = plan_prefill(p);
+        if (pl.nsplit > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "KV-split prefill needs a workspace (vattn_attn_workspace_bytes)");
         bool launched = false;
         if constexpr (HD == 128) {
-            if (tiling == 2) {
-                launch_prefill<T, 128, 4, 2, false>(p, st, use_tr);
+            if (pl.tiling == 2) {
+                launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);
                 launched = true;
-            } else if (tiling == 6) {
+            } else if (pl.tiling == 6) {
                 const int nqb = (p->seqlen_q + 255) / 256;
                 static const bool once6 = [] {
                     (void)hipFuncSetAttribute((const void*)prefill_ilv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
@@ -1302,9 +1453,9 @@ template <typename T, int HD> int launch_attn_t(const vattn_attn_params* p, hipS
             }
         }
         if (launched) {
-        } else if (tiling == 4) launch_prefill<T, HD, 4, 1, false>(p, st, use_tr);
-        else if ((p->variant & 16) && HD == 128) launch_prefill<T, HD == 128 ? 128 : HD, 8, 1, HD == 128>(p, st, use_tr);      // denominator on the matrix pipe
-        else launch_prefill<T, HD, 8, 1, false>(p, st, use_tr);
+        } else if (pl.tiling == 4) launch_prefill<T, HD, 4, 1, false>(p, st, use_tr, pl.nsplit);
+        else if ((p->variant & 16) && HD == 128) launch_prefill<T, HD == 128 ? 128 : HD, 8, 1, HD == 128>(p, st, use_tr, pl.nsplit);      // denominator on the matrix pipe
+        else launch_prefill<T, HD, 8, 1, false>(p, st, use_tr, pl.nsplit);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
@@ -1344,7 +1495,11 @@ extern "C" {
 const char* vattn_kernels_last_error(void) { return g_err.c_str(); }
 
 size_t vattn_attn_workspace_bytes(const vattn_attn_params* p) {
-    if (!p || p->seqlen_q != 1 || p->h_k <= 0) return 0;
+    if (!p || p->h_k <= 0 || p->h <= 0 || p->b <= 0 || p->seqlen_q <= 0) return 0;
+    if (p->seqlen_q != 1) {
+        const int ns = plan_prefill(p).nsplit;
+        return ns > 1 ? (size_t)ns * p->b * p->seqlen_q * p->h * (p->d + 1) * sizeof(float) : 0;
+    }
     const int G = p->h / p->h_k;
     const int gblocks = (G + 15) / 16;
     const int splits = pick_splits(p, gblocks);

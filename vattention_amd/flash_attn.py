@@ -46,7 +46,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             cache_batch_idx: Optional[torch.Tensor] = None, cache_leftpad=None, block_table=None,
                             softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                             rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
-                            out=None, _variant=0):
+                            out=None, _variant=0, _max_seqlen_k: int = 0):
     if rotary_cos is not None or rotary_sin is not None:
         raise NotImplementedError("rotary embedding inside flash_attn_with_kvcache is not used by the vAttention path")
     if block_table is not None:
@@ -67,7 +67,11 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     if softmax_scale is None:
         softmax_scale = D ** (-0.5)
     dev = q.device
+    # host-side bound on the sequences' lengths (sizes the prefill KV split): known when cache_seqlens is an int or the
+    # caller (the attention wrapper, which has the lengths on the host) passes _max_seqlen_k; else the cache's row count
+    hint = int(_max_seqlen_k)
     if cache_seqlens is not None and isinstance(cache_seqlens, int):
+        hint = hint or cache_seqlens + (k.shape[1] if k is not None else 0)
         cache_seqlens = torch.full((B,), cache_seqlens, dtype=torch.int32, device=dev)
     if cache_seqlens is not None:
         if cache_seqlens.dtype != torch.int32:
@@ -119,6 +123,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.num_splits = int(num_splits)
     p.softmax_scale = float(softmax_scale)
     p.variant = int(_variant)
+    p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
     lib = K.klib()
     need = lib.vattn_attn_workspace_bytes(C.byref(p))
     ws = None

@@ -24,6 +24,7 @@ class AttnParams(C.Structure):
         ("cache_seqlens", vp), ("cache_batch_idx", vp), ("softmax_lse", vp), ("workspace", vp),
         ("b", i32), ("seqlen_q", i32), ("seqlen_k", i32), ("seqlen_knew", i32), ("h", i32), ("h_k", i32), ("d", i32),
         ("is_causal", i32), ("dtype", i32), ("num_splits", i32), ("softmax_scale", C.c_float), ("variant", i32),
+        ("max_seqlen_k_hint", i32),
     ]
 
 
