@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Hybrid batch (one prefill chunk + a decode batch in the same iteration, Sarathi scheduler): does running the two
 attention kernels on two HIP streams overlap the matrix-bound prefill with the HBM-bound decode on MI355X?
-Times, per layer: prefill alone, decode alone, both serial on one stream, both on two non-blocking streams
-(prefill tilings: default / 4-wave).  usage: python tools/hybrid_probe.py"""
+Times, per layer: prefill alone (default plan = KV-split when its grid underfills the chip, and single pass), decode alone,
+both serial on one stream, both on two non-blocking streams.  usage: python tools/hybrid_probe.py"""
 import ctypes as C
 import os
 import sys
@@ -59,34 +59,28 @@ def main():
         idx = torch.arange(B, dtype=torch.int32, device=DEV)
         pd, keepd = params(qd, kd, vd, cld, idx, kn, vn)
         print("== %s" % name)
-        for variant, vname in ((0, "default tiling"), (8, "4-wave tiling")):
-            pp, keepp = params(q, kc, vc, cl, variant=variant)
-            t_p = timeit(lambda: launch(pp, s_main))
-            t_d = timeit(lambda: launch(pd, s_main))
-            t_ser = timeit(lambda: (launch(pp, s_main), launch(pd, s_main)))
+        pa, keepa = params(q, kc, vc, cl, splits=0)      # default plan: KV-split when the grid underfills the chip
+        pu, keepu = params(q, kc, vc, cl, splits=1)      # single pass
+        t_pa = timeit(lambda: launch(pa, s_main))
+        t_pu = timeit(lambda: launch(pu, s_main))
+        t_d = timeit(lambda: launch(pd, s_main))
+        t_ser = timeit(lambda: (launch(pa, s_main), launch(pd, s_main)))
 
-            def both():
-                s1.wait_stream(s_main)
-                s2.wait_stream(s_main)
-                launch(pp, s1)
-                launch(pd, s2)
-                s_main.wait_stream(s1)
-                s_main.wait_stream(s2)
-
-            t_par = timeit(both)
-
-            def both_rev():
+        def both(pp):
+            def f():
                 s1.wait_stream(s_main)
                 s2.wait_stream(s_main)
                 launch(pd, s2)
                 launch(pp, s1)
                 s_main.wait_stream(s1)
                 s_main.wait_stream(s2)
+            return f
 
-            t_par2 = timeit(both_rev)
-            print("  %-15s prefill %.3f ms  decode %.3f ms  serial %.3f ms  two streams %.3f / %.3f ms (decode first)  -> %.2fx of serial, ideal max() %.3f" % (
-                vname, t_p, t_d, t_ser, t_par, t_par2, t_ser / min(t_par, t_par2), max(t_p, t_d)))
-            del keepp
+        t_par_u = timeit(both(pu))
+        t_par_a = timeit(both(pa))
+        print("  prefill %.3f ms (single pass %.3f)  decode %.3f ms | serial, default plan %.3f ms | two streams: single-pass prefill %.3f ms, "
+              "default-plan prefill %.3f ms | best/serial %.2fx" % (t_pa, t_pu, t_d, t_ser, t_par_u, t_par_a, t_ser / min(t_par_u, t_par_a, t_ser)))
+        del keepa, keepu
         del keepd, kd, vd
 
 

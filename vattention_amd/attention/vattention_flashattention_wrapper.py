@@ -47,6 +47,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         self._batch_index_host: Optional[List[int]] = None
         self.max_cache_len = 0
         self.decode_batch_size = 0
+        self._decode_lens_host: List[int] = []
 
     def get_cache_block(self, num_blocks: int, **kwargs):
         return None          # vAttention has no block tables
@@ -76,6 +77,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
             self.decode_batch_size = 0
             return
         self.decode_batch_size = len(dec)
+        self._decode_lens_host = dec
         self.decode_cache_lens = torch.tensor(dec, dtype=torch.int32, device=self.device)
         self.max_cache_len = max(dec) + 1
 
@@ -101,7 +103,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
             self._forward_decodes(query, key, value, kv_cache, softmax_scale, layer_id, output, tok)
         return output
 
-    def _forward_prefills(self, query, key, value, kv_cache, softmax_scale, layer_id, output) -> int:
+    def _forward_prefills(self, query, key, value, kv_cache, softmax_scale, layer_id, output, num_splits: int = 0) -> int:
         """Every prefill chunk of the iteration: cache_flat + causal attention against the cache prefix, written straight into
         the chunk's rows of `output`.  Returns the number of tokens consumed (the decode rows start there)."""
         Hq, Hkv, D = self.num_q_heads, self.num_kv_heads, self.head_dim
@@ -122,7 +124,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                 flash_attn_with_kvcache(q, k_rows.unsqueeze(0), v_rows.unsqueeze(0),
                                         cache_seqlens=self.current_total_len_device_lst[i],
                                         causal=True, softmax_scale=softmax_scale,
-                                        out=output[tok:tok + q_len].view(1, q_len, Hq, D), _max_seqlen_k=c_len + q_len)
+                                        out=output[tok:tok + q_len].view(1, q_len, Hq, D), _max_seqlen_k=c_len + q_len,
+                                        num_splits=num_splits)
             tok += q_len
         return tok
 
