@@ -78,6 +78,7 @@ def prefill(variant):
 def decode(variant):
     print("== decode (Sq=1, append + split-KV + combine), fp16, D=128 ==")
     for name, Hq, Hkv, B, ctx, slots in [("yi6b B16@32k", 32, 4, 16, 32768, 16), ("yi6b B1@32k", 32, 4, 1, 32768, 4), ("yi6b B4@32k", 32, 4, 4, 32768, 4),
+                                         ("yi6b B1@8k", 32, 4, 1, 8192, 4), ("yi6b B1@2k", 32, 4, 1, 2048, 4),
                                          ("llama8b B64@8k", 32, 8, 64, 8192, 64), ("llama8b B256@2k", 32, 8, 256, 2048, 256),
                                          ("llama70b/tp8 B64@32k", 8, 1, 64, 32768, 64), ("yi34b/tp2 B8@128k", 28, 4, 8, 131072, 8)]:
         if ONLY and ONLY not in name:

@@ -1277,7 +1277,9 @@ int pick_splits(const vattn_attn_params* p, int gblocks) {
     const int tiles = (max_len + DC_BN - 1) / DC_BN;
     long cap = tiles / 4;                       // at least one 32-key tile per wave and split
     if (cap < 1) cap = 1;
-    if (cap > 128) cap = 128;
+    // a split shorter than ~700 keys costs more in prologue / merge / combine than it returns: B1@32k 20.4 us at 32-48 splits
+    // vs 26 us at 128; short contexts still want one tile per wave (B1@2k: 16 splits 11 us vs 24 us unsplit)
+    if (cap > 48) cap = 48;
     if (wg * 10 >= slots * 6) return 1;      // the batch alone (nearly) fills the chip: splitting only adds combine work
     // otherwise: fill whole rounds of resident workgroups exactly (measured on MI355X, tools/kbench.py --splits:
     // 16 x 4 heads @32k: 12 splits = 768 workgroups 71.4 % of HBM peak vs 63.9-68.8 % for 4/6/8/16/24)
