@@ -32,7 +32,7 @@ def params(q, kc, vc, cl, idx=None, kn=None, vn=None, causal=True, splits=0, var
     p.cache_batch_idx = idx.data_ptr() if idx is not None else None
     p.b, p.seqlen_q, p.h, p.d = q.shape[0], q.shape[1], q.shape[2], q.shape[3]
     p.seqlen_k, p.h_k = kc.shape[1], kc.shape[2]
-    p.is_causal, p.dtype, p.num_splits, p.softmax_scale, p.variant = int(causal), 0, splits, q.shape[3] ** -0.5, variant
+    p.is_causal, p.dtype, p.num_splits, p.softmax_scale, p.variant = int(causal), (1 if q.dtype == torch.bfloat16 else 0), splits, q.shape[3] ** -0.5, variant
     p.max_seqlen_k_hint = kc.shape[1]        # the benchmark caches are exactly as long as the sequences
     keep = [out, q, kc, vc, cl, idx, kn, vn]
     need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
@@ -61,9 +61,9 @@ def prefill(variant):
         if ONLY and ONLY not in name:
             continue
         torch.manual_seed(0)
-        q = torch.randn(1, n, Hq, 128, device=DEV, dtype=torch.float16)
-        kc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
-        vc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        q = torch.randn(1, n, Hq, 128, device=DEV, dtype=DTYPE)
+        kc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=DTYPE)
+        vc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=DTYPE)
         scale = float(os.environ.get("KBENCH_DATA_SCALE", "1"))     # 0 = zero-filled inputs (data-dependent power: clocks rise)
         if scale != 1.0:
             q, kc, vc = q * scale, kc * scale, vc * scale
@@ -84,11 +84,11 @@ def decode(variant):
         if ONLY and ONLY not in name:
             continue
         torch.manual_seed(0)
-        q = torch.randn(B, 1, Hq, 128, device=DEV, dtype=torch.float16)
-        kc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=torch.float16)
-        vc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=torch.float16)
-        kn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=torch.float16)
-        vn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=torch.float16)
+        q = torch.randn(B, 1, Hq, 128, device=DEV, dtype=DTYPE)
+        kc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=DTYPE)
+        vc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=DTYPE)
+        kn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=DTYPE)
+        vn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=DTYPE)
         cl = torch.full((B,), ctx - 1, dtype=torch.int32, device=DEV)
         idx = torch.arange(B, dtype=torch.int32, device=DEV) % slots
         for splits in SPLITS:
@@ -101,6 +101,7 @@ def decode(variant):
 
 
 ONLY = None
+DTYPE = torch.float16
 SPLITS = (0,)
 PF_SPLITS = 0
 
@@ -108,6 +109,8 @@ if __name__ == "__main__":
     variant = 0
     if "--splits" in sys.argv:
         SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
+    if "--bf16" in sys.argv:
+        DTYPE = torch.bfloat16
     if "--pf-splits" in sys.argv:
         PF_SPLITS = int(sys.argv[sys.argv.index("--pf-splits") + 1])
     if "--only" in sys.argv:
