@@ -112,3 +112,79 @@ def test_hybrid_batches_two_streams_match_serial():
         for x, y in zip(a, b):
             assert torch.equal(x, y)
         assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
+def test_pool_pressure_reclaim_and_remap_keep_kv_intact():
+    """End-to-end integrity under memory pressure: a pool that holds ~3.5 sequences, sequences finishing (their pages stay mapped:
+    deferred reclamation) and new ones starting in OTHER slots, so pages are reclaimed on demand, unmapped, remapped at new
+    virtual addresses (quiesce + TLB invalidation path) while other sequences keep decoding.  Every attention
+    output of every iteration is compared with the CPU oracle evaluated on a host copy of that sequence's K/V."""
+    from vattention_amd import vattention
+    from vattention_amd.replay import CacheConfig, HotPathRunner, ModelConfig, ParallelConfig, Sequence, SequenceMetadata
+    Hq, Hkv, D = 4, 2, 128
+    model = ModelConfig(name="tiny", num_layers=1, num_q_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype=torch.float16,
+                        max_model_len=2048, attention_backend="fa_vattn")
+    page = 64 << 10                                   # 128 tokens per page; one page-group = 2 pages (1 layer)
+    groups = 29                                       # 3712 tokens of KV in total
+    r = HotPathRunner(model, ParallelConfig(1, 1), CacheConfig(page_size=page, max_batch_size=6, memory_for_gpu=groups * 2 * page), seed=3)
+    r.sample_kv_util = False
+    host_kv, checked = {}, 0
+    vm0 = vattention.stats()
+
+    def step(mds):
+        nonlocal checked
+        T = sum(md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len) if md.is_prompt else 1 for md in mds)
+        q, k, v = r._qkv(T)
+        torch.cuda.synchronize()
+        qh, kh, vh = q.cpu(), k.cpu(), v.cpu()
+        before = {md.seq.seq_id: md.seq.get_num_prompt_tokens_processed() for md in mds if md.is_prompt}
+        out = r.run_iteration(mds)
+        torch.cuda.synchronize()
+        tok = 0
+        for md in mds:
+            sid = md.seq.seq_id
+            n = (md.seq.prompt_processed - before[sid]) if md.is_prompt else 1
+            kk, vv = kh[tok:tok + n].view(n, Hkv, D), vh[tok:tok + n].view(n, Hkv, D)
+            pk, pv = host_kv.get(sid, (kk[:0], vv[:0]))
+            host_kv[sid] = (torch.cat([pk, kk]), torch.cat([pv, vv]))
+            fk, fv = host_kv[sid]
+            ref = flash_attn_with_kvcache_ref(qh[tok:tok + n].view(1, n, Hq, D), fk.unsqueeze(0).clone(), fv.unsqueeze(0).clone(),
+                                              cache_seqlens=fk.shape[0], causal=True, softmax_scale=D ** -0.5)
+            got = out[tok:tok + n].view(1, n, Hq, D).double().cpu()
+            err = (got - ref).abs().max().item()
+            assert err < 4e-3, "seq %d (%s, %d tokens): mismatch %.3e after %d checks" % (sid, "prefill" if md.is_prompt else "decode", fk.shape[0], err, checked)
+            checked += 1
+            tok += n
+
+    try:
+        # three sequences of ~1000 tokens fill 24-27 of the 29 groups; sequence 2 outlives the others and keeps decoding
+        # while pages move between slots
+        live = [Sequence(0, 950, 1000), Sequence(1, 987, 1037), Sequence(2, 1024, 1144)]
+        for s in live:
+            step([SequenceMetadata(s, s.prompt_len, True)])
+        for _ in range(5):
+            step([SequenceMetadata(s, 0, False) for s in live])
+        # sequences 0 and 1 finish (their slots keep their pages); two new, LONGER sequences arrive: the pool has 4 free
+        # groups, each newcomer needs 10-11 -> on-demand reclamation from the finished slots, remap into the new slots
+        for s in live[:2]:
+            while not s.is_finished():
+                step([SequenceMetadata(x, 0, False) for x in live if not x.is_finished()])
+        assert not live[2].is_finished()
+        live = [live[2]]
+        # admission-respecting sizes: 9 (seq 2) + 12 + 7 groups = 28 <= 29.  The 12-group newcomer takes a finished slot (8-9 groups
+        # mapped, best fit) and must pull the rest out of the OTHER finished slot: unmap there, map here
+        for i, plen in ((3, 1480), (4, 850)):
+            s = Sequence(i, plen, plen + 30)
+            while not s.prompt_done:
+                step([SequenceMetadata(s, 600, True)])
+            live.append(s)
+            step([SequenceMetadata(x, 0, False) for x in live if not x.is_finished()])
+        for _ in range(8):
+            step([SequenceMetadata(x, 0, False) for x in live if not x.is_finished()])
+        assert not live[0].is_finished(), "sequence 2 must still be decoding: it was live through every remap"
+        vm1 = vattention.stats()
+        assert vm1["unmap_calls"] > vm0["unmap_calls"], "the scenario must force on-demand reclamation (unmap + remap)"
+        assert vm1["tlb_flushes"] > vm0["tlb_flushes"]
+        assert checked >= 30
+    finally:
+        r.close()
