@@ -138,3 +138,31 @@ def test_lazy_pool_and_driver_failure_surface():
     with pytest.raises(RuntimeError):
         p.step([8000, 0] if s == 0 else [0, 8000], False)
     p.pm.close()
+
+
+@pytest.mark.parametrize("flags", [0, 4], ids=["mapper_thread", "inline"])
+def test_lifecycle_cleanup_twice_use_after_cleanup_destroy_with_pending_work(flags):
+    """Teardown paths of the C ABI: cleanup is idempotent, mutating calls after cleanup are explicit errors (the reference
+    dereferences freed state), destroying a manager whose mapper thread still has a batch queued joins it and releases
+    every handle and reservation."""
+    cfg = dict(num_layers=2, num_kv_heads=2, head_size=128, max_batch_size=4, max_context_length=1024, itemsize=2,
+               page_size=65536, megacache=False)
+    p = ProductImpl(cfg, flags=flags)
+    assert p.reserve_physical_pages(40 * 65536) == 40
+    assert p.alloc_new_batch_idx(100) == 0
+    p.step_async([300, 0, 0, 0])
+    p.cleanup()
+    c = fake_counters()
+    assert c["violations"] == 0 and c["live_handles"] == 0 and c["mapped_pages"] == 0 and c["reserved_ranges"] == 0
+    p.cleanup()                                        # second cleanup: no-op
+    for call in (lambda: p.step_async([1, 0, 0, 0]), lambda: p.step([1, 0, 0, 0], True), lambda: p.reserve_physical_pages(8 * 65536)):
+        with pytest.raises(ValueError):
+            call()
+    assert p.alloc_new_batch_idx(5) == -1
+    assert fake_counters()["violations"] == 0
+    q = ProductImpl(cfg, flags=flags)
+    q.reserve_physical_pages(40 * 65536)
+    q.step_async([500, 400, 0, 0])                     # look-ahead work is queued for the mapper thread
+    q.pm.close()                                       # vattn_destroy without cleanup(): must join, unmap, release, free
+    c = fake_counters()
+    assert c["violations"] == 0 and c["live_handles"] == 0 and c["mapped_pages"] == 0 and c["reserved_ranges"] == 0
