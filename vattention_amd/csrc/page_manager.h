@@ -104,6 +104,7 @@ private:
     std::vector<uint64_t> bases_;
     std::vector<uint64_t> handles_;              // page id -> backend handle (0 = not created yet)
     std::vector<uint8_t> created_;
+    std::vector<uint32_t> create_order_;         // page ids in creation order: handles are released oldest-first (see cleanup)
     std::atomic<uint64_t> precreate_left_{0};   // ids [0, precreate_left_) still to be looked at, top down
     std::atomic<uint64_t> join_wait_ns_{0};
     uint64_t precreate_floor_ = 0;              // ids below this are created on first use only
