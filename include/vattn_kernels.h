@@ -56,6 +56,11 @@ typedef struct vattn_attn_params {
     float* softmax_lse;               /* optional float[b, h, seqlen_q] (natural log), or NULL          */
     /* split-KV workspace; sized by vattn_attn_workspace_bytes, may be NULL if that returns 0 */
     void* workspace;
+    /* batched prefill of several sequences with DIFFERENT chunk lengths (MI355X extension; both NULL otherwise): q / out are
+     * then [total_tokens, h, d] (q_batch_stride / o_batch_stride ignored), batch entry i owns rows
+     * [q_start[i], q_start[i] + q_lens[i]) and seqlen_q is the maximum of q_lens (it sizes the grid) */
+    const int32_t* q_start;           /* int32[b] on device */
+    const int32_t* q_lens;            /* int32[b] on device */
     int32_t b, seqlen_q, seqlen_k, seqlen_knew, h, h_k, d;
     int32_t is_causal;                /* bottom-right aligned; ignored when seqlen_q == 1               */
     int32_t dtype;                    /* VATTN_DTYPE_*                                                  */

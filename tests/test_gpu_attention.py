@@ -214,6 +214,42 @@ def test_prefill_kv_split_heuristic_engages():
     assert (a.float() - b.float()).abs().max().item() <= 2e-3
 
 
+@pytest.mark.parametrize("variant,splits", [(0, 0), (2, 0), (8, 0), (0, 3), (2, 2)], ids=["default", "w8", "w4", "default_split3", "w8_split2"])
+def test_batched_variable_length_prefill(variant, splits):
+    """One launch for the chunks of several sequences with different lengths (flash_attn_varlen_with_kvcache): every entry
+    must equal the single-sequence call bit for bit and match the oracle; entries shorter than the grid's block count, an
+    entry of length 1, chunks on long and short prefixes, slots through cache_batch_idx."""
+    from vattention_amd.flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
+    torch.manual_seed(11)
+    Hq, Hkv, D, ctx = 8, 2, 128, 1400
+    q_lens = [300, 1, 513, 37, 256]
+    prefix = [0, 700, 64, 1000, 5]
+    slots = [4, 0, 2, 5, 1]
+    T = sum(q_lens)
+    q = torch.randn(T, Hq, D).half()
+    kc = torch.randn(6, ctx, Hkv, D).half()
+    vc = torch.randn(6, ctx, Hkv, D).half()
+    starts = [sum(q_lens[:i]) for i in range(len(q_lens))]
+    cl = [c + n for c, n in zip(prefix, q_lens)]
+    qg, kg, vg = q.to(DEV), kc.to(DEV), vc.to(DEV)
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
+    out = flash_attn_varlen_with_kvcache(qg, kg, vg, i32(starts), i32(q_lens), max(q_lens), i32(cl), i32(slots), causal=True,
+                                         num_splits=splits, _variant=variant, _max_seqlen_k=max(cl))
+    torch.cuda.synchronize()
+    for i, (s0, n) in enumerate(zip(starts, q_lens)):
+        qi = q[s0:s0 + n].unsqueeze(0)
+        cli = torch.tensor([cl[i]], dtype=torch.int32)
+        idxi = torch.tensor([slots[i]], dtype=torch.int32)
+        ref64 = flash_attn_with_kvcache_ref(qi, kc, vc, cache_seqlens=cli, cache_batch_idx=idxi, causal=True)
+        ref32 = flash_attn_with_kvcache_ref(qi, kc, vc, cache_seqlens=cli, cache_batch_idx=idxi, causal=True, math="f32")
+        _check(out[s0:s0 + n].unsqueeze(0), ref64, ref32, torch.float16, "varlen entry %d" % i)
+        if n > 1 and splits == 0:
+            one = flash_attn_with_kvcache(qg[s0:s0 + n].unsqueeze(0), kg, vg, cache_seqlens=cli.to(DEV), cache_batch_idx=idxi.to(DEV),
+                                          causal=True, num_splits=1, _variant=variant)
+            if variant != 0:            # same tiling on both sides (the default plan picks by grid size): bit-identical
+                assert torch.equal(one[0].cpu(), out[s0:s0 + n].cpu())
+
+
 def test_prefill_non_causal_and_seqlen_q_gt_k():
     from vattention_amd.flash_attn import flash_attn_func, flash_attn_with_kvcache
     torch.manual_seed(5)

@@ -188,3 +188,47 @@ def test_pool_pressure_reclaim_and_remap_keep_kv_intact():
         assert checked >= 30
     finally:
         r.close()
+
+
+def test_multi_prompt_iteration_uses_one_batched_launch_and_matches_oracle():
+    """vLLM-scheduler iterations that carry several (short) prompts: the wrapper appends each chunk and issues ONE batched
+    variable-length attention launch; outputs must match the oracle per sequence, then decode continues normally."""
+    from vattention_amd.replay import CacheConfig, HotPathRunner, ModelConfig, ParallelConfig, Sequence, SequenceMetadata
+    Hq, Hkv, D = 8, 2, 128
+    model = ModelConfig(name="tiny", num_layers=2, num_q_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype=torch.float16,
+                        max_model_len=2048, attention_backend="fa_vattn")
+    r = HotPathRunner(model, ParallelConfig(1, 1), CacheConfig(page_size=2 << 20, max_batch_size=8, memory_for_gpu=1 << 30), seed=5)
+    r.sample_kv_util = False
+    host_kv = {}
+
+    def step(mds):
+        T = sum(md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len) if md.is_prompt else 1 for md in mds)
+        q, k, v = r._qkv(T)
+        torch.cuda.synchronize()
+        qh, kh, vh = q.cpu(), k.cpu(), v.cpu()
+        before = {md.seq.seq_id: md.seq.get_num_prompt_tokens_processed() for md in mds if md.is_prompt}
+        out = r.run_iteration(mds)
+        torch.cuda.synchronize()
+        tok = 0
+        for md in mds:
+            sid = md.seq.seq_id
+            n = (md.seq.prompt_processed - before[sid]) if md.is_prompt else 1
+            kk, vv = kh[tok:tok + n].view(n, Hkv, D), vh[tok:tok + n].view(n, Hkv, D)
+            pk, pv = host_kv.get(sid, (kk[:0], vv[:0]))
+            host_kv[sid] = (torch.cat([pk, kk]), torch.cat([pv, vv]))
+            fk, fv = host_kv[sid]
+            ref = flash_attn_with_kvcache_ref(qh[tok:tok + n].view(1, n, Hq, D), fk.unsqueeze(0).clone(), fv.unsqueeze(0).clone(),
+                                              cache_seqlens=fk.shape[0], causal=True, softmax_scale=D ** -0.5)
+            err = (out[tok:tok + n].view(1, n, Hq, D).double().cpu() - ref).abs().max().item()
+            assert err < 4e-3, "seq %d: mismatch %.3e" % (sid, err)
+            tok += n
+
+    try:
+        seqs = [Sequence(0, 333, 340), Sequence(1, 64, 70), Sequence(2, 700, 705), Sequence(3, 129, 133)]
+        step([SequenceMetadata(s, s.prompt_len, True) for s in seqs[:3]])              # three whole prompts in one iteration
+        step([SequenceMetadata(seqs[3], 100, True)] + [SequenceMetadata(s, 0, False) for s in seqs[:3]])
+        step([SequenceMetadata(seqs[3], 100, True)] + [SequenceMetadata(s, 0, False) for s in seqs[:3]])
+        for _ in range(3):
+            step([SequenceMetadata(s, 0, False) for s in seqs if not s.is_finished()])
+    finally:
+        r.close()

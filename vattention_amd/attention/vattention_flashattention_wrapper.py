@@ -23,7 +23,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from ..cache_ops import cache_flat
-from ..flash_attn import flash_attn_with_kvcache
+from ..flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
 from .base_attention_wrapper import BaseAttentionWrapper
 from .timers import OperationMetrics
 
@@ -68,9 +68,11 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                 dec.append(md.seq.get_len() - 1)
         self.prefill_query_lens = q_lens
         self.prefill_cache_lens = c_lens
-        if totals:      # one H2D copy for all prefills, then 1-element views
-            allt = torch.tensor(totals, dtype=torch.int32, device=self.device)
-            self.current_total_len_device_lst = [allt[i:i + 1] for i in range(len(totals))]
+        if totals:      # one H2D copy for all prefills, then views
+            starts = [sum(q_lens[:i]) for i in range(len(q_lens))]
+            meta = torch.tensor([totals, starts, q_lens], dtype=torch.int32, device=self.device)
+            self.current_total_len_device_lst = [meta[0, i:i + 1] for i in range(len(totals))]
+            self._prefill_totals, self._prefill_starts, self._prefill_qlens = meta[0], meta[1], meta[2]
         else:
             self.current_total_len_device_lst = []
         if not dec:
@@ -108,6 +110,24 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         the chunk's rows of `output`.  Returns the number of tokens consumed (the decode rows start there)."""
         Hq, Hkv, D = self.num_q_heads, self.num_kv_heads, self.head_dim
         k_all, v_all = kv_cache
+        P = len(self.prefill_query_lens)
+        if P >= 2 and max(self.prefill_query_lens) >= 2:
+            # several prompts / chunks in one iteration (vLLM scheduler with short prompts): append each chunk's K/V, then ONE
+            # batched launch over all of them instead of the reference's one attention call per prompt (:129-174)
+            tok = 0
+            with self.get_timer(OperationMetrics.ATTN_KV_CACHE_SAVE, layer_id):
+                for i, (c_len, q_len) in enumerate(zip(self.prefill_cache_lens, self.prefill_query_lens)):
+                    slot = self._batch_index_host[i]
+                    cache_flat(key[tok:tok + q_len].view(q_len, Hkv, D), value[tok:tok + q_len].view(q_len, Hkv, D),
+                               k_all[slot][c_len:], v_all[slot][c_len:], "auto")
+                    tok += q_len
+            with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id):
+                flash_attn_varlen_with_kvcache(query[:tok].view(tok, Hq, D), k_all, v_all, self._prefill_starts, self._prefill_qlens,
+                                               max(self.prefill_query_lens), self._prefill_totals, self.batch_index[:P],
+                                               softmax_scale=softmax_scale, causal=True, out=output[:tok].view(tok, Hq, D),
+                                               num_splits=num_splits,
+                                               _max_seqlen_k=max(c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)))
+            return tok
         tok = 0
         for i, (c_len, q_len) in enumerate(zip(self.prefill_cache_lens, self.prefill_query_lens)):
             slot = self._batch_index_host[i]

@@ -255,10 +255,13 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
     // loaded values are wave-uniform; readfirstlane makes that provable (descriptors must live in SGPRs)
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
     const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
-    const int Sq = p.seqlen_q;
+    // batched chunks of different lengths: entry b owns rows [q_first, q_first + Sq) of the flattened q / out
+    const int Sq = p.q_lens ? __builtin_amdgcn_readfirstlane(p.q_lens[b]) : p.seqlen_q;
+    const int64_t q_first = p.q_start ? (int64_t)__builtin_amdgcn_readfirstlane(p.q_start[b]) : 0;
     const bool causal = p.is_causal != 0;
     const int off = Lk - Sq;                                   // bottom-right alignment (mask.h:164-196)
     const int q_wg0 = qb * BM;
+    if (q_wg0 >= Sq) return;                                   // shorter chunk than the grid was sized for (before any barrier)
     const int qw0 = q_wg0 + wave * 32 * QC;                    // first query row of this wave
 
     int n_end = Lk;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
 #pragma unroll
     for (int qc = 0; qc < QC; qc++) {
         const int my_q = qw0 + 32 * qc + l31;
-        const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
+        const T* qptr = (const T*)p.q + (p.q_start ? 0 : (int64_t)b * p.q_batch_stride) + (q_first + my_q) * p.q_row_stride + (int64_t)h * p.q_head_stride;
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -522,9 +525,9 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
         if (my_q < Sq && nsplit > 1) {
             // KV-split: normalised fp32 partial + its log2-domain LSE; combine_kernel merges the nsplit partials of a row
             // workspace: float o_part[nsplit][B][Sq][H][HD]; float lse_part[nsplit][B][Sq][H]
-            const int64_t row = (((int64_t)split * p.b + b) * Sq + my_q) * p.h + h;
+            const int64_t row = (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
             float* opart = (float*)p.workspace + row * HD;
-            float* lpart = (float*)p.workspace + (int64_t)nsplit * p.b * Sq * p.h * HD;
+            float* lpart = (float*)p.workspace + (int64_t)nsplit * p.b * p.seqlen_q * p.h * HD;
 #pragma unroll
             for (int db = 0; db < DB; db++)
 #pragma unroll
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
                 }
             if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_run[qc] * sc + __log2f(l_tot));
         } else if (my_q < Sq) {
-            T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
+            T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + my_q) * p.o_row_stride + (int64_t)h * p.o_head_stride;
 #pragma unroll
             for (int db = 0; db < DB; db++)
 #pragma unroll
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
             if (p.softmax_lse && g == 0) {
                 // natural-log LSE of scale*QK^T; +inf for fully masked rows (flash convention)
                 const float lse = (l_tot == 0.f) ? INFINITY : (m_run[qc] * p.softmax_scale + __logf(l_tot));
-                p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
+                p.softmax_lse[((int64_t)b * p.h + h) * p.seqlen_q + my_q] = lse;
             }
         }
     }
@@ -1139,6 +1142,8 @@ __global__ __launch_bounds__(256) void combine_rows_kernel(vattn_attn_params p, 
     const int hh = (int)(row % p.h);
     const int64_t bq = row / p.h;
     const int q = (int)(bq % sq), b = (int)(bq / sq);
+    if (p.q_lens && q >= p.q_lens[b]) return;             // batched chunks: rows past this entry's length were never produced
+    const int64_t q_first = p.q_start ? p.q_start[b] : 0;
     const float* oacc = (const float*)p.workspace;
     const int64_t sstride = rows;
     const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(256) void combine_rows_kernel(vattn_attn_params p, 
             a0 += ws * v.x;
             a1 += ws * v.y;
         }
-        T* dst = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)q * p.o_row_stride + (int64_t)hh * p.o_head_stride + 2 * lane;
+        T* dst = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + q) * p.o_row_stride + (int64_t)hh * p.o_head_stride + 2 * lane;
         dst[0] = Tr<T>::cvt(a0 * inv);
         dst[1] = Tr<T>::cvt(a1 * inv);
     }
@@ -1329,6 +1334,7 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
     // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
     if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6))) pl.tiling = 1;
+    if (pl.tiling == 6 && p->q_lens) pl.tiling = 1;                  // the interleaved kernel has no batched-chunk form
     if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
     // keys an average query block sees; without a host-side length only the chunk itself is certain
     const long lk = p->max_seqlen_k_hint > 0 ? p->max_seqlen_k_hint : p->seqlen_q;
@@ -1478,6 +1484,9 @@ int validate(const vattn_attn_params* p) {
     if (p->k_new && !p->cache_seqlens)
         return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");        // :1453
     if (p->seqlen_q <= 0 || p->seqlen_k < 0) return fail(VATTN_K_ERR_INVALID, "bad sequence lengths");
+    if ((p->q_start == nullptr) != (p->q_lens == nullptr)) return fail(VATTN_K_ERR_INVALID, "q_start and q_lens must be given together");
+    if (p->q_lens && p->seqlen_q == 1) return fail(VATTN_K_ERR_UNSUPPORTED, "batched chunks need max(q_lens) > 1 (the decode form is already batched)");
+    if (p->q_lens && p->k_new) return fail(VATTN_K_ERR_UNSUPPORTED, "batched chunks: append the new keys/values with cache_flat first");
     // 16-byte vector access requirements
     const int64_t strides[] = {p->q_batch_stride, p->q_row_stride, p->q_head_stride, p->k_batch_stride, p->k_row_stride,
                                p->k_head_stride, p->v_batch_stride, p->v_row_stride, p->v_head_stride};

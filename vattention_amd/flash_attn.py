@@ -143,3 +143,67 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
         raise NotImplementedError("dropout / attention probabilities are not supported (inference path)")
     return flash_attn_with_kvcache(q, k, v, softmax_scale=softmax_scale, causal=causal, window_size=window_size,
                                    softcap=softcap, alibi_slopes=alibi_slopes)
+
+
+def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q_lens: torch.Tensor, max_q_len: int,
+                                   cache_seqlens: torch.Tensor, cache_batch_idx: Optional[torch.Tensor] = None,
+                                   softmax_scale=None, causal=True, out=None, num_splits=0, _variant=0, _max_seqlen_k: int = 0):
+    """MI355X extension (SURVEY §8f "batched multi-prefill"): ONE launch for the prefill chunks of several sequences with
+    different lengths.  q / out are the flattened tokens [T, Hq, D]; entry i attends with rows [q_start[i], q_start[i] +
+    q_lens[i]) over cache slot cache_batch_idx[i] (identity if None), keys [0, cache_seqlens[i]) — the chunk's own K/V must
+    already be in the cache (cache_flat).  Bottom-right-aligned causal mask per entry, exactly as flash_attn_with_kvcache
+    does for one sequence (the reference's wrapper issues one call per prompt, vattention_flashattention_wrapper.py:129-174)."""
+    _check_cuda(q, k_cache, v_cache, q_start, q_lens, cache_seqlens, cache_batch_idx)
+    if q.dim() != 3:
+        raise RuntimeError("q must be [total_tokens, num_heads, head_size]")
+    T, Hq, D = q.shape
+    Bc, Sk, Hkv, Dk = k_cache.shape
+    if k_cache.dtype != q.dtype or v_cache.dtype != q.dtype:
+        raise RuntimeError("query, key and value must have the same dtype")
+    for t, name in ((q_start, "q_start"), (q_lens, "q_lens"), (cache_seqlens, "seqlens_k")):
+        if t.dtype != torch.int32:
+            raise RuntimeError(name + " must have dtype int32")
+    B = q_lens.shape[0]
+    assert q_start.shape == (B,) and cache_seqlens.shape == (B,)
+    if cache_batch_idx is not None:
+        if cache_batch_idx.dtype != torch.int32:
+            raise RuntimeError("cache_batch_idx must have dtype int32")
+        assert cache_batch_idx.shape == (B,)
+    elif Bc < B:
+        raise RuntimeError("batch size of the cache is smaller than the number of chunks")
+    if max_q_len < 2:
+        raise RuntimeError("max_q_len must be >= 2 (single-token queries take the decode form)")
+    assert k_cache.stride(-1) == 1 and v_cache.stride(-1) == 1 and q.stride(-1) == 1
+    if softmax_scale is None:
+        softmax_scale = D ** (-0.5)
+    if out is None:
+        out = torch.empty_like(q)
+    elif out.shape != q.shape or out.dtype != q.dtype or out.stride(-1) != 1:
+        raise RuntimeError("Output tensor must have the shape and dtype of q and a contiguous last dimension")
+    dev = q.device
+    p = K.AttnParams()
+    p.q, p.out = q.data_ptr(), out.data_ptr()
+    p.q_batch_stride, p.q_row_stride, p.q_head_stride = 0, q.stride(0), q.stride(1)
+    p.o_batch_stride, p.o_row_stride, p.o_head_stride = 0, out.stride(0), out.stride(1)
+    p.k_cache, p.v_cache = k_cache.data_ptr(), v_cache.data_ptr()
+    p.k_batch_stride, p.k_row_stride, p.k_head_stride = k_cache.stride(0), k_cache.stride(1), k_cache.stride(2)
+    p.v_batch_stride, p.v_row_stride, p.v_head_stride = v_cache.stride(0), v_cache.stride(1), v_cache.stride(2)
+    p.cache_seqlens = cache_seqlens.contiguous().data_ptr()
+    p.cache_batch_idx = cache_batch_idx.contiguous().data_ptr() if cache_batch_idx is not None else None
+    p.q_start, p.q_lens = q_start.contiguous().data_ptr(), q_lens.contiguous().data_ptr()
+    p.b, p.seqlen_q, p.seqlen_k, p.seqlen_knew, p.h, p.h_k, p.d = B, int(max_q_len), Sk, 0, Hq, Hkv, D
+    p.is_causal = 1 if causal else 0
+    p.dtype = K.dtype_code(q.dtype)
+    p.num_splits = int(num_splits)
+    p.softmax_scale = float(softmax_scale)
+    p.variant = int(_variant)
+    p.max_seqlen_k_hint = min(int(_max_seqlen_k), Sk) if _max_seqlen_k > 0 else 0
+    lib = K.klib()
+    need = lib.vattn_attn_workspace_bytes(C.byref(p))
+    if need:
+        ws = _workspace(need, dev)
+        p.workspace = ws.data_ptr()
+    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), K.current_stream_ptr(dev))
+    if rc != 0:
+        raise RuntimeError(K.last_error())
+    return out

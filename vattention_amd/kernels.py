@@ -22,6 +22,7 @@ class AttnParams(C.Structure):
         ("knew_batch_stride", i64), ("knew_row_stride", i64), ("knew_head_stride", i64),
         ("vnew_batch_stride", i64), ("vnew_row_stride", i64), ("vnew_head_stride", i64),
         ("cache_seqlens", vp), ("cache_batch_idx", vp), ("softmax_lse", vp), ("workspace", vp),
+        ("q_start", vp), ("q_lens", vp),
         ("b", i32), ("seqlen_q", i32), ("seqlen_k", i32), ("seqlen_knew", i32), ("h", i32), ("h_k", i32), ("d", i32),
         ("is_causal", i32), ("dtype", i32), ("num_splits", i32), ("softmax_scale", C.c_float), ("variant", i32),
         ("max_seqlen_k_hint", i32),
