@@ -266,14 +266,20 @@ class HotPathRunner:
                 total_groups = free
             wm = int(watermark * total_groups)
             promised = sum(pages(s.total_len) - pages(max(s.get_len(), 1)) for s in running)
-            admitted = None
-            if waiting and len(running) < B:
+            # vLLM scheduler (sarathi-lean/sarathi/core/scheduler/vllm_scheduler.py): prefills are prioritised; whole prompts
+            # are batched into one iteration while they fit max_tokens_in_batch (= max_tokens here) and pass admission
+            admitted, budget = [], max_tokens
+            while waiting and len(running) < B:
                 s = waiting[0]
-                if free - promised - pages(s.total_len) >= wm:
-                    admitted = waiting.pop(0)
-                    running.append(admitted)
-            if admitted is not None:       # vLLM scheduler: prefills are prioritised, one whole prompt per iteration
-                mds = [SequenceMetadata(admitted, admitted.prompt_len, True)]
+                if s.prompt_len > budget or free - promised - pages(s.total_len) < wm:
+                    break
+                waiting.pop(0)
+                running.append(s)
+                admitted.append(s)
+                budget -= s.prompt_len
+                promised += pages(s.total_len)
+            if admitted:
+                mds = [SequenceMetadata(s, s.prompt_len, True) for s in admitted]
             else:
                 mds = [SequenceMetadata(s, 0, False) for s in running]
             self.run_iteration(mds)
