@@ -15,9 +15,9 @@ constexpr uint64_t kEagerNumSteps = 10;    // vattention.cu:484
 constexpr uint64_t kEagerNumKvBlocks = 2;  // vattention.cu:485
 constexpr uint64_t kPrecreateSlice = 16;   // handles created per idle slice of the mapper thread
 // hipMemCreate is O(live handles) on ROCm 7.2 (9 us at 5 k handles, 106 us at 20 k, 382 us at 50 k, 931 us at 100 k:
-// profiles/r01_vmm_scale_probe.txt), so materialising a whole pool up front is quadratic.  Only this many handles at
-// the top of the LIFO are created ahead of demand; the rest are created by the map that first needs them.
-constexpr uint64_t kPrecreateAhead = 4096;
+// profiles/r01_vmm_scale_probe.txt), so materialising a whole pool up front is quadratic.  The idle mapper thread keeps
+// PageManager::kPrecreateAheadPages handles created BELOW the lowest page id the pool has handed out so far (a window that
+// slides down as the pool is consumed); a map that outruns the window creates its handle itself.
 
 inline uint64_t now_ns() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
@@ -125,10 +125,18 @@ uint64_t PageManager::need_new_page_async(int r, uint64_t eager) const {   // ut
     return req <= mapped ? 0 : req - mapped;
 }
 
+void PageManager::note_popped(uint32_t lowest) {     // state_mu_ held
+    if (lowest < frontier_.load(std::memory_order_relaxed)) {
+        frontier_.store(lowest, std::memory_order_relaxed);
+        q_cv_.notify_one();        // the window slid down: the idle mapper may create more handles
+    }
+}
+
 int PageManager::plan_map_pair(int r, uint32_t layer, uint64_t off) {      // mux.h:37-48, cudaInternal.h:70-82
     if (pool_.size() < 2) return fail(VATTN_ERR_POOL_EMPTY, "***** page pool is empty *****");
     const uint32_t k = pool_.back(); pool_.pop_back();
     const uint32_t v = pool_.back(); pool_.pop_back();
+    note_popped(k < v ? k : v);
     plan_.push_back({0, k_tensor(layer), k, off});
     plan_.push_back({0, v_tensor(layer), v, off});
     pagemap_[std::make_tuple((uint64_t)r, off, (uint64_t)layer)] = std::make_pair(k, v);
@@ -276,8 +284,8 @@ int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInt
         // lazy pool: the mapper materialises handles while it is idle, top of the LIFO first
         {
             std::lock_guard<std::mutex> q(q_mu_);
+            frontier_.store(num_pages_);
             precreate_left_.store(num_pages_);
-            precreate_floor_ = num_pages_ > kPrecreateAhead ? num_pages_ - kPrecreateAhead : 0;
         }
         q_cv_.notify_all();
     }
@@ -389,6 +397,7 @@ int PageManager::map_common_pages(uint64_t num_tokens) {   // vattention.cu:325-
             if (pool_.size() < 2) { err = fail(VATTN_ERR_POOL_EMPTY, "***** page pool is empty *****"); break; }
             const uint32_t k = pool_.back(); pool_.pop_back();
             const uint32_t v = pool_.back(); pool_.pop_back();
+            note_popped(k < v ? k : v);
             for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
                 const uint64_t off = (uint64_t)r * virt_per_req_ + mapped_pages_[r] * cfg_.page_size;
                 plan_.push_back({0, k_tensor(layer), k, off});
@@ -643,7 +652,7 @@ void PageManager::mapper_main() {
     if (be_.thread_init) be_.thread_init(be_.ctx);
     std::unique_lock<std::mutex> q(q_mu_);
     for (;;) {
-        q_cv_.wait(q, [this] { return stop_ || !queue_.empty() || precreate_left_.load() > 0; });
+        q_cv_.wait(q, [this] { return stop_ || !queue_.empty() || precreate_left_.load() > precreate_floor(); });
         if (stop_) return;
         if (!queue_.empty()) {
             std::vector<PhysOp> ops = std::move(queue_.front());
@@ -666,8 +675,8 @@ void PageManager::mapper_main() {
             std::lock_guard<std::mutex> e(exec_mu_);
             for (uint64_t i = 0; i < kPrecreateSlice; i++) {
                 const uint64_t left = precreate_left_.load();
-                if (left == 0) break;
-                if (left <= precreate_floor_ || left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) { precreate_left_.store(0); break; }
+                if (left == 0 || left <= precreate_floor()) break;          // window full: wait until the pool is consumed further
+                if (left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) { precreate_left_.store(0); break; }
                 precreate_left_.store(left - 1);
             }
         }

@@ -107,7 +107,12 @@ private:
     std::vector<uint32_t> create_order_;         // page ids in creation order: handles are released oldest-first (see cleanup)
     std::atomic<uint64_t> precreate_left_{0};   // ids [0, precreate_left_) still to be looked at, top down
     std::atomic<uint64_t> join_wait_ns_{0};
-    uint64_t precreate_floor_ = 0;              // ids below this are created on first use only
+    std::atomic<uint64_t> frontier_{0};          // lowest page id ever handed out by the pool (ids below it were never used)
+    uint64_t precreate_floor() const {           // ids below this are not created ahead of demand (yet): sliding window
+        const uint64_t f = frontier_.load(std::memory_order_relaxed);
+        return f > kPrecreateAheadPages ? f - kPrecreateAheadPages : 0;
+    }
+    static constexpr uint64_t kPrecreateAheadPages = 4096;
     std::mutex exec_mu_;                         // serialises driver calls
     std::mutex q_mu_;
     std::condition_variable q_cv_, done_cv_;
@@ -122,6 +127,7 @@ private:
     int flush_sync();
     void flush_async();
     int execute(const std::vector<PhysOp>& ops, bool is_async);
+    void note_popped(uint32_t lowest);
     int ensure_created(uint32_t page);
     void mapper_main();
     int wait_locked_free();
