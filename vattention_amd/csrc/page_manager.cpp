@@ -265,6 +265,11 @@ int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInt
     uint64_t n = free_memory / cfg_.page_size;
     n -= n % (2ull * cfg_.num_layers);            // multiple of 2*L even in megacache mode
     if (n > 0xFFFFFFF0ull) return fail(VATTN_ERR_INVALID, "page count exceeds 32-bit page ids");
+    if (n > 100000 && be_.tlb_flush) {            // a real (HIP) backend: creation cost grows with the number of live handles
+        std::cerr << "[vattn] warning: " << n << " physical pages of " << (cfg_.page_size >> 10) << " KiB = one hipMemCreate handle each; "
+                  << "handle creation on ROCm is O(live handles) (about 1 ms per call beyond 100 k, DESIGN.md section 3): prefer larger pages"
+                  << (cfg_.megacache ? "" : " with the megacache layout") << " (8 MiB pages: " << (free_memory >> 23) << " handles)" << std::endl;
+    }
     {
         std::lock_guard<std::mutex> e(exec_mu_);
         while (pool_.size() < n) {
