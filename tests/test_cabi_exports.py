@@ -59,3 +59,24 @@ def test_no_gpu_calls_fail_loudly():
         flash_attn_with_kvcache(q, kc, kc, cache_seqlens=4)
     with pytest.raises(RuntimeError, match="no CPU path"):
         cache_flat(kc[0], kc[0], kc[0], kc[0], "auto")
+
+
+def test_plain_c_client_drives_the_boundary(tmp_path):
+    """include/*.h are valid C99 and libvattn_amd.so is usable from plain C (what a cgo / JNI / FFI binding sees): a gcc-built
+    client runs init -> reserve -> alloc -> step_async -> free -> cleanup on the fake backend and validates kernel arguments."""
+    import subprocess
+    exe = str(tmp_path / "cabi_client")
+    lib_dir = os.path.join(ROOT, "vattention_amd")
+    fake_dir = os.path.join(ROOT, "tests", "native")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(fake_dir, "cabi_client.c"), "-L" + lib_dir, "-lvattn_amd", "-L" + fake_dir,
+                           "-lvattn_fake_backend", "-Wl,-rpath," + lib_dir, "-Wl,-rpath," + fake_dir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if not ln.startswith("[")]
+    text = "\n".join(lines)
+    assert "tensors 4 ndim 4" in text and "pool 64" in text and "slot 0" in text
+    # 300 tokens = 3 pages of 128 tokens now + look-ahead; 2 layers x (K, V) = 4 pages per group
+    assert "step_async 0" in text and "pool_pages 52 mapped_groups 3 needed_groups 3 active_slots 1 map_calls 12" in text
+    assert "bad_len -1 err 'seq_lens must have max_batch_size entries'" in text
+    assert "cleanup 0" in text and "null_params" in text and "null tensor pointer" in text
