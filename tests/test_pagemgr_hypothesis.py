@@ -22,12 +22,16 @@ op_st = st.one_of(
 )
 
 
+MEGA = dict(CFG, megacache=True, num_layers=4)           # 16 tokens per page, 64 pages per request, 2 pages per group
+
+
 @settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow])
-@given(st.lists(op_st, min_size=1, max_size=40), st.sampled_from([0, 4]))
-def test_any_call_sequence_matches_oracle(ops, flags):
+@given(st.lists(op_st, min_size=1, max_size=40), st.sampled_from([0, 4]), st.booleans())
+def test_any_call_sequence_matches_oracle(ops, flags, mega):
     ops = [list(o) for o in ops] + [["cleanup"]]
-    o = T.OracleImpl(CFG)
-    p = ProductImpl(CFG, flags=flags)
+    cfg = MEGA if mega else CFG
+    o = T.OracleImpl(cfg)
+    p = ProductImpl(cfg, flags=flags)
     try:
         for op in ops:
             ra = T.replay(o, [op], full=True)[0]
