@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "vattention_amd")
 CSRC = os.path.join(PKG, "csrc")
 ARCH = "gfx950"
+LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "attn_api.hip", "prefill_kernels.hip", "decode_kernels.hip",
+               "cache_kernels.hip")
 
 
 def _newer(target, sources):
@@ -32,13 +34,20 @@ def _run(cmd):
 
 def build_lib(force=False):
     out = os.path.join(PKG, "libvattn_amd.so")
-    srcs = [os.path.join(CSRC, f) for f in ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "attn_kernels.hip")]
-    deps = srcs + [os.path.join(CSRC, "page_manager.h"), os.path.join(ROOT, "include", "vattn.h"),
+    srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "page_manager.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(ROOT, "include", "vattn.h"),
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unused-value",
-              *srcs, "-o", out])
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-unused-value"] + os.environ.get("VATTN_CXXFLAGS", "").split()
+        objdir = os.path.join(ROOT, "build", "obj")
+        os.makedirs(objdir, exist_ok=True)
+        objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]
+        # one hipcc per translation unit, in parallel (the prefill kernels dominate: ~40 s)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+            list(ex.map(lambda so: _run([hipcc, *flags, "-c", so[0], "-o", so[1]]), zip(srcs, objs)))
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-pthread", *objs, "-o", out])
     return out
 
 

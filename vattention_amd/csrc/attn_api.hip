@@ -1,0 +1,194 @@
+// C ABI of the gfx950 attention kernels over virtually-contiguous KV tensors (include/vattn_kernels.h).
+//   prefill_kernels.hip : seqlen_q > 1   (chunked causal prefill, KV split, batched variable-length chunks)
+//   decode_kernels.hip  : seqlen_q == 1  (split-KV decode with in-kernel append, combine)
+//   cache_kernels.hip   : cache_flat / append
+// Semantics follow the operator the reference calls (flash_attn_with_kvcache):
+//   /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, flash_api.cpp:1291-1578,
+//   mask.h:164-196 (bottom-right causal), softmax.h:69-157 (fp32 max/sum, exp2, P rounded to the
+//   I/O dtype before PV), flash_fwd_kernel.h:1116-1297 (split combine).
+// Every K/V access is predicated on the sequence's visible length: rows at or beyond it may sit
+// on unmapped virtual pages (SURVEY §7 "never touch unmapped VA").
+#include "attn_common.h"
+
+namespace vattn_k {
+
+// ============================================================================================
+// hardware-layout self test
+// ============================================================================================
+
+// Checks, against plain integer arithmetic, the three layout facts the kernels rely on:
+//  [0] 32x32x16 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+//  [1] 16x16x32 C/D map: col = lane&15, row = 4*(lane>>4) + r
+//  [2] ds_read_b64_tr_b16: lane i of a 16-lane group receives element (i&3) of the 8-byte chunks
+//      addressed by lanes 4*j + (i>>2), j = 0..3, of the same group
+//  [3] A/B operands: lane (x = lane&31, g = lane>>5) contributes row/col x with k-slots (g, 0..7) (32x32x16)
+//  [4] same for 16x16x32 with g = lane>>4
+__global__ void selftest_kernel(int* res) {
+    __shared__ __attribute__((aligned(16))) short lds[64 * 4];
+    const int lane = threadIdx.x;
+    // [0],[3]: A = one-hot rows, B = one-hot cols with distinct values -> C[m][n] = sum_k A[m][k]B[k][n]
+    {
+        // A[m][slot] = (m + 1) if slot == (m & 15) else 0 ; B[slot][n] = (n + 1) * 64 + ... keep small ints
+        f16x8 a, bq;
+        const int x = lane & 31, g = lane >> 5;
+        for (int j = 0; j < 8; j++) {
+            const int slot = 8 * g + j;                 // logical k index shared by A and B
+            a[j] = (_Float16)((slot == (x & 15)) ? (float)(x + 1) : 0.f);      // A[m=x][k]
+            bq[j] = (_Float16)((slot == 3) ? 0.f : 0.f);
+        }
+        // B[k][n=x] = 1 for every k -> C[m][n] = sum_k A[m][k] = m + 1 for every n
+        for (int j = 0; j < 8; j++) bq[j] = (_Float16)1.f;
+        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, c, 0, 0, 0);
+        int bad = 0;
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (c[r] != (float)(row + 1)) bad = 1;
+        }
+        // columns: A[m][k] = 1 for all, B[k][n] = (n+1) if k-slot == (n & 15) -> C[m][n] = n + 1
+        for (int j = 0; j < 8; j++) {
+            a[j] = (_Float16)1.f;
+            bq[j] = (_Float16)(((8 * g + j) == (x & 15)) ? (float)(x + 1) : 0.f);
+        }
+        f32x16 c2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, c2, 0, 0, 0);
+        int bad3 = 0;
+        for (int r = 0; r < 16; r++)
+            if (c2[r] != (float)(x + 1)) bad3 = 1;
+        if (bad) atomicOr(&res[0], 1);
+        if (bad3) atomicOr(&res[3], 1);
+    }
+    {
+        f16x8 a, bq;
+        const int x = lane & 15, g = lane >> 4;
+        for (int j = 0; j < 8; j++) {
+            a[j] = (_Float16)(((8 * g + j) == x) ? (float)(x + 1) : 0.f);
+            bq[j] = (_Float16)1.f;
+        }
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c, 0, 0, 0);
+        int bad = 0;
+        for (int r = 0; r < 4; r++)
+            if (c[r] != (float)(4 * g + r + 1)) bad = 1;
+        for (int j = 0; j < 8; j++) {
+            a[j] = (_Float16)1.f;
+            bq[j] = (_Float16)(((8 * g + j) == x) ? (float)(x + 1) : 0.f);
+        }
+        f32x4 c2 = {0.f, 0.f, 0.f, 0.f};
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c2, 0, 0, 0);
+        int bad4 = 0;
+        for (int r = 0; r < 4; r++)
+            if (c2[r] != (float)(x + 1)) bad4 = 1;
+        if (bad) atomicOr(&res[1], 1);
+        if (bad4) atomicOr(&res[4], 1);
+    }
+    {
+        // each lane owns the 8-byte chunk at lds[lane*4 .. lane*4+3]; value encodes (lane, element)
+        for (int e = 0; e < 4; e++) lds[lane * 4 + e] = (short)(lane * 4 + e);
+        __syncthreads();
+        const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, &lds[lane * 4]));
+        const int grp = lane >> 4, i = lane & 15;
+        int bad = 0;
+        for (int j = 0; j < 4; j++) {
+            const int src_lane = grp * 16 + 4 * j + (i >> 2);
+            if (t[j] != (short)(src_lane * 4 + (i & 3))) bad = 1;
+        }
+        if (bad) atomicOr(&res[2], 1);
+    }
+}
+
+thread_local std::string g_err;
+int fail(int code, const char* msg) {
+    g_err = msg;
+    return code;
+}
+
+int validate(const vattn_attn_params* p) {
+    if (!p || !p->q || !p->out || !p->k_cache || !p->v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
+    if (p->dtype != VATTN_DTYPE_F16 && p->dtype != VATTN_DTYPE_BF16)
+        return fail(VATTN_K_ERR_UNSUPPORTED, "FlashAttention only support fp16 and bf16 data type");      // flash_api.cpp:1325-1326
+    // d = 256 instantiates but spills (O^T alone is 128 accumulator registers per wave): not shipped until it has its own tiling
+    if (p->d != 64 && p->d != 128) return fail(VATTN_K_ERR_UNSUPPORTED, "this build supports head dimensions 64 and 128");
+    if (p->b <= 0) return fail(VATTN_K_ERR_INVALID, "batch size must be postive");                       // flash_api.cpp:1353
+    if (p->h_k <= 0 || p->h % p->h_k != 0)
+        return fail(VATTN_K_ERR_INVALID, "Number of heads in key/value must divide number of heads in query");   // :1355
+    if ((p->k_new == nullptr) != (p->v_new == nullptr))
+        return fail(VATTN_K_ERR_INVALID, "If key is supplied, value must also be passed in");            // :1452
+    if (p->k_new && !p->cache_seqlens)
+        return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");        // :1453
+    if (p->seqlen_q <= 0 || p->seqlen_k < 0) return fail(VATTN_K_ERR_INVALID, "bad sequence lengths");
+    if ((p->q_start == nullptr) != (p->q_lens == nullptr)) return fail(VATTN_K_ERR_INVALID, "q_start and q_lens must be given together");
+    if (p->q_lens && p->seqlen_q == 1) return fail(VATTN_K_ERR_UNSUPPORTED, "batched chunks need max(q_lens) > 1 (the decode form is already batched)");
+    if (p->q_lens && p->k_new) return fail(VATTN_K_ERR_UNSUPPORTED, "batched chunks: append the new keys/values with cache_flat first");
+    // 16-byte vector access requirements
+    const int64_t strides[] = {p->q_batch_stride, p->q_row_stride, p->q_head_stride, p->k_batch_stride, p->k_row_stride,
+                               p->k_head_stride, p->v_batch_stride, p->v_row_stride, p->v_head_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0) return fail(VATTN_K_ERR_UNSUPPORTED, "strides must be multiples of 8 elements (16-byte vector access)");
+    if (((uintptr_t)p->q | (uintptr_t)p->k_cache | (uintptr_t)p->v_cache | (uintptr_t)p->out) & 15)
+        return fail(VATTN_K_ERR_UNSUPPORTED, "tensor base pointers must be 16-byte aligned");
+    if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
+        return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
+    return VATTN_K_OK;
+}
+
+}  // namespace vattn_k
+
+using namespace vattn_k;
+
+extern "C" {
+
+const char* vattn_kernels_last_error(void) { return g_err.c_str(); }
+
+size_t vattn_attn_workspace_bytes(const vattn_attn_params* p) {
+    if (!p || p->h_k <= 0 || p->h <= 0 || p->b <= 0 || p->seqlen_q <= 0) return 0;
+    return p->seqlen_q != 1 ? prefill_workspace_bytes(p) : decode_workspace_bytes(p);
+}
+
+int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
+    int rc = validate(p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->k_new && p->seqlen_knew > 0 && !p->cache_seqlens) return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");
+    return p->seqlen_q == 1 ? launch_decode_form(p, st) : launch_prefill_form(p, st);
+}
+
+int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
+    hipStream_t st = (hipStream_t)stream;
+    int* d = nullptr;
+    if (hipMalloc(&d, 8 * sizeof(int)) != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed");
+    hipMemsetAsync(d, 0, 8 * sizeof(int), st);
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d);
+    int h[8] = {0};
+    hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
+    int bad = 0;
+    for (int i = 0; i < 8; i++) {
+        if (detail_out) detail_out[i] = h[i];
+        bad |= h[i];
+    }
+    return bad ? fail(VATTN_K_ERR_INVALID, "hardware layout assumption violated") : VATTN_K_OK;
+}
+
+float vattn_time_attn(const vattn_attn_params* p, void* stream, int32_t warmup, int32_t iters) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < warmup; i++)
+        if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < iters; i++)
+        if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ms / (iters > 0 ? iters : 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// Shared types and device helpers of the gfx950 attention kernels (see attn_api.hip for the overview).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/vattn_kernels.h"
+
+namespace vattn_k {
+
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+template <typename T> struct Tr;
+template <> struct Tr<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)x; }
+};
+template <> struct Tr<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ __bf16 cvt(float x) { return (__bf16)x; }
+};
+
+template <typename V8> __device__ __forceinline__ V8 as_v8(uint4 x) {
+    V8 r;
+    __builtin_memcpy(&r, &x, 16);
+    return r;
+}
+template <typename V8> __device__ __forceinline__ V8 join_tr(s16x4 lo, s16x4 hi) {
+    s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    V8 r;
+    __builtin_memcpy(&r, &t, 16);
+    return r;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float xor_shuffle(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// value of lane (l ^ 32): one v_permlane32_swap (VALU) instead of a ds_bpermute round trip through LDS
+__device__ __forceinline__ float swap_halves(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = {lo,lo}, r[1] = {hi,hi}
+    const unsigned other = (threadIdx.x & 32) ? r[0] : r[1];
+    return __builtin_bit_cast(float, other);
+}
+
+// Bounds-checked 16-byte loads through a buffer descriptor: a lane whose byte offset lies at or beyond
+// `bytes` gets zeros WITHOUT touching memory, so rows past the sequence's visible length (possibly on
+// unmapped virtual pages) are never accessed, and the load stream is branch-free (counted vmcnt waits).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    // the byte count comes out of a clamp that instruction selection turns into a VALU v_med3: pull it
+    // back into an SGPR, otherwise every load is wrapped in a waterfall loop
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+// wave-uniform pointer: make the uniformity provable so the descriptor lives in SGPRs (no waterfall loop)
+template <typename P> __device__ __forceinline__ const P* uniform_ptr(const P* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const P*)(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- host-side pieces shared by the translation units ----
+int fail(int code, const char* msg);                                    // attn_api.hip: records the message for vattn_kernels_last_error
+void launch_append(const vattn_attn_params* p, hipStream_t st);         // cache_kernels.hip
+int launch_prefill_form(const vattn_attn_params* p, hipStream_t st);    // prefill_kernels.hip (seqlen_q > 1)
+size_t prefill_workspace_bytes(const vattn_attn_params* p);
+int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
+size_t decode_workspace_bytes(const vattn_attn_params* p);
+
+}  // namespace vattn_k

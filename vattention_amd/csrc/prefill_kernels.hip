@@ -1,162 +1,15 @@
-// gfx950 (CDNA4) attention kernels over virtually-contiguous KV tensors.
-//
-//   prefill_kernel : chunked causal prefill (seqlen_q > 1).  One workgroup = 4 waves x 32 query rows,
-//                    KV tiles of 64 keys double-buffered in LDS (register-staged global loads issued
-//                    one tile ahead), S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_{f16,bf16},
-//                    softmax entirely in registers (the "swapped QK^T" form: a lane owns one query
-//                    column), K tile XOR-swizzled for conflict-free ds_read_b128, V tile stored as
-//                    [d-block][key][32 d] sub-tiles and consumed through ds_read_b64_tr_b16.
-//   decode_kernel  : seqlen_q == 1, GQA group packed into the MFMA N dimension, split-KV over the
-//                    context, K fragments loaded straight from HBM into MFMA operand registers,
-//                    V through a wave-private LDS transpose stage, fp32 online softmax, in-workgroup
-//                    merge of the 4 waves, LSE-weighted combine across splits (combine_kernel).
-//   cache_flat / append : contiguous KV append (16-byte vector copies).
-//
-// Semantics follow the operator the reference calls (flash_attn_with_kvcache):
-//   /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, flash_api.cpp:1291-1578,
-//   mask.h:164-196 (bottom-right causal), softmax.h:69-157 (fp32 max/sum, exp2, P rounded to the
-//   I/O dtype before PV), flash_fwd_kernel.h:1116-1297 (split combine).
-// Every K/V access is predicated on the sequence's visible length: rows at or beyond it may sit
-// on unmapped virtual pages (SURVEY §7 "never touch unmapped VA").
-#include <hip/hip_runtime.h>
+// Prefill form (seqlen_q > 1) of flash_attn_with_kvcache on gfx950: chunked causal attention over virtually contiguous K/V.
+//   prefill_kernel      : 8 (or 4) waves x 32 query rows per workgroup, 64-key tiles double-buffered in LDS (register-staged
+//                         global loads two tiles ahead), S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_{f16,bf16},
+//                         softmax entirely in registers (a lane owns one query column), K tile XOR-swizzled for conflict-free
+//                         ds_read_b128, V tile as [d-block][key][32 d] sub-tiles read through ds_read_b64_tr_b16;
+//                         optional KV split (fp32 partials merged by combine_rows_kernel) and batched variable-length chunks
+//   prefill_ilv_kernel  : the same data flow software-pipelined with a hand-written issue order (variant 12)
+// Semantics: /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, flash_api.cpp:1291-1578, mask.h:164-196
+// (bottom-right causal), softmax.h:69-157 (fp32 max/sum, exp2, P rounded to the I/O dtype before PV).
+#include "attn_common.h"
 
-#include <cstdio>
-#include <cstring>
-#include <string>
-
-#include "../../include/vattn_kernels.h"
-
-namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
-
-constexpr float kLog2e = 1.4426950408889634f;
-
-template <typename T> struct Tr;
-template <> struct Tr<_Float16> {
-    using v8 = f16x8;
-    using v4 = f16x4;
-    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)x; }
-};
-template <> struct Tr<__bf16> {
-    using v8 = bf16x8;
-    using v4 = bf16x4;
-    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ __bf16 cvt(float x) { return (__bf16)x; }
-};
-
-template <typename V8> __device__ __forceinline__ V8 as_v8(uint4 x) {
-    V8 r;
-    __builtin_memcpy(&r, &x, 16);
-    return r;
-}
-template <typename V8> __device__ __forceinline__ V8 join_tr(s16x4 lo, s16x4 hi) {
-    s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    V8 r;
-    __builtin_memcpy(&r, &t, 16);
-    return r;
-}
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float xor_shuffle(float v, int mask) { return __shfl_xor(v, mask, 64); }
-// value of lane (l ^ 32): one v_permlane32_swap (VALU) instead of a ds_bpermute round trip through LDS
-__device__ __forceinline__ float swap_halves(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = {lo,lo}, r[1] = {hi,hi}
-    const unsigned other = (threadIdx.x & 32) ? r[0] : r[1];
-    return __builtin_bit_cast(float, other);
-}
-
-// Bounds-checked 16-byte loads through a buffer descriptor: a lane whose byte offset lies at or beyond
-// `bytes` gets zeros WITHOUT touching memory, so rows past the sequence's visible length (possibly on
-// unmapped virtual pages) are never accessed, and the load stream is branch-free (counted vmcnt waits).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    // the byte count comes out of a clamp that instruction selection turns into a VALU v_med3: pull it
-    // back into an SGPR, otherwise every load is wrapped in a waterfall loop
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-// wave-uniform pointer: make the uniformity provable so the descriptor lives in SGPRs (no waterfall loop)
-template <typename P> __device__ __forceinline__ const P* uniform_ptr(const P* p) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return (const P*)(((unsigned long long)hi << 32) | lo);
-}
-
-// ============================================================================================
-// cache_flat / append
-// ============================================================================================
-
-// One 16-byte chunk per thread; K and V rows copied by the same launch (cache_kernels.cu:483-520).
-__global__ void cache_flat_vec_kernel(const uint4* __restrict__ key, const uint4* __restrict__ value,
-                                      uint4* __restrict__ k_cache, uint4* __restrict__ v_cache,
-                                      int64_t num_tokens, int chunks_per_row, int64_t key_stride, int64_t value_stride,
-                                      int64_t k_cache_stride, int64_t v_cache_stride) {
-    // strides are in 16-byte chunks here
-    const int64_t total = num_tokens * chunks_per_row;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t t = i / chunks_per_row;
-        const int c = (int)(i - t * chunks_per_row);
-        const uint4 kv = key[t * key_stride + c];
-        const uint4 vv = value[t * value_stride + c];
-        k_cache[t * k_cache_stride + c] = kv;
-        v_cache[t * v_cache_stride + c] = vv;
-    }
-}
-
-template <typename E>
-__global__ void cache_flat_scalar_kernel(const E* __restrict__ key, const E* __restrict__ value, E* __restrict__ k_cache,
-                                         E* __restrict__ v_cache, int64_t num_tokens, int n, int64_t key_stride,
-                                         int64_t value_stride, int64_t k_cache_stride, int64_t v_cache_stride) {
-    const int64_t total = num_tokens * n;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t t = i / n;
-        const int c = (int)(i - t * n);
-        k_cache[t * k_cache_stride + c] = key[t * key_stride + c];
-        v_cache[t * v_cache_stride + c] = value[t * value_stride + c];
-    }
-}
-
-// Append of k_new/v_new [b, sn, h_k, d] at row cache_seqlens[b] of slot cache_batch_idx[b]
-// (flash_attn_interface.py:1168-1176).  16-byte chunks; d*itemsize is a multiple of 16.
-__global__ void append_kv_kernel(vattn_attn_params p) {
-    const int b = blockIdx.y;
-    const int slot = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
-    const int len = p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k;
-    const int cpr = p.d / 8;                       // 16-byte chunks per head row
-    const int total = p.seqlen_knew * p.h_k * cpr;
-    const uint16_t* kn = (const uint16_t*)p.k_new;
-    const uint16_t* vn = (const uint16_t*)p.v_new;
-    uint16_t* kc = (uint16_t*)p.k_cache;
-    uint16_t* vc = (uint16_t*)p.v_cache;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int c = i % cpr;
-        const int hk = (i / cpr) % p.h_k;
-        const int t = i / (cpr * p.h_k);
-        const int row = len + t;
-        if (row >= p.seqlen_k) continue;           // never write past the cache view
-        const uint4 kv = *(const uint4*)(kn + b * p.knew_batch_stride + t * p.knew_row_stride + hk * p.knew_head_stride + c * 8);
-        const uint4 vv = *(const uint4*)(vn + b * p.vnew_batch_stride + t * p.vnew_row_stride + hk * p.vnew_head_stride + c * 8);
-        *(uint4*)(kc + (int64_t)slot * p.k_batch_stride + (int64_t)row * p.k_row_stride + hk * p.k_head_stride + c * 8) = kv;
-        *(uint4*)(vc + (int64_t)slot * p.v_batch_stride + (int64_t)row * p.v_row_stride + hk * p.v_head_stride + c * 8) = vv;
-    }
-}
+namespace vattn_k {
 
 // ============================================================================================
 // prefill
@@ -841,299 +694,6 @@ __global__ __launch_bounds__(512, 2) void prefill_ilv_kernel(vattn_attn_params p
     }
 }
 
-// ============================================================================================
-// decode (seqlen_q == 1): split-KV
-// ============================================================================================
-
-constexpr int DC_WAVES = 4;
-constexpr int DC_BN = 32;     // keys per wave tile
-
-// workspace layout: float o_accum[splits][b][h][d]; float lse_accum[splits][b][h]  (log2 domain, scaled)
-template <typename T, int HD, bool USE_TR>
-__global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append) {
-    using X = Tr<T>;
-    using V8 = typename X::v8;
-    constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
-    constexpr int DB = HD / 16;          // 16-wide d blocks of O^T
-    constexpr int CPR = HD / 8;          // 16-byte chunks per row
-    constexpr int VPASS = (DC_BN * CPR) / 64;
-    constexpr int V_WAVE_BYTES = DC_BN * HD * 2;        // [d/16][32 keys][16 d] sub-tiles, 32-byte rows
-    constexpr int VSUB = DC_BN * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15;
-    const int g4 = lane >> 4;
-
-    const int split = blockIdx.x;
-    const int hk = blockIdx.y / gblocks;
-    const int gb = blockIdx.y % gblocks;
-    const int b = blockIdx.z;
-    const int G = p.h / p.h_k;
-    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
-    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
-
-    // each sequence divides ITS OWN length evenly over the splits (balanced for ragged batches)
-    const int ntiles_total = (Lk + DC_BN - 1) / DC_BN;
-    const int tiles_per_split = (ntiles_total + num_splits - 1) / num_splits;
-    const int tile_begin = split * tiles_per_split;
-    const int tile_end = min(ntiles_total, tile_begin + tiles_per_split);
-
-    // Fused append (seqlen_knew == 1): the new K/V row sits at key index Lk-1.  Every workgroup that reads the tile
-    // holding it substitutes the row from k_new/v_new in registers; the gb == 0 workgroup also stores it into the
-    // cache (flash_attn_interface.py:1168-1176: append, then attend).  No inter-workgroup ordering is needed.
-    const int new_key = fused_append ? Lk - 1 : -1;
-    const int new_tile = fused_append ? new_key / DC_BN : -1;
-
-    const int row_head = gb * 16 + l15;                 // query head within the group handled by this lane's column
-    const bool row_valid = row_head < G;
-    const int h = hk * G + row_head;
-    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
-    const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
-    const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
-
-    // Q^T fragments (B operand, n = query head): slot (g4, j) <-> d = 32*kk + 8*g4 + j
-    V8 qf[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row_valid) v = *(const uint4*)(qptr + 32 * kk + 8 * g4);
-        qf[kk] = as_v8<V8>(v);
-    }
-
-    f32x4 o[DB];
-#pragma unroll
-    for (int i = 0; i < DB; i++) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = p.softmax_scale * kLog2e;
-    char* vsm = smem + wave * V_WAVE_BYTES;
-
-    uint4 kreg[2][KK], vreg[VPASS];
-    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
-    const T* kbase_u = uniform_ptr(kbase);
-    const T* vbase_u = uniform_ptr(vbase);
-    unsigned koff[2], voff[VPASS];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) koff[kb] = (unsigned)(16 * kb + l15) * k_rs_bytes + (unsigned)g4 * 16u;
-#pragma unroll
-    for (int ps = 0; ps < VPASS; ps++) {
-        const int idx = ps * 64 + lane;
-        voff[ps] = (unsigned)(idx / CPR) * v_rs_bytes + (unsigned)(idx % CPR) * 16u;
-    }
-    auto load_tile = [&](int tile) {
-        const int k0 = tile * DC_BN;
-        int rem = Lk - k0;
-        rem = rem < 0 ? 0 : (rem > DC_BN ? DC_BN : rem);
-        const __amdgpu_buffer_rsrc_t kr = make_rsrc(kbase_u + (int64_t)k0 * p.k_row_stride, (unsigned)rem * k_rs_bytes);
-        const __amdgpu_buffer_rsrc_t vr = make_rsrc(vbase_u + (int64_t)k0 * p.v_row_stride, (unsigned)rem * v_rs_bytes);
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int kk = 0; kk < KK; kk++) kreg[kb][kk] = buf_load16(kr, koff[kb] + 64u * kk);
-#pragma unroll
-        for (int ps = 0; ps < VPASS; ps++) vreg[ps] = buf_load16(vr, voff[ps]);
-        if (tile == new_tile) {      // wave-uniform, at most once per workgroup
-            const T* kn = (const T*)p.k_new + (int64_t)b * p.knew_batch_stride + (int64_t)hk * p.knew_head_stride;
-            const T* vn = (const T*)p.v_new + (int64_t)b * p.vnew_batch_stride + (int64_t)hk * p.vnew_head_stride;
-            T* kc = (T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride + (int64_t)new_key * p.k_row_stride;
-            T* vc = (T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride + (int64_t)new_key * p.v_row_stride;
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-                if (k0 + 16 * kb + l15 == new_key) {
-#pragma unroll
-                    for (int kk = 0; kk < KK; kk++) {
-                        const uint4 v = *(const uint4*)(kn + 32 * kk + 8 * g4);
-                        kreg[kb][kk] = v;
-                        if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(kc + 32 * kk + 8 * g4) = v;
-                    }
-                }
-#pragma unroll
-            for (int ps = 0; ps < VPASS; ps++) {
-                const int idx = ps * 64 + lane;
-                if (k0 + idx / CPR == new_key) {
-                    const uint4 v = *(const uint4*)(vn + (idx % CPR) * 8);
-                    vreg[ps] = v;
-                    if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(vc + (idx % CPR) * 8) = v;
-                }
-            }
-        }
-    };
-
-    int tile = __builtin_amdgcn_readfirstlane(tile_begin + wave);
-    load_tile(tile < tile_end ? tile : ntiles_total);     // past the end: every lane out of range, no access
-    for (; tile < tile_end; tile += DC_WAVES) {
-        const int k0 = tile * DC_BN;
-        // ---- V: registers -> wave-private LDS ([d/16][key][16 d]) ----
-#pragma unroll
-        for (int ps = 0; ps < VPASS; ps++) {
-            const int idx = ps * 64 + lane;
-            const int row = idx / CPR, c = idx % CPR;
-            *(uint4*)(vsm + (c >> 1) * VSUB + row * 32 + ((c & 1) << 4)) = vreg[ps];
-        }
-        // ---- S^T = K.Q^T on the register-resident K fragments ----
-        f32x4 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KK; kk++) s[kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qf[kk], s[kb]);
-        }
-        // prefetch the wave's next tile while this one is being consumed (out of range past the split's end)
-        load_tile(tile + DC_WAVES < tile_end ? tile + DC_WAVES : ntiles_total);
-
-        // s[kb][r] = S^T[key = k0 + 16*kb + 4*g4 + r][head row l15]
-        if (k0 + DC_BN > Lk) {
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (k0 + 16 * kb + 4 * g4 + r >= Lk) s[kb][r] = -INFINITY;
-        }
-        float mloc = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) mloc = fmaxf(mloc, s[kb][r]);
-        mloc = fmaxf(mloc, xor_shuffle(mloc, 16));
-        mloc = fmaxf(mloc, xor_shuffle(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
-        const float alpha = fast_exp2(m_run * sc - msub);
-        m_run = m_new;
-        float psum = 0.f;
-        V8 pf;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float e = fast_exp2(__builtin_fmaf(s[kb][r], sc, -msub));
-                psum += e;
-                pf[4 * kb + r] = X::cvt(e);
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DB; i++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[i][r] *= alpha;
-
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- O^T += V^T.P^T : A slot (g4, j) <-> key k0 + (j<4 ? 4*g4 + j : 16 + 4*g4 + j-4) ----
-#pragma unroll
-        for (int db = 0; db < DB; db++) {
-            V8 a;
-            if constexpr (USE_TR) {
-                const char* a1 = vsm + db * VSUB + (4 * g4 + (l15 >> 2)) * 32 + (4 * (l15 & 3)) * 2;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 16 * 32));
-                a = join_tr<V8>(lo, hi);
-            } else {
-                const T* vs = (const T*)(vsm + db * VSUB);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int key = (j < 4) ? 4 * g4 + j : 16 + 4 * g4 + (j - 4);
-                    a[j] = vs[key * 16 + l15];
-                }
-            }
-            o[db] = X::mfma16(a, pf, o[db]);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // ---- merge the 4 waves (each holds a partial softmax over its own tiles) ----
-    l_run += xor_shuffle(l_run, 16);
-    l_run += xor_shuffle(l_run, 32);
-    __syncthreads();                                    // all waves are done with their V staging area
-    // o[db][r] = O^T[d = 16*db + 4*g4 + r][head row l15]
-    float* osm = (float*)smem;                          // [wave][16 rows][HD]
-    float* msm = (float*)(smem + DC_WAVES * 16 * HD * 4);   // [wave][16] m, then [wave][16] l
-    float* lsm = msm + DC_WAVES * 16;
-#pragma unroll
-    for (int db = 0; db < DB; db++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) osm[(wave * 16 + l15) * HD + 16 * db + 4 * g4 + r] = o[db][r];
-    if (g4 == 0) {
-        msm[wave * 16 + l15] = m_run;
-        lsm[wave * 16 + l15] = l_run;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 16 * HD; idx += 64 * DC_WAVES) {
-        const int row = idx / HD, d = idx % HD;
-        const int rh = gb * 16 + row;
-        if (rh >= G) continue;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < DC_WAVES; w++) mx = fmaxf(mx, msm[w * 16 + row]);
-        float acc = 0.f, lsum = 0.f;
-        const float mxs = (mx == -INFINITY) ? 0.f : mx * sc;
-#pragma unroll
-        for (int w = 0; w < DC_WAVES; w++) {
-            const float f = fast_exp2(msm[w * 16 + row] * sc - mxs);
-            acc += f * osm[(w * 16 + row) * HD + d];
-            lsum += f * lsm[w * 16 + row];
-        }
-        const int hh = hk * G + rh;
-        const float inv = (lsum == 0.f || lsum != lsum) ? 1.f : 1.f / lsum;
-        if (num_splits == 1) {
-            ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d] = X::cvt(acc * inv);
-            if (p.softmax_lse && d == 0)
-                p.softmax_lse[(int64_t)b * p.h + hh] = (lsum == 0.f) ? INFINITY : (mx * p.softmax_scale + __logf(lsum));
-        } else {
-            float* oacc = (float*)p.workspace;
-            float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
-            const int64_t row_idx = ((int64_t)split * p.b + b) * p.h + hh;
-            oacc[row_idx * HD + d] = acc * inv;
-            if (d == 0) lacc[row_idx] = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
-        }
-    }
-}
-
-// LSE-weighted merge of the split partials (flash_fwd_kernel.h:1116-1297). One 128-thread block per output row
-// (b, q, h): the split weights are computed once (lanes over splits), then every thread owns one d and streams its
-// partials with independent loads.  Serves the decode form (sq = 1) and the KV-split prefill form.
-// workspace: float o_part[splits][b][sq][h][HD]; float lse_part[splits][b][sq][h]  (log2 domain)
-template <typename T, int HD>
-__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits, int sq) {   // 128 threads: one per split weight, first HD also one per output column
-    __shared__ float wsm[128];
-    __shared__ float red[4];
-    const int64_t row = blockIdx.x;                  // (b * sq + q) * h + head
-    const int hh = (int)(row % p.h);
-    const int64_t bq = row / p.h;
-    const int q = (int)(bq % sq), b = (int)(bq / sq);
-    const int tid = threadIdx.x;
-    const float* oacc = (const float*)p.workspace;
-    const int64_t sstride = (int64_t)p.b * sq * p.h;
-    const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
-    const float my = (tid < num_splits) ? lacc[(int64_t)tid * sstride + row] : -INFINITY;    // num_splits <= 128
-    float mx = my;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(red[0], red[1]);
-    const float mxs = (mx == -INFINITY) ? 0.f : mx;
-    const float w = (tid < num_splits) ? fast_exp2(my - mxs) : 0.f;
-    float ws = w;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ws += xor_shuffle(ws, o);
-    if ((tid & 63) == 0) red[2 + (tid >> 6)] = ws;
-    wsm[tid] = w;
-    __syncthreads();
-    const float wsum = red[2] + red[3];
-    const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
-    if (tid < HD) {
-        const float* src = oacc + row * HD + tid;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < num_splits; s++) acc += wsm[s] * src[(int64_t)s * sstride * HD];
-        ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)q * p.o_row_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
-    }
-    if (p.softmax_lse && tid == 0)
-        p.softmax_lse[((int64_t)b * p.h + hh) * sq + q] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
-}
-
 // Same merge for the KV-split prefill form, where there are b * sq * h output rows (tens of thousands) and at most 16
 // partials each: one WAVE per row (4 rows per 256-thread block), lane l < splits holds partial l's LSE, the weights are
 // broadcast by readlane, every lane owns two adjacent d.
@@ -1177,134 +737,6 @@ __global__ __launch_bounds__(256) void combine_rows_kernel(vattn_attn_params p, 
     }
     if (p.softmax_lse && lane == 0)
         p.softmax_lse[((int64_t)b * p.h + hh) * sq + q] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
-}
-
-// ============================================================================================
-// hardware-layout self test
-// ============================================================================================
-
-// Checks, against plain integer arithmetic, the three layout facts the kernels rely on:
-//  [0] 32x32x16 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-//  [1] 16x16x32 C/D map: col = lane&15, row = 4*(lane>>4) + r
-//  [2] ds_read_b64_tr_b16: lane i of a 16-lane group receives element (i&3) of the 8-byte chunks
-//      addressed by lanes 4*j + (i>>2), j = 0..3, of the same group
-//  [3] A/B operands: lane (x = lane&31, g = lane>>5) contributes row/col x with k-slots (g, 0..7) (32x32x16)
-//  [4] same for 16x16x32 with g = lane>>4
-__global__ void selftest_kernel(int* res) {
-    __shared__ __attribute__((aligned(16))) short lds[64 * 4];
-    const int lane = threadIdx.x;
-    // [0],[3]: A = one-hot rows, B = one-hot cols with distinct values -> C[m][n] = sum_k A[m][k]B[k][n]
-    {
-        // A[m][slot] = (m + 1) if slot == (m & 15) else 0 ; B[slot][n] = (n + 1) * 64 + ... keep small ints
-        f16x8 a, bq;
-        const int x = lane & 31, g = lane >> 5;
-        for (int j = 0; j < 8; j++) {
-            const int slot = 8 * g + j;                 // logical k index shared by A and B
-            a[j] = (_Float16)((slot == (x & 15)) ? (float)(x + 1) : 0.f);      // A[m=x][k]
-            bq[j] = (_Float16)((slot == 3) ? 0.f : 0.f);
-        }
-        // B[k][n=x] = 1 for every k -> C[m][n] = sum_k A[m][k] = m + 1 for every n
-        for (int j = 0; j < 8; j++) bq[j] = (_Float16)1.f;
-        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, c, 0, 0, 0);
-        int bad = 0;
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (c[r] != (float)(row + 1)) bad = 1;
-        }
-        // columns: A[m][k] = 1 for all, B[k][n] = (n+1) if k-slot == (n & 15) -> C[m][n] = n + 1
-        for (int j = 0; j < 8; j++) {
-            a[j] = (_Float16)1.f;
-            bq[j] = (_Float16)(((8 * g + j) == (x & 15)) ? (float)(x + 1) : 0.f);
-        }
-        f32x16 c2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, c2, 0, 0, 0);
-        int bad3 = 0;
-        for (int r = 0; r < 16; r++)
-            if (c2[r] != (float)(x + 1)) bad3 = 1;
-        if (bad) atomicOr(&res[0], 1);
-        if (bad3) atomicOr(&res[3], 1);
-    }
-    {
-        f16x8 a, bq;
-        const int x = lane & 15, g = lane >> 4;
-        for (int j = 0; j < 8; j++) {
-            a[j] = (_Float16)(((8 * g + j) == x) ? (float)(x + 1) : 0.f);
-            bq[j] = (_Float16)1.f;
-        }
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c, 0, 0, 0);
-        int bad = 0;
-        for (int r = 0; r < 4; r++)
-            if (c[r] != (float)(4 * g + r + 1)) bad = 1;
-        for (int j = 0; j < 8; j++) {
-            a[j] = (_Float16)1.f;
-            bq[j] = (_Float16)(((8 * g + j) == x) ? (float)(x + 1) : 0.f);
-        }
-        f32x4 c2 = {0.f, 0.f, 0.f, 0.f};
-        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq, c2, 0, 0, 0);
-        int bad4 = 0;
-        for (int r = 0; r < 4; r++)
-            if (c2[r] != (float)(x + 1)) bad4 = 1;
-        if (bad) atomicOr(&res[1], 1);
-        if (bad4) atomicOr(&res[4], 1);
-    }
-    {
-        // each lane owns the 8-byte chunk at lds[lane*4 .. lane*4+3]; value encodes (lane, element)
-        for (int e = 0; e < 4; e++) lds[lane * 4 + e] = (short)(lane * 4 + e);
-        __syncthreads();
-        const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, &lds[lane * 4]));
-        const int grp = lane >> 4, i = lane & 15;
-        int bad = 0;
-        for (int j = 0; j < 4; j++) {
-            const int src_lane = grp * 16 + 4 * j + (i >> 2);
-            if (t[j] != (short)(src_lane * 4 + (i & 3))) bad = 1;
-        }
-        if (bad) atomicOr(&res[2], 1);
-    }
-}
-
-// ============================================================================================
-// host side
-// ============================================================================================
-
-thread_local std::string g_err;
-int fail(int code, const char* msg) {
-    g_err = msg;
-    return code;
-}
-
-// Split count for the decode form.  The kernel is built for 3 workgroups per CU (<= 168 VGPRs, 33 KiB LDS), i.e.
-// 768 resident workgroups on 256 CUs; like the reference's heuristic (flash_api.cpp:258-323) pick the smallest
-// split count whose last "round" of workgroups is nearly full, but against THIS chip's residency.
-int pick_splits(const vattn_attn_params* p, int gblocks) {
-    if (p->num_splits > 0) return p->num_splits > 128 ? 128 : p->num_splits;
-    const long wg = (long)p->b * p->h_k * gblocks;
-    const long slots = 768;
-    const int max_len = p->seqlen_k + p->seqlen_knew;
-    const int tiles = (max_len + DC_BN - 1) / DC_BN;
-    long cap = tiles / 4;                       // at least one 32-key tile per wave and split
-    if (cap < 1) cap = 1;
-    // a split shorter than ~700 keys costs more in prologue / merge / combine than it returns: B1@32k 20.4 us at 32-48 splits
-    // vs 26 us at 128; short contexts still want one tile per wave (B1@2k: 16 splits 11 us vs 24 us unsplit)
-    if (cap > 48) cap = 48;
-    if (wg * 10 >= slots * 6) return 1;      // the batch alone (nearly) fills the chip: splitting only adds combine work
-    // otherwise: fill whole rounds of resident workgroups exactly (measured on MI355X, tools/kbench.py --splits:
-    // 16 x 4 heads @32k: 12 splits = 768 workgroups 71.4 % of HBM peak vs 63.9-68.8 % for 4/6/8/16/24)
-    double best = 0.0;
-    long pick = 1;
-    for (long s = 1; s <= cap; s++) {
-        const double waves = (double)(wg * s) / slots;
-        const double eff = waves / (double)((wg * s + slots - 1) / slots);
-        if (eff > best + 1e-9) { best = eff; pick = s; }
-    }
-    return (int)pick;
-}
-
-void launch_append(const vattn_attn_params* p, hipStream_t st) {
-    const int total = p->seqlen_knew * p->h_k * (p->d / 8);
-    dim3 grid((total + 255) / 256, p->b), block(256);
-    hipLaunchKernelGGL(append_kv_kernel, grid, block, 0, st, *p);
 }
 
 // variant bits 5-6: workgroup order (wg_to_work): 0 = default (XCD-grouped when the kv heads divide the 8 XCDs),
@@ -1424,191 +856,47 @@ template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(
     }
 }
 
-template <typename T, int HD> int launch_attn_t(const vattn_attn_params* p, hipStream_t st, bool time_only_main) {
-    (void)time_only_main;
+template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, hipStream_t st) {
     const bool use_tr = (p->variant & 1) == 0;
-    if (p->seqlen_q == 1) {
-        const int G = p->h / p->h_k;
-        const int gblocks = (G + 15) / 16;
-        const int splits = pick_splits(p, gblocks);
-        if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
-        dim3 grid(splits, p->h_k * gblocks, p->b), block(64 * DC_WAVES);
-        const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
-        const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
-        if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
-        if (use_tr)
-            hipLaunchKernelGGL((decode_kernel<T, HD, true>), grid, block, smem, st, *p, splits, gblocks, fused_append);
-        else
-            hipLaunchKernelGGL((decode_kernel<T, HD, false>), grid, block, smem, st, *p, splits, gblocks, fused_append);
-        if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits, 1);
-    } else {
-        if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
-        const PrefillPlan pl = plan_prefill(p);
-        if (pl.nsplit > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "KV-split prefill needs a workspace (vattn_attn_workspace_bytes)");
-        bool launched = false;
-        if constexpr (HD == 128) {
-            if (pl.tiling == 2) {
-                launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);
-                launched = true;
-            } else if (pl.tiling == 6) {
-                const int nqb = (p->seqlen_q + 255) / 256;
-                static const bool once6 = [] {
-                    (void)hipFuncSetAttribute((const void*)prefill_ilv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
-                    return true;
-                }();
-                (void)once6;
-                int order;
-                const dim3 grid = prefill_grid(p, nqb, &order);
-                hipLaunchKernelGGL((prefill_ilv_kernel<T>), grid, dim3(512), PfSmem<128>::kTotal, st, *p, order, nqb);
-                launched = true;
-            }
+    if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
+    const PrefillPlan pl = plan_prefill(p);
+    if (pl.nsplit > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "KV-split prefill needs a workspace (vattn_attn_workspace_bytes)");
+    bool launched = false;
+    if constexpr (HD == 128) {
+        if (pl.tiling == 2) {
+            launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);
+            launched = true;
+        } else if (pl.tiling == 6) {
+            const int nqb = (p->seqlen_q + 255) / 256;
+            static const bool once6 = [] {
+                (void)hipFuncSetAttribute((const void*)prefill_ilv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+                return true;
+            }();
+            (void)once6;
+            int order;
+            const dim3 grid = prefill_grid(p, nqb, &order);
+            hipLaunchKernelGGL((prefill_ilv_kernel<T>), grid, dim3(512), PfSmem<128>::kTotal, st, *p, order, nqb);
+            launched = true;
         }
-        if (launched) {
-        } else if (pl.tiling == 4) launch_prefill<T, HD, 4, 1, false>(p, st, use_tr, pl.nsplit);
-        else if ((p->variant & 16) && HD == 128) launch_prefill<T, HD == 128 ? 128 : HD, 8, 1, HD == 128>(p, st, use_tr, pl.nsplit);      // denominator on the matrix pipe
-        else launch_prefill<T, HD, 8, 1, false>(p, st, use_tr, pl.nsplit);
     }
+    if (launched) {
+    } else if (pl.tiling == 4) launch_prefill<T, HD, 4, 1, false>(p, st, use_tr, pl.nsplit);
+    else if ((p->variant & 16) && HD == 128) launch_prefill<T, HD == 128 ? 128 : HD, 8, 1, HD == 128>(p, st, use_tr, pl.nsplit);      // denominator on the matrix pipe
+    else launch_prefill<T, HD, 8, 1, false>(p, st, use_tr, pl.nsplit);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;
 }
 
-int validate(const vattn_attn_params* p) {
-    if (!p || !p->q || !p->out || !p->k_cache || !p->v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
-    if (p->dtype != VATTN_DTYPE_F16 && p->dtype != VATTN_DTYPE_BF16)
-        return fail(VATTN_K_ERR_UNSUPPORTED, "FlashAttention only support fp16 and bf16 data type");      // flash_api.cpp:1325-1326
-    // d = 256 instantiates but spills (O^T alone is 128 accumulator registers per wave): not shipped until it has its own tiling
-    if (p->d != 64 && p->d != 128) return fail(VATTN_K_ERR_UNSUPPORTED, "this build supports head dimensions 64 and 128");
-    if (p->b <= 0) return fail(VATTN_K_ERR_INVALID, "batch size must be postive");                       // flash_api.cpp:1353
-    if (p->h_k <= 0 || p->h % p->h_k != 0)
-        return fail(VATTN_K_ERR_INVALID, "Number of heads in key/value must divide number of heads in query");   // :1355
-    if ((p->k_new == nullptr) != (p->v_new == nullptr))
-        return fail(VATTN_K_ERR_INVALID, "If key is supplied, value must also be passed in");            // :1452
-    if (p->k_new && !p->cache_seqlens)
-        return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");        // :1453
-    if (p->seqlen_q <= 0 || p->seqlen_k < 0) return fail(VATTN_K_ERR_INVALID, "bad sequence lengths");
-    if ((p->q_start == nullptr) != (p->q_lens == nullptr)) return fail(VATTN_K_ERR_INVALID, "q_start and q_lens must be given together");
-    if (p->q_lens && p->seqlen_q == 1) return fail(VATTN_K_ERR_UNSUPPORTED, "batched chunks need max(q_lens) > 1 (the decode form is already batched)");
-    if (p->q_lens && p->k_new) return fail(VATTN_K_ERR_UNSUPPORTED, "batched chunks: append the new keys/values with cache_flat first");
-    // 16-byte vector access requirements
-    const int64_t strides[] = {p->q_batch_stride, p->q_row_stride, p->q_head_stride, p->k_batch_stride, p->k_row_stride,
-                               p->k_head_stride, p->v_batch_stride, p->v_row_stride, p->v_head_stride};
-    for (int64_t s : strides)
-        if (s % 8 != 0) return fail(VATTN_K_ERR_UNSUPPORTED, "strides must be multiples of 8 elements (16-byte vector access)");
-    if (((uintptr_t)p->q | (uintptr_t)p->k_cache | (uintptr_t)p->v_cache | (uintptr_t)p->out) & 15)
-        return fail(VATTN_K_ERR_UNSUPPORTED, "tensor base pointers must be 16-byte aligned");
-    if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
-        return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
-    return VATTN_K_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-const char* vattn_kernels_last_error(void) { return g_err.c_str(); }
-
-size_t vattn_attn_workspace_bytes(const vattn_attn_params* p) {
-    if (!p || p->h_k <= 0 || p->h <= 0 || p->b <= 0 || p->seqlen_q <= 0) return 0;
-    if (p->seqlen_q != 1) {
-        const int ns = plan_prefill(p).nsplit;
-        return ns > 1 ? (size_t)ns * p->b * p->seqlen_q * p->h * (p->d + 1) * sizeof(float) : 0;
-    }
-    const int G = p->h / p->h_k;
-    const int gblocks = (G + 15) / 16;
-    const int splits = pick_splits(p, gblocks);
-    if (splits <= 1) return 0;
-    return (size_t)splits * p->b * p->h * (p->d + 1) * sizeof(float);
-}
-
-int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
-    int rc = validate(p);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (p->k_new && p->seqlen_knew > 0 && !p->cache_seqlens) return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");
+int launch_prefill_form(const vattn_attn_params* p, hipStream_t st) {
     const bool f16 = p->dtype == VATTN_DTYPE_F16;
-    switch (p->d) {
-        case 64: return f16 ? launch_attn_t<_Float16, 64>(p, st, false) : launch_attn_t<__bf16, 64>(p, st, false);
-        default: return f16 ? launch_attn_t<_Float16, 128>(p, st, false) : launch_attn_t<__bf16, 128>(p, st, false);
-    }
+    if (p->d == 64) return f16 ? launch_prefill_t<_Float16, 64>(p, st) : launch_prefill_t<__bf16, 64>(p, st);
+    return f16 ? launch_prefill_t<_Float16, 128>(p, st) : launch_prefill_t<__bf16, 128>(p, st);
 }
 
-int vattn_cache_flat(const void* key, const void* value, void* k_cache, void* v_cache, int64_t num_tokens,
-                     int32_t num_heads, int32_t head_size, int64_t key_stride, int64_t value_stride,
-                     int64_t k_cache_stride, int64_t v_cache_stride, int32_t itemsize, void* stream) {
-    if (num_tokens <= 0) return VATTN_K_OK;
-    if (!key || !value || !k_cache || !v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t n = (int64_t)num_heads * head_size;
-    const int64_t row_bytes = n * itemsize;
-    const bool vec = row_bytes % 16 == 0 && (key_stride * itemsize) % 16 == 0 && (value_stride * itemsize) % 16 == 0 &&
-                     (k_cache_stride * itemsize) % 16 == 0 && (v_cache_stride * itemsize) % 16 == 0 &&
-                     ((((uintptr_t)key) | ((uintptr_t)value) | ((uintptr_t)k_cache) | ((uintptr_t)v_cache)) & 15) == 0;
-    if (vec) {
-        const int cpr = (int)(row_bytes / 16);
-        const int64_t total = num_tokens * cpr;
-        int64_t blocks = (total + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        const int64_t f = 16 / itemsize;
-        hipLaunchKernelGGL(cache_flat_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)key, (const uint4*)value,
-                           (uint4*)k_cache, (uint4*)v_cache, num_tokens, cpr, key_stride / f, value_stride / f,
-                           k_cache_stride / f, v_cache_stride / f);
-    } else {
-        const int64_t total = num_tokens * n;
-        int64_t blocks = (total + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        if (itemsize == 2)
-            hipLaunchKernelGGL(cache_flat_scalar_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t*)key,
-                               (const uint16_t*)value, (uint16_t*)k_cache, (uint16_t*)v_cache, num_tokens, (int)n, key_stride,
-                               value_stride, k_cache_stride, v_cache_stride);
-        else if (itemsize == 4)
-            hipLaunchKernelGGL(cache_flat_scalar_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)key,
-                               (const uint32_t*)value, (uint32_t*)k_cache, (uint32_t*)v_cache, num_tokens, (int)n, key_stride,
-                               value_stride, k_cache_stride, v_cache_stride);
-        else
-            return fail(VATTN_K_ERR_UNSUPPORTED, "cache_flat supports 2- and 4-byte element types");
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
-    return VATTN_K_OK;
+size_t prefill_workspace_bytes(const vattn_attn_params* p) {
+    const int ns = plan_prefill(p).nsplit;
+    return ns > 1 ? (size_t)ns * p->b * p->seqlen_q * p->h * (p->d + 1) * sizeof(float) : 0;
 }
 
-int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
-    hipStream_t st = (hipStream_t)stream;
-    int* d = nullptr;
-    if (hipMalloc(&d, 8 * sizeof(int)) != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed");
-    hipMemsetAsync(d, 0, 8 * sizeof(int), st);
-    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d);
-    int h[8] = {0};
-    hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d);
-    if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
-    int bad = 0;
-    for (int i = 0; i < 8; i++) {
-        if (detail_out) detail_out[i] = h[i];
-        bad |= h[i];
-    }
-    return bad ? fail(VATTN_K_ERR_INVALID, "hardware layout assumption violated") : VATTN_K_OK;
-}
-
-float vattn_time_attn(const vattn_attn_params* p, void* stream, int32_t warmup, int32_t iters) {
-    hipStream_t st = (hipStream_t)stream;
-    for (int i = 0; i < warmup; i++)
-        if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, st);
-    for (int i = 0; i < iters; i++)
-        if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
-    hipEventRecord(e1, st);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    return ms / (iters > 0 ? iters : 1);
-}
-
-}  // extern "C"
+}  // namespace vattn_k
