@@ -32,10 +32,26 @@ __global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel
     const int l15 = lane & 15;
     const int g4 = lane >> 4;
 
-    const int split = blockIdx.x;
-    const int hk = blockIdx.y / gblocks;
-    const int gb = blockIdx.y % gblocks;
-    const int b = blockIdx.z;
+    int split, hk, gb, b;
+    if (gridDim.y == 1 && gridDim.z == 1 && gblocks > 1) {
+        // G > 16 query heads per kv head (MQA models): the ceil(G/16) head blocks of one (split, kv head, sequence) read the
+        // SAME K/V rows.  1-D grid laid out so that those sibling workgroups get consecutive slots on ONE XCD (ids 8 apart):
+        // the first reader pulls the rows from HBM, the others hit that XCD's L2
+        const int L = blockIdx.x;
+        const int xcd = L & 7, j = L >> 3;
+        gb = j % gblocks;
+        const int w = (j / gblocks) * 8 + xcd;             // flattened (split, kv head, sequence)
+        const int per_b = num_splits * p.h_k;
+        if (w >= per_b * p.b) return;
+        b = w / per_b;
+        hk = (w % per_b) / num_splits;
+        split = w % num_splits;
+    } else {
+        split = blockIdx.x;
+        hk = blockIdx.y / gblocks;
+        gb = blockIdx.y % gblocks;
+        b = blockIdx.z;
+    }
     const int G = p.h / p.h_k;
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
     const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
@@ -334,6 +350,10 @@ template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hi
     const int splits = pick_splits(p, gblocks);
     if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
     dim3 grid(splits, p->h_k * gblocks, p->b), block(64 * DC_WAVES);
+    if (gblocks > 1 && !(p->variant & 64)) {           // sibling head blocks share an XCD (variant bit 6: plain 3-D grid, for A/B)
+        const long w = (long)splits * p->h_k * p->b;
+        grid = dim3((unsigned)(((w + 7) / 8) * 8 * gblocks));
+    }
     const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
