@@ -35,6 +35,24 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def _set_cache(p, k_cache, v_cache):
+    p.k_cache, p.v_cache = k_cache.data_ptr(), v_cache.data_ptr()
+    p.k_batch_stride, p.k_row_stride, p.k_head_stride = k_cache.stride(0), k_cache.stride(1), k_cache.stride(2)
+    p.v_batch_stride, p.v_row_stride, p.v_head_stride = v_cache.stride(0), v_cache.stride(1), v_cache.stride(2)
+
+
+def _launch(p, dev):
+    """Attach the split-KV workspace the call needs (one buffer per device and stream) and launch on the current stream."""
+    lib = K.klib()
+    need = lib.vattn_attn_workspace_bytes(C.byref(p))
+    if need:
+        ws = _workspace(need, dev)       # kept alive by the per-(device, stream) cache until a larger one replaces it
+        p.workspace = ws.data_ptr()
+    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), K.current_stream_ptr(dev))
+    if rc != 0:
+        raise RuntimeError(K.last_error())
+
+
 def _check_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -107,9 +125,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.q, p.out = q.data_ptr(), out.data_ptr()
     p.q_batch_stride, p.q_row_stride, p.q_head_stride = q.stride(0), q.stride(1), q.stride(2)
     p.o_batch_stride, p.o_row_stride, p.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
-    p.k_cache, p.v_cache = k_cache.data_ptr(), v_cache.data_ptr()
-    p.k_batch_stride, p.k_row_stride, p.k_head_stride = k_cache.stride(0), k_cache.stride(1), k_cache.stride(2)
-    p.v_batch_stride, p.v_row_stride, p.v_head_stride = v_cache.stride(0), v_cache.stride(1), v_cache.stride(2)
+    _set_cache(p, k_cache, v_cache)
     if k is not None:
         p.k_new, p.v_new = k.data_ptr(), v.data_ptr()
         p.knew_batch_stride, p.knew_row_stride, p.knew_head_stride = k.stride(0), k.stride(1), k.stride(2)
@@ -124,15 +140,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.softmax_scale = float(softmax_scale)
     p.variant = int(_variant)
     p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
-    lib = K.klib()
-    need = lib.vattn_attn_workspace_bytes(C.byref(p))
-    ws = None
-    if need:
-        ws = _workspace(need, dev)
-        p.workspace = ws.data_ptr()
-    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), K.current_stream_ptr(dev))
-    if rc != 0:
-        raise RuntimeError(K.last_error())
+    _launch(p, dev)
     return (out, lse) if return_softmax_lse else out
 
 
@@ -185,9 +193,7 @@ def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q
     p.q, p.out = q.data_ptr(), out.data_ptr()
     p.q_batch_stride, p.q_row_stride, p.q_head_stride = 0, q.stride(0), q.stride(1)
     p.o_batch_stride, p.o_row_stride, p.o_head_stride = 0, out.stride(0), out.stride(1)
-    p.k_cache, p.v_cache = k_cache.data_ptr(), v_cache.data_ptr()
-    p.k_batch_stride, p.k_row_stride, p.k_head_stride = k_cache.stride(0), k_cache.stride(1), k_cache.stride(2)
-    p.v_batch_stride, p.v_row_stride, p.v_head_stride = v_cache.stride(0), v_cache.stride(1), v_cache.stride(2)
+    _set_cache(p, k_cache, v_cache)
     p.cache_seqlens = cache_seqlens.contiguous().data_ptr()
     p.cache_batch_idx = cache_batch_idx.contiguous().data_ptr() if cache_batch_idx is not None else None
     p.q_start, p.q_lens = q_start.contiguous().data_ptr(), q_lens.contiguous().data_ptr()
@@ -198,12 +204,5 @@ def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q
     p.softmax_scale = float(softmax_scale)
     p.variant = int(_variant)
     p.max_seqlen_k_hint = min(int(_max_seqlen_k), Sk) if _max_seqlen_k > 0 else 0
-    lib = K.klib()
-    need = lib.vattn_attn_workspace_bytes(C.byref(p))
-    if need:
-        ws = _workspace(need, dev)
-        p.workspace = ws.data_ptr()
-    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), K.current_stream_ptr(dev))
-    if rc != 0:
-        raise RuntimeError(K.last_error())
+    _launch(p, dev)
     return out
