@@ -80,3 +80,43 @@ def test_plain_c_client_drives_the_boundary(tmp_path):
     assert "step_async 0" in text and "pool_pages 52 mapped_groups 3 needed_groups 3 active_slots 1 map_calls 12" in text
     assert "bad_len -1 err 'seq_lens must have max_batch_size entries'" in text
     assert "cleanup 0" in text and "null_params" in text and "null tensor pointer" in text
+
+
+def test_split_plans_from_the_workspace_query():
+    import ctypes as C
+    """vattn_attn_workspace_bytes is pure host code: it exposes the split decisions (decode split-KV, prefill KV split) without
+    a GPU.  Pins the documented plans (DESIGN.md §5 / §6b) so a heuristic change shows up here."""
+    from vattention_amd import kernels as K
+    lib = K.klib()
+
+    def ws(b, sq, sk, h, hk, d=128, hint=0, causal=1, splits=0, variant=0):
+        p = K.AttnParams()
+        p.b, p.seqlen_q, p.seqlen_k, p.seqlen_knew, p.h, p.h_k, p.d = b, sq, sk, 0, h, hk, d
+        p.is_causal, p.dtype, p.num_splits, p.variant, p.max_seqlen_k_hint = causal, 0, splits, variant, hint
+        return lib.vattn_attn_workspace_bytes(C.byref(p))
+
+    def dec_splits(b, ctx, h, hk, d=128):
+        n = ws(b, 1, ctx, h, hk, d)
+        return n // (b * h * (d + 1) * 4) if n else 1
+
+    def pf_splits(sq, sk, h, hk, hint, b=1, d=128, **kw):
+        n = ws(b, sq, sk, h, hk, d, hint=hint, **kw)
+        return n // (b * sq * h * (d + 1) * 4) if n else 1
+
+    # decode: fill the 768 resident workgroups, never more than 48 splits, none when the batch alone fills the chip
+    assert dec_splits(16, 32768, 32, 4) == 12           # c2: 16 x 4 kv heads x 12 = 768
+    assert dec_splits(1, 32768, 32, 4) == 48
+    assert dec_splits(4, 32768, 32, 4) == 48
+    assert dec_splits(256, 2048, 32, 8) == 1
+    assert dec_splits(1, 2048, 32, 4) == 16             # one 32-key tile per wave and split at most
+    # prefill: shapes that fill the chip stay single-pass
+    assert pf_splits(32702, 32768, 32, 4, 32702) == 1   # c2 whole prompt
+    assert pf_splits(4096, 32768, 32, 4, 32768) == 1    # 4k chunk, 32 heads: 512 workgroups
+    assert pf_splits(8192, 8192, 8, 1, 8192) == 1       # TP8 8k prompt: exactly one 8-wave workgroup per CU -> 4-wave tiling, no split
+    # tensor-parallel shards / short chunks on long prefixes are split (only when the host knows the lengths)
+    assert pf_splits(2048, 32768, 8, 1, 32768) == 4     # 64 workgroups x 4 = one round
+    assert pf_splits(2048, 32768, 8, 1, 0) <= 2          # without the lengths only the chunk itself is certain: 16 tiles
+    assert pf_splits(512, 16384, 8, 1, 16384) == 8
+    assert 2 <= pf_splits(1024, 65536, 28, 4, 65536) <= 8
+    assert pf_splits(2048, 32768, 8, 1, 32768, variant=12) == 1      # the interleaved kernel has no split epilogue
+    assert pf_splits(300, 1400, 8, 2, 1200, splits=5) == 5           # forced
