@@ -353,3 +353,42 @@ def test_attention_on_virtual_tensors_never_touches_unmapped_pages():
             assert (out[i:i + 1].double().cpu() - ref).abs().max() < 4e-3
     finally:
         vattention.cleanup()
+
+
+def test_decode_call_is_hip_graph_capturable():
+    """An engine that captures its decode step in a HIP graph (torch.cuda.graph) can include this path: the launch makes no
+    allocation or synchronising call once the split-KV workspace exists, and everything that changes between steps (lengths,
+    slots, the new K/V rows, q) is read from device memory at replay time."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(21)
+    B, Hq, Hkv, D, ctx = 4, 8, 2, 128, 3000
+    kc = torch.randn(6, ctx, Hkv, D, device=DEV).half()
+    vc = torch.randn(6, ctx, Hkv, D, device=DEV).half()
+    q = torch.randn(B, 1, Hq, D, device=DEV).half()
+    kn = torch.randn(B, 1, Hkv, D, device=DEV).half()
+    vn = torch.randn(B, 1, Hkv, D, device=DEV).half()
+    cl = torch.tensor([100, 2500, 31, 1999], dtype=torch.int32, device=DEV)
+    idx = torch.tensor([5, 0, 3, 1], dtype=torch.int32, device=DEV)
+    out = torch.empty_like(q)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up on the capture stream: creates that stream's workspace
+        flash_attn_with_kvcache(q, kc.clone(), vc.clone(), kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    kg, vg = kc.clone(), vc.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        flash_attn_with_kvcache(q, kg, vg, kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, out=out)
+    for step in range(3):
+        # new inputs written into the captured buffers, then replay
+        q.copy_(torch.randn_like(q)); kn.copy_(torch.randn_like(kn)); vn.copy_(torch.randn_like(vn))
+        if step:
+            cl.add_(1)
+        ke, ve = kg.clone(), vg.clone()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = flash_attn_with_kvcache(q, ke, ve, kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), step
+        assert torch.equal(kg, ke) and torch.equal(vg, ve)
