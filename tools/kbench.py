@@ -67,6 +67,25 @@ def prefill(variant):
         scale = float(os.environ.get("KBENCH_DATA_SCALE", "1"))     # 0 = zero-filled inputs (data-dependent power: clocks rise)
         if scale != 1.0:
             q, kc, vc = q * scale, kc * scale, vc * scale
+        if os.environ.get("KBENCH_DATA_STYLE") == "same_token":
+            # what the reference's own benchmark feeds its kernels: prompt ids [1]*n through random-init weights
+            # (scripts/benchmark_e2e_static_trace.py) -> every position carries the SAME hidden state, so v rows are identical and
+            # q / k rows are RoPE rotations of one vector per head
+            def rope(x, pos0):
+                T, H, Dh = x.shape[1], x.shape[2], x.shape[3]
+                pos = torch.arange(pos0, pos0 + T, device=DEV, dtype=torch.float32)[:, None]
+                inv = 10000.0 ** (-torch.arange(0, Dh, 2, device=DEV, dtype=torch.float32) / Dh)
+                ang = pos * inv[None, :]
+                cos, sin = ang.cos()[None, :, None, :], ang.sin()[None, :, None, :]
+                x = x.float()
+                x1, x2 = x[..., 0::2], x[..., 1::2]
+                o = torch.empty_like(x)
+                o[..., 0::2] = x1 * cos - x2 * sin
+                o[..., 1::2] = x1 * sin + x2 * cos
+                return o.to(DTYPE)
+            q = rope(q[:, :1].expand(-1, n, -1, -1).contiguous(), c)
+            kc = rope(kc[:, :1].expand(-1, c + n, -1, -1).contiguous(), 0)
+            vc = vc[:, :1].expand(-1, c + n, -1, -1).contiguous()
         cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
         p, keep = params(q, kc, vc, cl, variant=variant, splits=PF_SPLITS)
         ms = time_ms(p, 1, 3 if n > 10000 else 10)
