@@ -1,0 +1,124 @@
+"""Seeded random sweep of the operator's argument space against the CPU oracle (small sizes, many shapes): head counts and
+group sizes, head dimension 64 / 128, fp16 / bf16, ragged batches through cache_batch_idx, causal and full attention,
+query chunks longer than the visible keys, forced and automatic split counts, every workgroup order / tiling, batched
+variable-length chunks, decode with in-kernel append.  Deterministic (fixed seeds), ~100 cases."""
+import random
+
+import pytest
+import torch
+
+from oracle.attn import flash_attn_with_kvcache_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _tol(dtype):
+    return (2e-3, 2e-3) if dtype == torch.float16 else (1.6e-2, 1.6e-2)
+
+
+def _check(out, ref64, dtype, what):
+    atol, rtol = _tol(dtype)
+    err = (out.double().cpu() - ref64).abs()
+    bound = atol + rtol * ref64.abs()
+    assert bool((err <= bound).all()), "%s: max err %.3e" % (what, err.max().item())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_prefill(seed):
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    rng = random.Random(1000 + seed)
+    torch.manual_seed(seed)
+    for case in range(8):
+        D = rng.choice([64, 128, 128])
+        dtype = rng.choice([torch.float16, torch.float16, torch.bfloat16])
+        Hkv = rng.choice([1, 2, 3, 4, 8])
+        G = rng.choice([1, 2, 4, 7, 8])
+        Hq = Hkv * G
+        B = rng.choice([1, 1, 2, 3])
+        n = rng.choice([2, 17, 64, 100, 129, 257, 300, 520])
+        ctx = 1200
+        causal = rng.random() < 0.8
+        cls = [rng.choice([0, 1, 30, 64, 333, 600]) + (n if rng.random() < 0.85 else rng.randrange(1, n + 1)) for _ in range(B)]
+        slots = rng.sample(range(B + 2), B)
+        variant = rng.choice([0, 0, 1, 2, 8, 9, 32, 64, 12 if D == 128 else 0, 4 if D == 128 else 0])
+        splits = rng.choice([0, 0, 0, 1, 2, 3, 7])
+        q = torch.randn(B, n, Hq, D).to(dtype)
+        kc = torch.randn(B + 2, ctx, Hkv, D).to(dtype)
+        vc = torch.randn(B + 2, ctx, Hkv, D).to(dtype)
+        cl = torch.tensor(cls, dtype=torch.int32)
+        idx = torch.tensor(slots, dtype=torch.int32)
+        ref = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=causal)
+        out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
+                                      causal=causal, num_splits=splits, _variant=variant, _max_seqlen_k=rng.choice([0, max(cls)]))
+        torch.cuda.synchronize()
+        _check(out, ref, dtype, "prefill seed %d case %d (D=%d Hq=%d Hkv=%d B=%d n=%d cl=%s causal=%s variant=%d splits=%d)" % (
+            seed, case, D, Hq, Hkv, B, n, cls, causal, variant, splits))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_batched_chunks(seed):
+    from vattention_amd.flash_attn import flash_attn_varlen_with_kvcache
+    rng = random.Random(2000 + seed)
+    torch.manual_seed(100 + seed)
+    for case in range(5):
+        D = rng.choice([64, 128])
+        Hkv = rng.choice([1, 2, 4])
+        Hq = Hkv * rng.choice([1, 4, 8])
+        B = rng.choice([2, 3, 5])
+        lens = [rng.choice([1, 5, 64, 130, 256, 300, 511]) for _ in range(B)]
+        if max(lens) < 2:
+            lens[0] = 40
+        pre = [rng.choice([0, 3, 128, 400]) for _ in range(B)]
+        ctx = 1000
+        T = sum(lens)
+        q = torch.randn(T, Hq, D).half()
+        kc = torch.randn(B + 1, ctx, Hkv, D).half()
+        vc = torch.randn(B + 1, ctx, Hkv, D).half()
+        starts = [sum(lens[:i]) for i in range(B)]
+        cls = [a + b for a, b in zip(pre, lens)]
+        slots = rng.sample(range(B + 1), B)
+        i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
+        out = flash_attn_varlen_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), i32(starts), i32(lens), max(lens), i32(cls), i32(slots),
+                                             causal=True, num_splits=rng.choice([0, 0, 2, 5]), _variant=rng.choice([0, 2, 8, 64]),
+                                             _max_seqlen_k=max(cls))
+        torch.cuda.synchronize()
+        for i in range(B):
+            ref = flash_attn_with_kvcache_ref(q[starts[i]:starts[i] + lens[i]].unsqueeze(0), kc, vc,
+                                              cache_seqlens=torch.tensor([cls[i]], dtype=torch.int32),
+                                              cache_batch_idx=torch.tensor([slots[i]], dtype=torch.int32), causal=True)
+            _check(out[starts[i]:starts[i] + lens[i]].unsqueeze(0), ref, torch.float16, "varlen seed %d case %d entry %d" % (seed, case, i))
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_fuzz_decode(seed):
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    rng = random.Random(3000 + seed)
+    torch.manual_seed(200 + seed)
+    for case in range(8):
+        D = rng.choice([64, 128, 128])
+        dtype = rng.choice([torch.float16, torch.bfloat16])
+        Hkv = rng.choice([1, 2, 4, 8])
+        G = rng.choice([1, 4, 7, 8, 16, 17, 40])
+        Hq = Hkv * G
+        B = rng.choice([1, 2, 5, 9])
+        ctx = rng.choice([40, 700, 2100])
+        cls = [rng.randrange(0, ctx - 1) for _ in range(B)]
+        slots = rng.sample(range(B + 3), B)
+        append = rng.random() < 0.7
+        q = torch.randn(B, 1, Hq, D).to(dtype)
+        kc = torch.randn(B + 3, ctx, Hkv, D).to(dtype)
+        vc = torch.randn(B + 3, ctx, Hkv, D).to(dtype)
+        kn = torch.randn(B, 1, Hkv, D).to(dtype) if append else None
+        vn = torch.randn(B, 1, Hkv, D).to(dtype) if append else None
+        cl = torch.tensor(cls if append else [c + 1 for c in cls], dtype=torch.int32)
+        idx = torch.tensor(slots, dtype=torch.int32)
+        kr, vr = kc.clone(), vc.clone()
+        ref = flash_attn_with_kvcache_ref(q, kr, vr, kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+        kg, vg = kc.to(DEV), vc.to(DEV)
+        out = flash_attn_with_kvcache(q.to(DEV), kg, vg, kn.to(DEV) if append else None, vn.to(DEV) if append else None,
+                                      cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True,
+                                      num_splits=rng.choice([0, 0, 1, 2, 9, 48]), _variant=rng.choice([0, 1, 64]))
+        torch.cuda.synchronize()
+        _check(out, ref, dtype, "decode seed %d case %d (D=%d Hq=%d Hkv=%d B=%d ctx=%d append=%s)" % (seed, case, D, Hq, Hkv, B, ctx, append))
+        assert torch.equal(kg.cpu(), kr) and torch.equal(vg.cpu(), vr)
