@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--page-size", type=int, default=2 << 20)
     ap.add_argument("--mem-util", type=float, default=0.9)
     ap.add_argument("--chunk", type=int, default=0, help="0 = vLLM scheduler (whole prompts); >0 = chunked prefill")
+    ap.add_argument("--tp", type=int, default=1, help="run ONE rank's share of a tensor-parallel model (heads / tp); other configs than the default are not the bench line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; makes the number INVALID)")
     return ap.parse_args()
@@ -119,7 +120,7 @@ def main():
     model = ModelConfig.named(a.model, dtype=dtype, max_model_len=a.ctx, attention_backend="fa_vattn")
     if a.layers:
         model.num_layers = a.layers
-    par = ParallelConfig(1, 1)
+    par = ParallelConfig(a.tp, 1)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     # memory_for_gpu = total*util - peak of the (absent) model body; keep 12 GiB for activations/workspace
     mem_for_kv = min(int(total_b * a.mem_util), free_b) - (12 << 30)
@@ -188,12 +189,14 @@ def main():
 
     # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs, read side doubled per the gfx950 note in MI355X_MICROARCH.md); null for shapes that were not profiled
+    is_default = (a.model == "yi-6b" and a.ctx == 32768 and a.batch == 16 and a.pd_ratio == 500.0 and not a.chunk and a.tp == 1
+                  and not a.layers and a.page_size == 2 << 20)
     traffic_pf = traffic_dc = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if a.model == "yi-6b" and a.ctx == 32768 and not a.chunk:
+        if a.model == "yi-6b" and a.ctx == 32768 and not a.chunk and a.tp == 1:
             traffic_pf = tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"]
-        if a.model == "yi-6b" and a.ctx == 32768 and a.batch == 16:
+        if a.model == "yi-6b" and a.ctx == 32768 and a.batch == 16 and a.tp == 1:
             traffic_dc = tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -213,10 +216,11 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: %s TP=1 fa_vattn_2mb static trace @ %d ctx, P:D=%g (%d prefill + %d decode tokens/request), "
+                "workload": ("configs[1]: " if is_default else "custom (NOT the bench line; one rank of TP=%d): " % a.tp) +
+                            "%s fa_vattn_2mb static trace @ %d ctx, P:D=%g (%d prefill + %d decode tokens/request), "
                             "vLLM scheduler%s, one step = one max_batch_size=%d wave of requests over all %d layers, page %d KiB, async mapping; "
                             "attention+KV hot path only (transformer GEMMs out of scope, q/k/v synthetic)"
-                            % (a.model, a.ctx, a.pd_ratio, prefill, decode, "" if not a.chunk else " chunk=%d" % a.chunk, a.batch, L, a.page_size >> 10),
+                            % (a.model + (" TP=1" if is_default else ""), a.ctx, a.pd_ratio, prefill, decode, "" if not a.chunk else " chunk=%d" % a.chunk, a.batch, L, a.page_size >> 10),
                 "requests_per_step": a.batch, "layers": L, "hq": Hq, "hkv": Hkv, "head_dim": D,
                 "parallelism": "replicas x%d (no collective on the path)" % world if world > 1 else "single GPU",
             },
