@@ -95,3 +95,46 @@ def test_cache_flat_rejects_dtype():
     k = torch.zeros(2, 1, 8).half()
     with pytest.raises(RuntimeError, match="Unsupported data type"):
         cache_flat_ref(k, k, k.clone(), k.clone(), "fp8")
+
+
+def test_against_a_scalar_python_restatement():
+    """Third, fully independent leg for the oracle: a scalar pure-Python evaluation of the published operator
+    (flash_attn_interface.py:1168-1254: append at cache_seqlens, GQA head mapping h -> h // (Hq/Hkv), bottom-right aligned
+    causal mask, rows with no visible key -> 0) on tiny shapes, including seqlen_q > seqlen_k and cache_batch_idx."""
+    import math
+    torch.manual_seed(3)
+    B, Sq, Hq, Hkv, D, Sk = 2, 5, 4, 2, 8, 9
+    q = torch.randn(B, Sq, Hq, D, dtype=torch.float64)
+    kc = torch.randn(3, Sk, Hkv, D, dtype=torch.float64)
+    vc = torch.randn(3, Sk, Hkv, D, dtype=torch.float64)
+    kn = torch.randn(B, 2, Hkv, D, dtype=torch.float64)
+    vn = torch.randn(B, 2, Hkv, D, dtype=torch.float64)
+    cls = [1, 6]                      # entry 0: 1 cached + 2 new = 3 keys < 5 queries -> the first two query rows see nothing
+    idx = [2, 0]
+    for causal in (True, False):
+        k2, v2 = kc.clone(), vc.clone()
+        got = flash_attn_with_kvcache_ref(q, k2, v2, kn, vn, cache_seqlens=torch.tensor(cls, dtype=torch.int32),
+                                          cache_batch_idx=torch.tensor(idx, dtype=torch.int32), causal=causal)
+        ke, ve = kc.clone(), vc.clone()
+        scale = 1.0 / math.sqrt(D)
+        for b in range(B):
+            slot, c = idx[b], cls[b]
+            for t in range(2):
+                ke[slot, c + t] = kn[b, t]
+                ve[slot, c + t] = vn[b, t]
+            Lk = c + 2
+            for i in range(Sq):
+                for h in range(Hq):
+                    hk = h // (Hq // Hkv)
+                    vis = [j for j in range(Lk) if (not causal) or j <= i + (Lk - Sq)]
+                    if not vis:
+                        want = [0.0] * D
+                    else:
+                        s = [scale * sum(float(q[b, i, h, d]) * float(ke[slot, j, hk, d]) for d in range(D)) for j in vis]
+                        m = max(s)
+                        w = [math.exp(x - m) for x in s]
+                        z = sum(w)
+                        want = [sum(w[n] * float(ve[slot, j, hk, d]) for n, j in enumerate(vis)) / z for d in range(D)]
+                    for d in range(D):
+                        assert abs(float(got[b, i, h, d]) - want[d]) < 1e-9, (causal, b, i, h, d)
+        assert torch.equal(k2, ke) and torch.equal(v2, ve)       # the append itself
