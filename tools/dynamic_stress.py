@@ -18,6 +18,8 @@ ap.add_argument("--tp", type=int, default=1)
 ap.add_argument("--passes", type=int, default=1, help="replay the trace this many times on the same allocator (pass 2+ = warm handle pool)")
 ap.add_argument("--megacache", action="store_true", help="one page covers all layers (2 handles per page-group instead of 2L)")
 a = ap.parse_args()
+_fx = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "c3_arxiv_lengths_256.json")
+LENGTHS = json.load(open(_fx))["requests"] if os.path.exists(_fx) and not os.environ.get("VATTN_FITTED_LENGTHS") else None
 torch.zeros(1, device="cuda")
 model = ModelConfig.named(a.model, dtype=torch.float16, max_model_len=32768, attention_backend="fa_vattn_megacache" if "--megacache" in sys.argv else "fa_vattn")
 if a.layers:
@@ -28,7 +30,8 @@ r = HotPathRunner(model, ParallelConfig(a.tp, 1), CacheConfig(page_size=a.page_k
 try:
     for ps in range(a.passes):
         r.stats.__init__()
-        out = r.run_dynamic_trace(a.requests)
+        out = r.run_dynamic_trace(a.requests, lengths=LENGTHS)
+        out["lengths_from"] = "tests/golden/c3_arxiv_lengths_256.json (reference recipe)" if LENGTHS else "fitted log-normals"
         out["pass"] = ps + 1
         if ps + 1 < a.passes:
             print(json.dumps(out), flush=True)

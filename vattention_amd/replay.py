@@ -229,11 +229,12 @@ class HotPathRunner:
             running = [s for s in running if not s.is_finished()]
         return self.stats
 
-    def run_dynamic_trace(self, num_requests: int, seed: int = 42, max_tokens: int = 32768, watermark: float = 0.01) -> dict:
+    def run_dynamic_trace(self, num_requests: int, seed: int = 42, max_tokens: int = 32768, watermark: float = 0.01,
+                          lengths: Optional[List[List[int]]] = None) -> dict:
         """Capacity / fragmentation stress in the shape of the reference's dynamic trace
         (scripts/benchmark_e2e_dynamic_trace.py:7-60: 256 requests, arxiv-summarisation lengths, vLLM scheduler,
-        max_batch_size 256).  The trace CSV is reference data that does not travel; lengths are drawn from shifted
-        log-normals fitted to its marginals (prefill min 4097 / p50 7958 / p75 13186 / max 31805, decode min 105 / p50 332 /
+        max_batch_size 256).  `lengths` = the request lengths the reference's recipe yields (fixture generated by
+        oracle/gen_golden_c3_lengths.py); without it lengths are drawn from shifted log-normals fitted to the trace's marginals (prefill min 4097 / p50 7958 / p75 13186 / max 31805, decode min 105 / p50 332 /
         p75 482; scripts/artifact_asplos25/traces/arxiv_sample.csv), total capped at max_tokens.  Arrivals are closed-loop
         (every request is waiting at t=0): without the transformer body an open-loop qps=4 would leave the GPU idle.
         Admission is the reference's count-based rule (vattention_block_space_manager.py:36-66):
@@ -246,8 +247,11 @@ class HotPathRunner:
         pages = lambda n: (n + tpp - 1) // tpp
         reqs = []
         for i in range(num_requests):
-            pre = min(31805, int(4097 + rng.lognormvariate(math.log(3861), 1.27)))
-            dec = int(105 + rng.lognormvariate(math.log(227), 0.75))
+            if lengths:        # (prefill, decode) pairs produced by the reference's own recipe: tests/golden/c3_arxiv_lengths_256.json
+                pre, dec = lengths[i % len(lengths)]
+            else:
+                pre = min(31805, int(4097 + rng.lognormvariate(math.log(3861), 1.27)))
+                dec = int(105 + rng.lognormvariate(math.log(227), 0.75))
             tot = min(max_tokens, pre + dec)
             pre = min(pre, tot - 1)
             reqs.append(Sequence(i, pre, tot))
