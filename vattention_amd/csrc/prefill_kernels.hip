@@ -396,15 +396,38 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
             if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_run[qc] * sc + __log2f(l_tot));
         } else if (my_q < Sq) {
             T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + my_q) * p.o_row_stride + (int64_t)h * p.o_head_stride;
+            if ((((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0) && !ABL(7)) {
+                // 16-byte stores: lane l (g = 0) and lane l + 32 (g = 1) hold d..d+3 and d+4..d+7 of the SAME row for every
+                // 8-wide d group tq; one v_permlane32_swap per dword hands the g = 0 lane the whole even group and the g = 1
+                // lane the whole odd group -> 8 x 16 B per lane instead of 16 x 8 B (the store tail is issue-bound)
 #pragma unroll
-            for (int db = 0; db < DB; db++)
+                for (int db = 0; db < DB; db++)
 #pragma unroll
-                for (int tq = 0; tq < 4; tq++) {
-                    typename X::v4 w;
+                    for (int pr = 0; pr < 2; pr++) {
+                        typename X::v4 we, wo;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][qc][4 * tq + e] * inv);
-                    *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
-                }
+                        for (int e = 0; e < 4; e++) {
+                            we[e] = X::cvt(o[db][qc][4 * (2 * pr) + e] * inv);
+                            wo[e] = X::cvt(o[db][qc][4 * (2 * pr + 1) + e] * inv);
+                        }
+                        uint2 ue, uo;
+                        __builtin_memcpy(&ue, &we, 8);
+                        __builtin_memcpy(&uo, &wo, 8);
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
+                        *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+            } else {
+#pragma unroll
+                for (int db = 0; db < DB; db++)
+#pragma unroll
+                    for (int tq = 0; tq < 4; tq++) {
+                        typename X::v4 w;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][qc][4 * tq + e] * inv);
+                        *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+                    }
+            }
             if (p.softmax_lse && g == 0) {
                 // natural-log LSE of scale*QK^T; +inf for fully masked rows (flash convention)
                 const float lse = (l_tot == 0.f) ? INFINITY : (m_run[qc] * p.softmax_scale + __logf(l_tot));
