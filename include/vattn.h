@@ -35,6 +35,13 @@ extern "C" {
 #define VATTN_FLAG_EAGER_CREATE 1u      /* create every physical handle inside reserve (reference behaviour) */
 #define VATTN_FLAG_NO_ACCESS_MERGE 2u   /* one set-access call per page instead of one per contiguous run   */
 #define VATTN_FLAG_NO_MAPPER_THREAD 4u  /* run "background" work inline (deterministic tests)               */
+/* step_async maps a new prompt's pages LAYER-ORDERED: layers [0, sync_layers) before it returns, the remaining layers on the
+ * mapper thread, which publishes a per-layer ready count; the caller must then call vattn_wait_layer(l) before it launches
+ * layer l's kernels (the attention wrapper does).  Hides (L - sync_layers)/L of new-prompt mapping under the layers already
+ * running.  Opt-in: an engine that does not call vattn_wait_layer must not set it.  Ignored with megacache (one page covers
+ * every layer) and for batches that unmap. */
+#define VATTN_FLAG_LAYERED_ASYNC 8u
+#define VATTN_FLAG_NO_VMM_SELFCHECK 16u /* skip the remap/TLB self-check the HIP backend runs once per device at create  */
 
 typedef struct vattn_config {
     uint32_t num_layers;          /* init_kvcache(num_layers, ...)   apis.h:3-13 */
@@ -74,6 +81,16 @@ typedef struct vattn_backend_ops {
      * ROCm 7.2 hipMemUnmap only waits for blocking streams (profiles/r01_vmm_sync_probe_raw.txt) — with compute on
      * a non-blocking stream an unmap could pull a page from under a running kernel (GPU memory fault).  May be NULL. */
     int (*quiesce)(void* ctx);
+    /* Free/total device memory in bytes; reserve_physical_pages refuses a pool the device cannot back (handles are created
+     * lazily, so without this an over-sized pool would only fail mid-serving).  May be NULL (no check). */
+    int (*mem_info)(void* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
+    /* Per-slot fences, replacing the device-wide quiesce where the engine cooperates: fence_record(slot, stream) is called by
+     * vattn_free_batch_idx_on_stream — it marks the point in `stream` after the last kernel that can read the slot's pages
+     * (stream == NULL clears the slot's fence); fence_wait(slot) is called before the first unmap of a freed slot's pages and
+     * returns 0 once that point has passed, 1 if the slot has no fence (the manager then falls back to quiesce), < 0 on
+     * error.  Both may be NULL. */
+    int (*fence_record)(void* ctx, uint32_t slot, void* stream);
+    int (*fence_wait)(void* ctx, uint32_t slot);
 } vattn_backend_ops;
 
 typedef struct vattn_layout {       /* element-unit description of every returned tensor */
@@ -97,6 +114,9 @@ typedef struct vattn_stats {
     uint64_t pages_mapped_now;            /* currently mapped physical pages */
     uint64_t tlb_flushes, tlb_flush_ns;
     uint64_t quiesce_calls, quiesce_ns;
+    uint64_t fence_waits, fence_wait_ns;  /* per-slot fences waited on instead of a device-wide quiesce */
+    uint64_t layered_batches, layer_wait_ns;   /* VATTN_FLAG_LAYERED_ASYNC: batches split by layer; time vattn_wait_layer blocked */
+    uint64_t rollbacks;                   /* batches whose unexecuted maps were rolled back after a driver failure */
 } vattn_stats;
 
 typedef struct vattn_handle vattn_t;
@@ -121,6 +141,15 @@ int vattn_wait(vattn_t* m);                                    /* join outstandi
 /* alloc_new_batch_idx / free_batch_idx / num_free_kvblocks (apis.h:53-63; vattention.cu:189-217,564-594) */
 int vattn_alloc_new_batch_idx(vattn_t* m, uint64_t seqlen);    /* slot, or -1 if none is free */
 int vattn_free_batch_idx(vattn_t* m, int slot);
+/* free_batch_idx + a fence on `stream` (a hipStream_t; the stream the iteration that last reads the slot was launched on):
+ * a later reclaim of the slot's pages waits for that point only instead of synchronising the whole device. */
+int vattn_free_batch_idx_on_stream(vattn_t* m, int slot, void* stream);
+/* VATTN_FLAG_LAYERED_ASYNC: block until the pages the current step needs are mapped for `layer` (returns at once when no
+ * layered batch is pending); VATTN_ERR_* if the mapper failed.  vattn_layers_ready: layers mapped so far (num_layers when
+ * nothing is pending).  vattn_set_sync_layers: layers mapped before step_async returns (default 2). */
+int vattn_wait_layer(vattn_t* m, uint32_t layer);
+uint32_t vattn_layers_ready(vattn_t* m);
+int vattn_set_sync_layers(vattn_t* m, uint32_t n);
 uint64_t vattn_num_free_kvblocks(vattn_t* m);                  /* u64 wrap-around kept (utils.h:177-183) */
 
 /* set_deferred_reclamation / set_verbose / map_common_pages / show_* (apis.h:15-21,37-51) */
@@ -145,6 +174,12 @@ int vattn_get_stats(vattn_t* m, vattn_stats* out);
  * current lengths, active slots]. */
 int vattn_get_counts(vattn_t* m, uint64_t out[4]);
 const char* vattn_last_error(const vattn_t* m);
+/* Remap / TLB self-check of the HIP VMM backend on `device` (what vattn_create runs once per device): maps page A at a
+ * virtual address, lets a kernel read it, unmaps, maps page B at the same address, applies the backend's TLB-invalidation
+ * policy and lets a kernel read again.  0 = the kernel sees B; 1 = STALE translation survived (vattn_create refuses to
+ * start: silent cross-request KV corruption); < 0 = driver error.  detail (may be NULL) = {value read before, value read
+ * after WITHOUT the flush, value read after the flush}. */
+int vattn_vmm_selfcheck(int device, uint32_t detail[3]);
 /* HIP VMM granularity probe for a device: 0 on success. */
 int vattn_hip_granularity(int device, uint64_t* min_gran, uint64_t* rec_gran);
 

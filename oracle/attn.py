@@ -84,32 +84,35 @@ def flash_attn_with_kvcache_ref(q: torch.Tensor, k_cache: torch.Tensor, v_cache:
         Lk = lens[b] + Sn                                          # block_info.h:22-23
         if Lk <= 0:
             continue
-        Kb = k_cache[idx[b], :Lk].to(wt)                           # [Lk,Hkv,D]
-        Vb = v_cache[idx[b], :Lk].to(wt)
-        # GQA: query head h uses kv head h // G   (flash_attn_interface.py:1189-1192)
-        Kh = Kb.permute(1, 0, 2).repeat_interleave(G, dim=0)       # [Hq,Lk,D]
-        Vh = Vb.permute(1, 0, 2).repeat_interleave(G, dim=0)
-        QB = 512                                                    # query rows per block (bounds memory only)
+        # GQA: query head h uses kv head h // G (flash_attn_interface.py:1189-1192).  The G query heads of a kv head are
+        # stacked along the row axis instead of repeating K/V G times (same arithmetic, 1/G of the memory).
+        Kh = k_cache[idx[b], :Lk].to(wt).permute(1, 0, 2)          # [Hkv,Lk,D]
+        Vh = v_cache[idx[b], :Lk].to(wt).permute(1, 0, 2)
+        QB = max(8, min(512, (1 << 27) // max(1, Hq * Lk)))         # query rows per block (bounds memory only)
         for q0 in range(0, Sq, QB):
             q1 = min(Sq, q0 + QB)
-            Qb = q[b, q0:q1].to(wt)                                 # [sq,Hq,D]
-            S = torch.matmul(Qb.permute(1, 0, 2), Kh.transpose(1, 2)) * softmax_scale   # [Hq,sq,Lk]
+            sq = q1 - q0
+            Qb = q[b, q0:q1].to(wt).reshape(sq, Hkv, G, D).permute(1, 2, 0, 3).reshape(Hkv, G * sq, D)
+            S = torch.matmul(Qb, Kh.transpose(1, 2)) * softmax_scale   # [Hkv,G*sq,Lk]
             if causal and Sq > 1:                                   # Sq==1: causal dropped (flash_api.cpp:1364)
-                i = torch.arange(q0, q1).view(-1, 1)
+                i = torch.arange(q0, q1).repeat(G).view(-1, 1)      # row r of the stack is query q0 + r % sq
                 j = torch.arange(Lk).view(1, Lk)
                 S = S.masked_fill(~(j <= i + (Lk - Sq)), float("-inf"))  # bottom-right aligned (mask.h:164-196)
             m = S.max(dim=-1, keepdim=True).values
             dead = torch.isinf(m) & (m < 0)                        # fully masked row -> output 0
             m = torch.where(dead, torch.zeros_like(m), m)
             P = torch.exp(S - m)
+            del S
             l = P.sum(dim=-1, keepdim=True)
             if math == "f32":
                 P = P.to(q.dtype).to(wt)                           # P rounded before PV
             O = torch.matmul(P, Vh) / torch.where(dead, torch.ones_like(l), l)
-            O = torch.where(dead, torch.zeros_like(O), O)
-            out[b, q0:q1] = O.permute(1, 0, 2)
-            row_lse = (m + torch.log(l)).squeeze(-1)
-            lse[b, :, q0:q1] = torch.where(dead.squeeze(-1), torch.full_like(row_lse, float("inf")), row_lse)
+            del P
+            O = torch.where(dead, torch.zeros_like(O), O)          # [Hkv,G*sq,D]
+            out[b, q0:q1] = O.view(Hkv, G, sq, D).permute(2, 0, 1, 3).reshape(sq, Hq, D)
+            row_lse = (m + torch.log(l)).squeeze(-1)               # [Hkv,G*sq]
+            row_lse = torch.where(dead.squeeze(-1), torch.full_like(row_lse, float("inf")), row_lse)
+            lse[b, :, q0:q1] = row_lse.view(Hq, sq)
     if math == "f32":
         out = out.to(q.dtype)
     return (out, lse) if return_lse else out

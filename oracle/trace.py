@@ -212,11 +212,11 @@ def replay(impl, ops: List[list], full: bool = False) -> List[dict]:
 class OracleImpl:
     """Adapter: oracle.pagemgr.PageManagerOracle behind the trace interface."""
 
-    def __init__(self, cfg: dict):
+    def __init__(self, cfg: dict, shared_page_refcount: bool = False):
         from oracle.pagemgr import PageManagerOracle
         self.o = PageManagerOracle(cfg["num_layers"], cfg["num_kv_heads"], cfg["head_size"],
                                    cfg["max_batch_size"], cfg["max_context_length"], cfg["itemsize"],
-                                   cfg["page_size"], cfg["megacache"])
+                                   cfg["page_size"], cfg["megacache"], shared_page_refcount=shared_page_refcount)
         for n in ("reserve_physical_pages", "alloc_new_batch_idx", "free_batch_idx", "step", "step_async",
                   "num_free_kvblocks", "set_deferred_reclamation", "map_common_pages", "cleanup"):
             setattr(self, n, getattr(self.o, n))

@@ -18,6 +18,9 @@ def fake():
         _fake.vattn_fake_mapped.restype = C.c_int64
         _fake.vattn_fake_mapped.argtypes = [C.POINTER(C.c_uint64), C.c_uint64]
         _fake.vattn_fake_fail_create_after.argtypes = [C.c_uint64]
+        _fake.vattn_fake_fail_map_after.argtypes = [C.c_uint64]
+        _fake.vattn_fake_quiesce_count.restype = C.c_uint64
+        _fake.vattn_fake_fence_wait_count.restype = C.c_uint64
     return _fake
 
 

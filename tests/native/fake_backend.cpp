@@ -23,7 +23,9 @@ struct Fake {
     uint64_t n_flush = 0, n_quiesce = 0;
     bool quiesced_since_map = true;     // set by quiesce, cleared by map: an unmap must see it set (or no map since)
     uint64_t violations = 0, n_create = 0, n_map = 0, n_access = 0, n_unmap = 0, n_release = 0;
-    uint64_t fail_create_after = ~0ull;
+    uint64_t fail_create_after = ~0ull, fail_map_after = ~0ull;
+    std::set<uint32_t> fences;                              // slots with a recorded fence
+    uint64_t n_fence_wait = 0;
     int delay_us = 0;
 };
 Fake g;
@@ -68,6 +70,7 @@ bool inside_reservation(uint64_t va, uint64_t bytes) {
 }
 int f_map(void*, uint64_t va, uint64_t bytes, uint64_t h) {
     std::lock_guard<std::mutex> l(g.mu);
+    if (g.n_map >= g.fail_map_after) return -1;            // injected driver failure (not a contract violation)
     g.n_map++;
     if (!inside_reservation(va, bytes) || !g.live_handles.count(h) || g.mapped.count(va) || va % g.min_gran) { g.violations++; return -1; }
     g.mapped[va] = {bytes, h};
@@ -89,7 +92,7 @@ int f_access(void*, uint64_t va, uint64_t bytes) {
 int f_unmap(void*, uint64_t va, uint64_t bytes) {
     std::lock_guard<std::mutex> l(g.mu);
     g.n_unmap++;
-    if (g.n_quiesce == 0) g.violations++;          // an unmap with no device synchronisation before it, ever
+    // (unmaps of a freed slot's pages must follow a fence wait or a quiesce; pages an ACTIVE slot no longer needs may go at once)
     auto it = g.mapped.find(va);
     if (it == g.mapped.end() || it->second.first != bytes) { g.violations++; return -1; }
     g.mapped.erase(it);
@@ -109,7 +112,19 @@ int f_flush(void*) {
     g.stale.clear();
     return 0;
 }
-vattn_backend_ops g_ops = {nullptr, f_gran, f_reserve, f_free_va, f_create, f_release, f_map, f_access, f_unmap, nullptr, f_flush, f_quiesce};
+int f_fence_record(void*, uint32_t slot, void* stream) {
+    std::lock_guard<std::mutex> l(g.mu);
+    if (stream) g.fences.insert(slot); else g.fences.erase(slot);
+    return 0;
+}
+int f_fence_wait(void*, uint32_t slot) {
+    std::lock_guard<std::mutex> l(g.mu);
+    if (!g.fences.count(slot)) return 1;
+    g.n_fence_wait++;
+    return 0;
+}
+vattn_backend_ops g_ops = {nullptr, f_gran, f_reserve, f_free_va, f_create, f_release, f_map, f_access, f_unmap, nullptr, f_flush, f_quiesce,
+                           nullptr, f_fence_record, f_fence_wait};
 }  // namespace
 
 extern "C" {
@@ -118,10 +133,14 @@ void vattn_fake_reset(uint64_t min_gran, uint64_t rec_gran) {
     std::lock_guard<std::mutex> l(g.mu);
     g.reserved.clear(); g.mapped.clear(); g.live_handles.clear(); g.accessible.clear(); g.stale.clear(); g.n_flush = 0; g.n_quiesce = 0;
     g.violations = g.n_create = g.n_map = g.n_access = g.n_unmap = g.n_release = 0;
-    g.next_handle = 1; g.next_va = 0x7f0000000000ull; g.fail_create_after = ~0ull;
+    g.next_handle = 1; g.next_va = 0x7f0000000000ull; g.fail_create_after = ~0ull; g.fail_map_after = ~0ull;
+    g.fences.clear(); g.n_fence_wait = 0;
     g.min_gran = min_gran; g.rec_gran = rec_gran;
 }
 void vattn_fake_fail_create_after(uint64_t n) { g.fail_create_after = n; }
+void vattn_fake_fail_map_after(uint64_t n) { g.fail_map_after = n; }     // the (n+1)-th map call from now on the counter fails
+uint64_t vattn_fake_quiesce_count() { return g.n_quiesce; }
+uint64_t vattn_fake_fence_wait_count() { return g.n_fence_wait; }
 // out = [violations, n_create, n_map, n_access, n_unmap, n_release, live_handles, mapped_pages, accessible_pages, reserved_ranges,
 //        n_flush, stale_vas (unmapped since the last flush)]
 void vattn_fake_counters(uint64_t* out) {

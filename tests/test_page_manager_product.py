@@ -21,8 +21,15 @@ def test_product_matches_reference_golden(path, flags):
     for tr in g["traces"]:
         impl = ProductImpl(cfg, flags=flags)
         got = T.replay(impl, tr["ops"], full=True)
+        seen_common = False
         for i, (a, b) in enumerate(zip(got, tr["expect"])):
+            seen_common |= tr["ops"][i][0] == "map_common"
             for k in KEYS:
+                if k == "ret" and seen_common and tr["ops"][i][0] == "nfree":
+                    # deliberate fix: a page-group aliased into B slots is ONE group of physical pages; the reference counts it
+                    # B times (utils.h:177-183 sums mapped - needed per slot); see test_shared_prefix_pages_are_refcounted
+                    assert a[k] <= b[k]
+                    continue
                 assert a[k] == b[k], "trace %s/%s op %d %s key %s" % (tr["kind"], tr["seed"], i, tr["ops"][i][:1], k)
         c = fake_counters()
         assert c["violations"] == 0
@@ -166,3 +173,206 @@ def test_lifecycle_cleanup_twice_use_after_cleanup_destroy_with_pending_work(fla
     q.pm.close()                                       # vattn_destroy without cleanup(): must join, unmap, release, free
     c = fake_counters()
     assert c["violations"] == 0 and c["live_handles"] == 0 and c["mapped_pages"] == 0 and c["reserved_ranges"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: prefix-sharing refcounts, rollback after a driver failure, per-slot fences, layer-ordered mapping
+# ---------------------------------------------------------------------------------------------------------------------
+SHARE_CFG = dict(num_layers=2, num_kv_heads=2, head_size=128, max_batch_size=4, max_context_length=2048, itemsize=2,
+                 page_size=32 << 10, megacache=False)          # 64 tokens per page
+
+
+def test_shared_prefix_pages_are_refcounted():
+    """map_common_pages aliases ONE physical pair per layer into every slot (vattention.cu:325-373).  The reference returns
+    such a page to the pool once per slot when slots are reclaimed (mux.h:51-66): duplicate ids in the LIFO pool, i.e. the same
+    physical page handed to two different (slot, layer) ranges later.  The product keeps a per-page refcount: the page goes back
+    exactly once, when its last mapping is unmapped, and num_free_kvblocks counts the shared group once."""
+    from tests.impls import fake_mapped
+    cfg = SHARE_CFG
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    # the reference's behaviour, restated by the oracle: duplicates
+    ref = T.OracleImpl(cfg)
+    ref.reserve_physical_pages(10 * group)
+    ref.map_common_pages(100)                       # 2 page-groups shared by all 4 slots
+    ref.step([0, 0, 0, 0], True)                    # eager reclaim of every slot
+    assert len(ref.o.pool) > len(set(ref.o.pool))   # the reference bug this test documents
+
+    p = ProductImpl(cfg, flags=4)
+    o = T.OracleImpl(cfg, shared_page_refcount=True)
+    for impl in (p, o):
+        impl.reserve_physical_pages(10 * group)
+        impl.map_common_pages(100)
+    st = p.pm.state()
+    assert st["mapped"] == [2, 2, 2, 2] and st["pool"] == 10 * 4 - 2 * 4
+    assert p.num_free_kvblocks() == o.num_free_kvblocks() == 8 + 2      # 8 pool groups + the 2 shared ones, ONCE each
+    assert len({h for _va, _n, h, _a in fake_mapped()}) == 8               # 8 physical pages behind 32 mappings
+    # a request that covers the prefix pins it: nothing of the shared groups is free-able
+    s = p.alloc_new_batch_idx(150)
+    assert s == o.alloc_new_batch_idx(150) == 0
+    lens = [150, 0, 0, 0]
+    p.step(lens, False); o.step(lens, False)
+    assert p.num_free_kvblocks() == o.num_free_kvblocks() == 7           # one exclusive group mapped for tokens 128..149
+    # eager reclaim of the idle slots drops 3 of the 4 mappings of every shared page: nothing returns to the pool yet
+    p.step(lens, True); o.step(lens, True)
+    st = p.pm.state()
+    assert st["mapped"] == [3, 0, 0, 0] and st["pool"] == o.snapshot()["pool"] == 7 * 4
+    assert len(st["pool_ids"]) == len(set(st["pool_ids"]))
+    # last holder goes: the shared pages return, exactly once
+    p.free_batch_idx(0); o.free_batch_idx(0)
+    p.step([0, 0, 0, 0], True); o.step([0, 0, 0, 0], True)
+    st = p.pm.state()
+    assert st["mapped"] == [0, 0, 0, 0] and st["pool"] == 10 * 4
+    assert sorted(st["pool_ids"]) == list(range(40))                      # every id once
+    assert p.snapshot(True)["pool_handles"] == o.snapshot(True)["pool_handles"]
+    c = fake_counters()
+    assert c["violations"] == 0 and c["mapped_pages"] == 0 and c["stale_vas"] == 0
+    p.pm.cleanup(); p.pm.close()
+
+
+@pytest.mark.parametrize("flags", [4, 0], ids=["inline", "mapper_thread"])
+@pytest.mark.parametrize("fail_after", [0, 3, 5, 9])
+def test_failed_map_is_rolled_back(flags, fail_after):
+    """A hipMemMap / hipMemCreate that fails mid-batch (the reference: exit(1), cudaInternal.h:1-13) must leave bookkeeping equal
+    to the driver state: the page-groups that did not get all their pages are taken back, the error is reported, and the
+    manager keeps working."""
+    from tests.impls import fake, fake_mapped
+    cfg = dict(SHARE_CFG, num_layers=3)
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    p = ProductImpl(cfg, flags=flags)
+    p.reserve_physical_pages(12 * group)
+    s0 = p.alloc_new_batch_idx(64)
+    lens = [0] * 4
+    lens[s0] = 64
+    p.step_async(lens)                                   # one group mapped (+ look-ahead)
+    p.pm.wait()
+    before = p.pm.state()
+    n_before = len(fake_mapped())
+    fake().vattn_fake_fail_map_after(fake_counters()["n_map"] + fail_after)
+    s1 = p.alloc_new_batch_idx(200)                      # needs 4 groups = 24 map calls
+    lens[s1] = 200
+    with pytest.raises(RuntimeError, match="hipMemMap failed"):
+        p.step_async(lens)
+    fake().vattn_fake_fail_map_after(1 << 62)
+    st = p.pm.state()
+    whole_groups = fail_after // 6                       # groups that were complete before the failing call
+    assert st["mapped"][s1] == whole_groups and st["mapped"][s0] == before["mapped"][s0]
+    assert st["pool"] == before["pool"] - whole_groups * 6
+    assert len(st["pool_ids"]) == len(set(st["pool_ids"]))
+    assert len(fake_mapped()) == n_before + whole_groups * 6          # driver state == bookkeeping
+    assert p.pm.stats()["rollbacks"] == 1
+    p.step_async(lens)                                   # the same request now goes through
+    p.pm.wait()
+    assert p.pm.state()["mapped"][s1] >= 4
+    assert p.mapped_ranges() is not None and fake_counters()["violations"] == 0
+    p.pm.cleanup(); p.pm.close()
+    c = fake_counters()
+    assert c["mapped_pages"] == 0 and c["live_handles"] == 0
+
+
+def test_background_map_failure_is_reported_once_and_rolled_back():
+    from tests.impls import fake, fake_mapped
+    cfg = SHARE_CFG
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    p = ProductImpl(cfg, flags=0)
+    p.reserve_physical_pages(12 * group)
+    s = p.alloc_new_batch_idx(63)
+    lens = [0] * 4
+    lens[s] = 63
+    fake().vattn_fake_fail_map_after(fake_counters()["n_map"] + 4 + 1)   # the sync group (4 maps) passes, the look-ahead fails
+    p.step_async(lens)            # the look-ahead (tokens 64.. need a second group) is planned for the mapper
+    with pytest.raises(RuntimeError, match="hipMemMap failed"):
+        p.pm.wait()
+    fake().vattn_fake_fail_map_after(1 << 62)
+    st = p.pm.state()
+    assert st["mapped"][s] == 1 and len(fake_mapped()) == 4 and st["pool"] == 12 * 4 - 4
+    p.pm.wait()                   # reported once
+    p.step_async(lens)
+    p.pm.wait()
+    assert p.pm.state()["mapped"][s] == 2
+    p.pm.cleanup(); p.pm.close()
+
+
+def test_slot_fences_replace_the_device_wide_quiesce():
+    """Unmapping a FREED slot's pages must wait for the kernels launched before the free.  With a fence recorded by
+    free_batch_idx_on_stream only that point is waited for; a plain free falls back to one device-wide quiesce per batch; pages
+    an ACTIVE slot merely no longer needs are unmapped without any wait."""
+    from tests.impls import fake
+    f = fake()
+    f.vattn_fake_quiesce_count.restype = f.vattn_fake_fence_wait_count.restype = __import__("ctypes").c_uint64
+    cfg = SHARE_CFG
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    p = ProductImpl(cfg, flags=4)
+    p.reserve_physical_pages(8 * group)
+    a = p.alloc_new_batch_idx(300); b = p.alloc_new_batch_idx(100)
+    lens = [0] * 4
+    lens[a], lens[b] = 300, 100
+    p.step(lens, True)
+    q0, w0 = f.vattn_fake_quiesce_count(), f.vattn_fake_fence_wait_count()
+    p.pm.free_batch_idx(a, stream=0x1234)               # engine frees slot a on its compute stream
+    lens[a] = 0
+    p.step(lens, True)                                  # eager reclaim of slot a: fence wait, no quiesce
+    assert f.vattn_fake_fence_wait_count() == w0 + 1 and f.vattn_fake_quiesce_count() == q0
+    assert p.pm.stats()["fence_waits"] == 1 and p.pm.stats()["quiesce_calls"] == 0
+    p.pm.free_batch_idx(b)                              # plain free: no fence -> quiesce fallback
+    lens[b] = 0
+    p.step(lens, True)
+    assert f.vattn_fake_quiesce_count() == q0 + 1
+    # an active slot shrunk by on-demand reclaim: no wait at all
+    c_ = p.alloc_new_batch_idx(500)
+    lens[c_] = 500
+    p.step(lens, False)
+    lens[c_] = 100                                      # (a restarted request) 8 groups mapped, 2 needed
+    d = p.alloc_new_batch_idx(300)
+    lens[d] = 300                                       # needs 5 groups, the pool has none left: reclaim from the active slot c_
+    q1, w1 = f.vattn_fake_quiesce_count(), f.vattn_fake_fence_wait_count()
+    p.step(lens, False)
+    assert p.pm.state()["mapped"][c_] == 2 and p.pm.state()["mapped"][d] == 5
+    assert f.vattn_fake_quiesce_count() == q1 and f.vattn_fake_fence_wait_count() == w1
+    assert fake_counters()["violations"] == 0 and fake_counters()["stale_vas"] == 0
+    p.pm.cleanup(); p.pm.close()
+
+
+def test_layer_ordered_async_mapping():
+    """VATTN_FLAG_LAYERED_ASYNC: step_async returns once layers [0, sync_layers) of a new prompt's pages are mapped; the mapper
+    maps the remaining layers in order and wait_layer(l) gates layer l.  End state identical to the plain path."""
+    import threading
+    from vattention_amd import _lib as L
+    cfg = dict(num_layers=8, num_kv_heads=2, head_size=128, max_batch_size=4, max_context_length=4096, itemsize=2,
+               page_size=32 << 10, megacache=False)          # 64 tokens per page
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    ref = ProductImpl(cfg, flags=0)
+    ref.reserve_physical_pages(40 * group)
+    s = ref.alloc_new_batch_idx(1000)
+    lens = [0] * 4
+    lens[s] = 1000
+    ref.step_async(lens); ref.pm.wait()
+    want_state, want_ranges = ref.pm.state(), ref.mapped_ranges()
+    want_maps = ref.pm.stats()["map_calls"]
+    ref.pm.cleanup(); ref.pm.close()
+
+    p = ProductImpl(cfg, flags=L.FLAG_LAYERED_ASYNC)
+    p.pm.set_sync_layers(2)
+    p.reserve_physical_pages(40 * group)
+    assert p.alloc_new_batch_idx(1000) == s
+    p.step_async(lens)
+    st = p.pm.stats()
+    assert st["layered_batches"] == 1
+    seen = []
+    for layer in range(cfg["num_layers"]):
+        p.pm.wait_layer(layer)
+        assert p.pm.layers_ready() > layer
+        seen.append(p.pm.layers_ready())
+    assert seen == sorted(seen)
+    p.pm.wait()
+    assert p.pm.layers_ready() == cfg["num_layers"]
+    assert p.pm.state() == want_state and p.mapped_ranges() == want_ranges
+    st = p.pm.stats()
+    assert st["map_calls"] == want_maps
+    # the synchronous share is sync_layers / num_layers of the prompt's maps (16 groups x 2 layers x 2 tensors)
+    assert st["sync_batches"] == 1 and st["async_batches"] >= 1
+    assert fake_counters()["violations"] == 0
+    # a second, small step (one page-group) stays on the plain path
+    lens[s] = 1030
+    p.step_async(lens); p.pm.wait()
+    assert p.pm.stats()["layered_batches"] == 1
+    p.pm.cleanup(); p.pm.close()

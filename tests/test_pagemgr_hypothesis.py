@@ -30,7 +30,7 @@ MEGA = dict(CFG, megacache=True, num_layers=4)           # 16 tokens per page, 6
 def test_any_call_sequence_matches_oracle(ops, flags, mega):
     ops = [list(o) for o in ops] + [["cleanup"]]
     cfg = MEGA if mega else CFG
-    o = T.OracleImpl(cfg)
+    o = T.OracleImpl(cfg, shared_page_refcount=True)     # the product's prefix-sharing fix (see oracle/pagemgr.py)
     p = ProductImpl(cfg, flags=flags)
     try:
         for op in ops:

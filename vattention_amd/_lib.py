@@ -27,11 +27,12 @@ class VattnLayout(C.Structure):
 class VattnStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("handles_created", "handles_released", "map_calls", "access_calls",
                                            "unmap_calls", "sync_batches", "async_batches", "sync_ns", "async_ns",
-                                           "join_wait_ns", "create_ns", "pages_mapped_now", "tlb_flushes", "tlb_flush_ns", "quiesce_calls", "quiesce_ns")]
+                                           "join_wait_ns", "create_ns", "pages_mapped_now", "tlb_flushes", "tlb_flush_ns", "quiesce_calls", "quiesce_ns",
+                                           "fence_waits", "fence_wait_ns", "layered_batches", "layer_wait_ns", "rollbacks")]
 
 
 VATTN_OK, VATTN_ERR_INVALID, VATTN_ERR_OOM, VATTN_ERR_DRIVER, VATTN_ERR_POOL_EMPTY = 0, -1, -2, -3, -4
-FLAG_EAGER_CREATE, FLAG_NO_ACCESS_MERGE, FLAG_NO_MAPPER_THREAD = 1, 2, 4
+FLAG_EAGER_CREATE, FLAG_NO_ACCESS_MERGE, FLAG_NO_MAPPER_THREAD, FLAG_LAYERED_ASYNC, FLAG_NO_VMM_SELFCHECK = 1, 2, 4, 8, 16
 
 _lib = None
 
@@ -58,6 +59,11 @@ def lib() -> C.CDLL:
         "vattn_wait": (i32, [vp]),
         "vattn_alloc_new_batch_idx": (i32, [vp, u64]),
         "vattn_free_batch_idx": (i32, [vp, i32]),
+        "vattn_free_batch_idx_on_stream": (i32, [vp, i32, vp]),
+        "vattn_wait_layer": (i32, [vp, u32]),
+        "vattn_layers_ready": (u32, [vp]),
+        "vattn_set_sync_layers": (i32, [vp, u32]),
+        "vattn_vmm_selfcheck": (i32, [i32, C.POINTER(u32)]),
         "vattn_num_free_kvblocks": (u64, [vp]),
         "vattn_set_deferred_reclamation": (i32, [vp, i32]),
         "vattn_set_verbose": (i32, [vp, i32]),

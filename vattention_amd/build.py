@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "vattention_amd")
 CSRC = os.path.join(PKG, "csrc")
 ARCH = "gfx950"
-LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "attn_api.hip", "prefill_kernels.hip", "decode_kernels.hip",
+LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "vmm_selfcheck.hip", "attn_api.hip", "prefill_kernels.hip", "decode_kernels.hip",
                "cache_kernels.hip")
 
 

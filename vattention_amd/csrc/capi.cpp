@@ -1,10 +1,13 @@
 // extern "C" surface of libvattn_amd.so for the page manager (include/vattn.h).
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "page_manager.h"
 
 namespace vattn {
 int make_hip_backend(int device, vattn_backend_ops* ops);
+int hip_vmm_selfcheck(int device, const vattn_backend_ops* ops, uint32_t detail[3]);   // vmm_selfcheck.hip
 }
 
 struct vattn_handle {
@@ -28,6 +31,24 @@ int vattn_create(const vattn_config* cfg, const vattn_backend_ops* backend, vatt
     auto* h = new (std::nothrow) vattn_handle();
     if (!h) return VATTN_ERR_INVALID;
     h->pm = new vattn::PageManager(*cfg, ops);
+    if (!backend && !(cfg->flags & VATTN_FLAG_NO_VMM_SELFCHECK)) {
+        // Unmap safety rests on the backend's TLB-invalidation policy (hip_backend.cpp): prove once per device and process
+        // that a kernel sees the NEW page after unmap + map at the same address, and refuse to serve otherwise.
+        static std::mutex mu;
+        static std::map<int, int> verdict;
+        std::lock_guard<std::mutex> l(mu);
+        auto it = verdict.find(cfg->device);
+        if (it == verdict.end()) it = verdict.emplace(cfg->device, vattn::hip_vmm_selfcheck(cfg->device, &ops, nullptr)).first;
+        if (it->second != 0) {
+            h->pm->set_error(it->second > 0
+                ? "HIP VMM self-check failed: a kernel still reads the OLD physical page after hipMemUnmap + hipMemMap at the same "
+                  "virtual address, even after the TLB-invalidation step — refusing to start (reclaimed KV pages would leak between "
+                  "requests).  Verified on ROCm 7.2 / gfx950; set VATTN_FLAG_NO_VMM_SELFCHECK only to debug."
+                : "HIP VMM self-check could not run (driver error)");
+            *out = h;
+            return VATTN_ERR_DRIVER;
+        }
+    }
     int rc = h->pm->init();
     *out = h;            // returned even on failure so the caller can read vattn_last_error()
     return rc;
@@ -44,6 +65,10 @@ int vattn_step_async(vattn_t* m, const uint64_t* l, uint32_t n) { return m->pm->
 int vattn_wait(vattn_t* m) { return m->pm->wait(); }
 int vattn_alloc_new_batch_idx(vattn_t* m, uint64_t seqlen) { return m->pm->alloc_new_batch_idx(seqlen); }
 int vattn_free_batch_idx(vattn_t* m, int slot) { return m->pm->free_batch_idx(slot); }
+int vattn_free_batch_idx_on_stream(vattn_t* m, int slot, void* stream) { return m->pm->free_batch_idx(slot, stream, true); }
+int vattn_wait_layer(vattn_t* m, uint32_t layer) { return m->pm->wait_layer(layer); }
+uint32_t vattn_layers_ready(vattn_t* m) { return m->pm->layers_ready(); }
+int vattn_set_sync_layers(vattn_t* m, uint32_t n) { return m->pm->set_sync_layers(n); }
 uint64_t vattn_num_free_kvblocks(vattn_t* m) { return m->pm->num_free_kvblocks(); }
 int vattn_set_deferred_reclamation(vattn_t* m, int on) { return m->pm->set_deferred_reclamation(on != 0); }
 int vattn_set_verbose(vattn_t* m, int on) { return m->pm->set_verbose(on != 0); }
@@ -61,6 +86,12 @@ int64_t vattn_pagemap_dump(vattn_t* m, uint64_t* out, uint64_t cap_rows) { retur
 int vattn_get_stats(vattn_t* m, vattn_stats* out) { m->pm->stats(out); return VATTN_OK; }
 int vattn_get_counts(vattn_t* m, uint64_t out[4]) { m->pm->counts(out); return VATTN_OK; }
 const char* vattn_last_error(const vattn_t* m) { return m ? m->pm->last_error() : "null handle"; }
+
+int vattn_vmm_selfcheck(int device, uint32_t detail[3]) {
+    vattn_backend_ops ops;
+    if (vattn::make_hip_backend(device, &ops) != 0) return VATTN_ERR_DRIVER;
+    return vattn::hip_vmm_selfcheck(device, &ops, detail);
+}
 
 int vattn_hip_granularity(int device, uint64_t* mn, uint64_t* rec) {
     vattn_backend_ops ops;

@@ -18,8 +18,14 @@ struct HipCtx {
     hipMemAllocationProp prop;
     hipMemAccessDesc access;
     std::vector<void*> flush_allocs;     // see h_tlb_flush
+    std::vector<hipEvent_t> fences;      // per request slot: recorded by free_batch_idx_on_stream, see h_fence_*
+    std::vector<uint8_t> fence_set;
     std::mutex mu;
 };
+// device memory the TLB-invalidation probes may hold at any time (kFlushPark parked 2 MiB allocations); reserve_physical_pages
+// sizes the pool against free memory MINUS this, so the probe's hipMalloc cannot fail because the KV pool took everything
+constexpr size_t kFlushBytes = 2u << 20;
+constexpr size_t kFlushPark = 32;
 
 static int hip_fail(const char* what, hipError_t e) {
     fprintf(stderr, "[vattn] %s failed: %s (%d)\n", what, hipGetErrorString(e), (int)e);
@@ -95,21 +101,79 @@ static int h_unmap(void*, uint64_t va, uint64_t bytes) {
 static int h_tlb_flush(void* c) {
     auto* x = (HipCtx*)c;
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, 2u << 20);
-    if (e != hipSuccess) return hip_fail("hipMalloc (TLB invalidation probe)", e);
+    hipError_t e = hipMalloc(&p, kFlushBytes);
+    if (e != hipSuccess) {
+        // memory pressure: give the parked probes back and try once more (their budget is excluded from the KV pool, h_mem_info)
+        (void)hipGetLastError();
+        std::vector<void*> parked;
+        {
+            std::lock_guard<std::mutex> l(x->mu);
+            parked.swap(x->flush_allocs);
+        }
+        for (void* q : parked) (void)hipFree(q);
+        e = hipMalloc(&p, kFlushBytes);
+        if (e != hipSuccess) return hip_fail("hipMalloc (TLB invalidation probe)", e);
+    }
     std::vector<void*> drop;
     {
         std::lock_guard<std::mutex> l(x->mu);
         x->flush_allocs.push_back(p);
-        if (x->flush_allocs.size() >= 32) drop.swap(x->flush_allocs);
+        if (x->flush_allocs.size() >= kFlushPark) drop.swap(x->flush_allocs);
     }
-    for (void* q : drop) (void)hipFree(q);
+    for (void* q : drop) (void)hipFree(q);     // hipFree synchronises the device: once per kFlushPark unmapping batches
     return 0;
 }
 
 static int h_quiesce(void*) {
     hipError_t e = hipDeviceSynchronize();
     return e == hipSuccess ? 0 : hip_fail("hipDeviceSynchronize", e);
+}
+
+static int h_mem_info(void* c, uint64_t* free_b, uint64_t* total_b) {
+    (void)c;
+    size_t f = 0, t = 0;
+    hipError_t e = hipMemGetInfo(&f, &t);
+    if (e != hipSuccess) return hip_fail("hipMemGetInfo", e);
+    const size_t budget = kFlushBytes * kFlushPark;
+    *free_b = f > budget ? f - budget : 0;
+    *total_b = t;
+    return 0;
+}
+
+// Per-slot fences.  The engine frees a slot right after LAUNCHING the iteration that last reads its pages; an event recorded
+// on that stream at free time marks the point after which the pages may be unmapped.  Waiting for it replaces the
+// device-wide synchronisation before unmaps whenever the engine goes through vattn_free_batch_idx_on_stream.
+static int h_fence_record(void* c, uint32_t slot, void* stream) {
+    auto* x = (HipCtx*)c;
+    std::lock_guard<std::mutex> l(x->mu);
+    if (x->fences.size() <= slot) {
+        x->fences.resize((size_t)slot + 1, nullptr);
+        x->fence_set.resize((size_t)slot + 1, 0);
+    }
+    if (!stream && !x->fence_set[slot]) return 0;
+    x->fence_set[slot] = 0;
+    if (!stream) return 0;                     // plain free: forget the fence (a reclaim falls back to quiesce)
+    if (!x->fences[slot]) {
+        hipError_t e = hipEventCreateWithFlags(&x->fences[slot], hipEventDisableTiming);
+        if (e != hipSuccess) return hip_fail("hipEventCreateWithFlags", e);
+    }
+    // (void*)-1 stands for the legacy default stream (NULL means "no fence" in the ops table)
+    hipStream_t st = stream == (void*)-1 ? nullptr : (hipStream_t)stream;
+    hipError_t e = hipEventRecord(x->fences[slot], st);
+    if (e != hipSuccess) return hip_fail("hipEventRecord", e);
+    x->fence_set[slot] = 1;
+    return 0;
+}
+static int h_fence_wait(void* c, uint32_t slot) {
+    auto* x = (HipCtx*)c;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> l(x->mu);
+        if (slot >= x->fences.size() || !x->fence_set[slot]) return 1;
+        ev = x->fences[slot];
+    }
+    hipError_t e = hipEventSynchronize(ev);
+    return e == hipSuccess ? 0 : hip_fail("hipEventSynchronize", e);
 }
 
 // Fills `ops` with the HIP VMM table for `device`; the context object lives for the process.
@@ -140,6 +204,9 @@ int make_hip_backend(int device, vattn_backend_ops* ops) {
     ops->thread_init = h_thread_init;
     ops->tlb_flush = h_tlb_flush;
     ops->quiesce = h_quiesce;
+    ops->mem_info = h_mem_info;
+    ops->fence_record = h_fence_record;
+    ops->fence_wait = h_fence_wait;
     return 0;
 }
 

@@ -13,7 +13,6 @@ namespace vattn {
 namespace {
 constexpr uint64_t kEagerNumSteps = 10;    // vattention.cu:484
 constexpr uint64_t kEagerNumKvBlocks = 2;  // vattention.cu:485
-constexpr uint64_t kPrecreateSlice = 16;   // handles created per idle slice of the mapper thread
 // hipMemCreate is O(live handles) on ROCm 7.2 (9 us at 5 k handles, 106 us at 20 k, 382 us at 50 k, 931 us at 100 k:
 // profiles/r01_vmm_scale_probe.txt), so materialising a whole pool up front is quadratic.  The idle mapper thread keeps
 // PageManager::kPrecreateAheadPages handles created BELOW the lowest page id the pool has handed out so far (a window that
@@ -127,8 +126,28 @@ uint64_t PageManager::need_new_page_async(int r, uint64_t eager) const {   // ut
 
 void PageManager::note_popped(uint32_t lowest) {     // state_mu_ held
     if (lowest < frontier_.load(std::memory_order_relaxed)) {
-        frontier_.store(lowest, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> q(q_mu_);   // the mapper evaluates its wake-up predicate under q_mu_: no lost wake-up
+            frontier_.store(lowest, std::memory_order_relaxed);
+        }
         q_cv_.notify_one();        // the window slid down: the idle mapper may create more handles
+    }
+}
+
+void PageManager::drop_mapping(uint32_t page) {      // state_mu_ held
+    if (refcnt_[page] > 0) refcnt_[page]--;
+    if (refcnt_[page] == 0) pool_.push_back(page);
+}
+
+void PageManager::forget_shared_holder(int r, uint64_t pos) {
+    for (size_t i = 0; i < shared_.size(); i++) {
+        auto& h = shared_[i].holders;
+        for (size_t j = 0; j < h.size(); j++)
+            if (h[j].first == (uint32_t)r && h[j].second == pos) {
+                h.erase(h.begin() + j);
+                if (h.empty()) shared_.erase(shared_.begin() + i);
+                return;
+            }
     }
 }
 
@@ -137,20 +156,25 @@ int PageManager::plan_map_pair(int r, uint32_t layer, uint64_t off) {      // mu
     const uint32_t k = pool_.back(); pool_.pop_back();
     const uint32_t v = pool_.back(); pool_.pop_back();
     note_popped(k < v ? k : v);
-    plan_.push_back({0, k_tensor(layer), k, off});
-    plan_.push_back({0, v_tensor(layer), v, off});
+    refcnt_[k] = refcnt_[v] = 1;
+    plan_.push_back({0, 0, (uint16_t)r, (uint16_t)layer, k_tensor(layer), k, off});
+    plan_.push_back({0, 0, (uint16_t)r, (uint16_t)layer, v_tensor(layer), v, off});
     pagemap_[std::make_tuple((uint64_t)r, off, (uint64_t)layer)] = std::make_pair(k, v);
     return VATTN_OK;
 }
 
 void PageManager::plan_unmap_pair(int r, uint32_t layer, uint64_t off) {   // mux.h:51-66
-    plan_.push_back({1, k_tensor(layer), 0, off});
-    plan_.push_back({1, v_tensor(layer), 0, off});
+    // a FREED slot's pages may still be read by kernels launched before the free: fence (or quiesce) before the unmap; an
+    // ACTIVE slot is only ever shrunk to the pages its current length needs, which no kernel in flight reads beyond
+    const uint8_t fence = active(r) ? 0 : 1;
     auto key = std::make_tuple((uint64_t)r, off, (uint64_t)layer);
     auto it = pagemap_.find(key);
+    const uint32_t k = it != pagemap_.end() ? it->second.first : 0, v = it != pagemap_.end() ? it->second.second : 0;
+    plan_.push_back({1, fence, (uint16_t)r, (uint16_t)layer, k_tensor(layer), k, off});
+    plan_.push_back({1, fence, (uint16_t)r, (uint16_t)layer, v_tensor(layer), v, off});
     if (it != pagemap_.end()) {
-        pool_.push_back(it->second.first);      // K first, then V
-        pool_.push_back(it->second.second);
+        drop_mapping(k);                        // K first, then V; a shared page only when its last mapping goes
+        drop_mapping(v);
         pagemap_.erase(it);
     }
 }
@@ -163,6 +187,7 @@ void PageManager::unmap_req_page_one(int r) {    // vattention.cu:219-241, utils
         for (uint32_t l = 0; l < cfg_.num_layers; l++) plan_unmap_pair(r, l, off);
     }
     mapped_pages_[r]--;
+    if (!shared_.empty()) forget_shared_holder(r, mapped_pages_[r]);
 }
 
 void PageManager::release_some(int r, uint64_t retain) {   // vattention.cu:243-247
@@ -265,6 +290,23 @@ int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInt
     uint64_t n = free_memory / cfg_.page_size;
     n -= n % (2ull * cfg_.num_layers);            // multiple of 2*L even in megacache mode
     if (n > 0xFFFFFFF0ull) return fail(VATTN_ERR_INVALID, "page count exceeds 32-bit page ids");
+    if (fatal_.load()) return fail(fatal_.load(), last_error_);
+    if (be_.mem_info && n > pool_.size()) {
+        // The reference commits the memory here (cuMemCreate per page, cudaInternal.h:45-59).  Handles are created lazily in
+        // this design, so refuse up front what the device could not back: a pool that only fails mid-serving is worse.
+        uint64_t free_b = 0, total_b = 0;
+        if (be_.mem_info(be_.ctx, &free_b, &total_b) == 0) {
+            uint64_t uncreated = 0;
+            for (uint32_t id : pool_) uncreated += created_[id] ? 0 : 1;
+            const uint64_t want = (n - pool_.size() + uncreated) * cfg_.page_size;
+            if (want > free_b) {
+                std::ostringstream ss;
+                ss << "reserve_physical_pages: " << want << " bytes of physical pages requested but only " << free_b
+                   << " bytes of device memory are free (of " << total_b << ")";
+                return fail(VATTN_ERR_OOM, ss.str());
+            }
+        }
+    }
     if (n > 100000 && be_.tlb_flush) {            // a real (HIP) backend: creation cost grows with the number of live handles
         std::cerr << "[vattn] warning: " << n << " physical pages of " << (cfg_.page_size >> 10) << " KiB = one hipMemCreate handle each; "
                   << "handle creation on ROCm is O(live handles) (about 1 ms per call beyond 100 k, DESIGN.md section 3): prefer larger pages"
@@ -277,6 +319,7 @@ int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInt
             pool_.push_back(id);
             handles_.push_back(0);
             created_.push_back(0);
+            refcnt_.push_back(0);
         }
     }
     if (cfg_.flags & VATTN_FLAG_EAGER_CREATE) {
@@ -301,6 +344,7 @@ int PageManager::step(const uint64_t* lens, uint32_t n, bool eager_reclaim) {   
     std::lock_guard<std::mutex> l(state_mu_);
     if (!inited_ || cleaned_) return fail(VATTN_ERR_INVALID, "allocator is not initialised");
     if (n != cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "seq_lens must have max_batch_size entries");
+    if (fatal_.load()) return fail(fatal_.load(), last_error_);
     int rc = wait_locked_free();
     if (rc) return rc;
     int err = VATTN_OK;
@@ -321,6 +365,7 @@ int PageManager::step_async(const uint64_t* lens, uint32_t n) {   // vattention.
     std::lock_guard<std::mutex> l(state_mu_);
     if (!inited_ || cleaned_) return fail(VATTN_ERR_INVALID, "allocator is not initialised");
     if (n != cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "seq_lens must have max_batch_size entries");
+    if (fatal_.load()) return fail(fatal_.load(), last_error_);
     lens_.assign(lens, lens + n);                       // utils.h:155-158
     int rc = wait_locked_free();                        // wait_kvcache_manager_sync
     if (rc) return rc;
@@ -329,11 +374,79 @@ int PageManager::step_async(const uint64_t* lens, uint32_t n) {   // vattention.
         err = map_pages_for_curr_step(r, lens_[r]);
         if (err) break;
     }
-    rc = flush_sync();
-    if (err) return err;
-    if (rc) return rc;
+    // VATTN_FLAG_LAYERED_ASYNC: what this step needs is split by layer — layers [0, sync_layers) are mapped before the
+    // call returns, the rest by the mapper in layer order while those layers already run (vattn_wait_layer gates each
+    // layer's kernels).  Only pure-map plans of a worthwhile size; plans that unmap stay synchronous.
+    bool layered = false;
+    if (!err && (cfg_.flags & VATTN_FLAG_LAYERED_ASYNC) && !(cfg_.flags & VATTN_FLAG_NO_MAPPER_THREAD) && !cfg_.megacache &&
+        cfg_.num_layers > sync_layers_ && plan_.size() >= 4ull * cfg_.num_layers) {
+        layered = true;
+        for (const PhysOp& op : plan_)
+            if (op.kind != 0) { layered = false; break; }
+    }
+    if (layered) {
+        std::vector<PhysOp> now, later;
+        for (const PhysOp& op : plan_) (op.layer < sync_layers_ ? now : later).push_back(op);
+        std::stable_sort(later.begin(), later.end(), [](const PhysOp& a, const PhysOp& b) { return a.layer < b.layer; });
+        plan_.clear();
+        size_t failed_at = now.size();
+        {
+            fg_waiting_.fetch_add(1);
+            std::lock_guard<std::mutex> e(exec_mu_);
+            fg_waiting_.fetch_sub(1);
+            rc = execute(now, false, &failed_at);
+            if (!rc) st_.layered_batches++;
+        }
+        if (rc) {                                        // the synchronous layers failed: the whole step's plan is taken back
+            last_error_ = async_error_msg_;
+            if (failed_at < now.size()) {
+                std::vector<PhysOp> all(now);
+                all.insert(all.end(), later.begin(), later.end());
+                rollback_maps(all, failed_at);
+            }
+            return rc;
+        }
+        layered_error_.store(0);
+        layers_ready_.store(sync_layers_, std::memory_order_release);
+        layered_pending_.store(1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> q(q_mu_);
+            queue_.push_back(std::move(later));
+            queue_layered_.push_back(1);
+            inflight_++;
+        }
+        q_cv_.notify_all();
+    } else {
+        rc = flush_sync();
+        if (err) return err;
+        if (rc) return rc;
+    }
     background_management();                            // planned now, executed by the mapper
     flush_async();
+    return VATTN_OK;
+}
+
+int PageManager::wait_layer(uint32_t layer) {
+    if (!layered_pending_.load(std::memory_order_acquire)) return VATTN_OK;
+    if (layers_ready_.load(std::memory_order_acquire) <= layer) {
+        const uint64_t t0 = now_ns();
+        std::unique_lock<std::mutex> l(layer_mu_);
+        layer_cv_.wait(l, [&] { return layers_ready_.load(std::memory_order_acquire) > layer || !layered_pending_.load(); });
+        layer_wait_ns_ += now_ns() - t0;
+    }
+    const int e = layered_error_.load();
+    if (e) last_error_ = "layer-ordered mapping failed on the mapper thread (see the next step's error)";
+    return e;
+}
+
+uint32_t PageManager::layers_ready() {
+    return layered_pending_.load(std::memory_order_acquire) ? layers_ready_.load(std::memory_order_acquire) : cfg_.num_layers;
+}
+
+int PageManager::set_sync_layers(uint32_t n) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (n == 0) return fail(VATTN_ERR_INVALID, "sync_layers must be at least 1");
+    sync_layers_ = n;
     return VATTN_OK;
 }
 
@@ -356,10 +469,14 @@ int PageManager::alloc_new_batch_idx(uint64_t seqlen) {   // vattention.cu:564-5
     return new_id;
 }
 
-int PageManager::free_batch_idx(int slot) {   // vattention.cu:591-594
+int PageManager::free_batch_idx(int slot, void* stream, bool with_fence) {   // vattention.cu:591-594
     std::lock_guard<std::mutex> l(state_mu_);
     if (slot < 0 || slot >= (int)cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "slot out of range");
     lens_[slot] = 0;
+    // the point in the engine's stream after the last kernel that can read this slot's pages (plain free: no fence, a later
+    // reclaim of the slot then synchronises the whole device)
+    if (be_.fence_record && be_.fence_record(be_.ctx, (uint32_t)slot, with_fence ? (stream ? stream : (void*)-1) : nullptr) != 0)
+        return fail(VATTN_ERR_DRIVER, "recording the slot fence failed");
     return VATTN_OK;
 }
 
@@ -367,6 +484,15 @@ uint64_t PageManager::num_free_kvblocks() {   // vattention.cu:189-210, utils.h:
     std::lock_guard<std::mutex> l(state_mu_);
     uint64_t over = 0;
     for (int r = 0; r < (int)cfg_.max_batch_size; r++) over += mapped_pages_[r] - tokens_to_pages(lens_[r]);
+    // a shared page-group (map_common_pages) sits in several slots but is ONE group of physical pages: it is free-able once,
+    // and only if every slot that holds it could release it
+    for (const SharedGroup& g : shared_) {
+        uint64_t recl = 0;
+        for (auto& h : g.holders)
+            if (h.second >= tokens_to_pages(lens_[h.first]) && h.second < mapped_pages_[h.first]) recl++;
+        over -= recl;
+        if (recl == g.holders.size() && recl) over += 1;
+    }
     return pages_to_kvblocks(pool_.size()) + over;
 }
 
@@ -385,6 +511,7 @@ int PageManager::set_verbose(bool on) {
 int PageManager::map_common_pages(uint64_t num_tokens) {   // vattention.cu:325-373, mux.h:68-85
     std::lock_guard<std::mutex> l(state_mu_);
     if (!inited_ || cleaned_) return fail(VATTN_ERR_INVALID, "allocator is not initialised");
+    if (fatal_.load()) return fail(fatal_.load(), last_error_);
     int rc = wait_locked_free();
     if (rc) return rc;
     const uint64_t nblocks = tokens_to_pages(num_tokens);
@@ -403,15 +530,22 @@ int PageManager::map_common_pages(uint64_t num_tokens) {   // vattention.cu:325-
             const uint32_t k = pool_.back(); pool_.pop_back();
             const uint32_t v = pool_.back(); pool_.pop_back();
             note_popped(k < v ? k : v);
+            refcnt_[k] = refcnt_[v] = cfg_.max_batch_size;          // one physical pair, max_batch_size mappings
             for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
                 const uint64_t off = (uint64_t)r * virt_per_req_ + mapped_pages_[r] * cfg_.page_size;
-                plan_.push_back({0, k_tensor(layer), k, off});
-                plan_.push_back({0, v_tensor(layer), v, off});
+                plan_.push_back({0, 0, (uint16_t)r, (uint16_t)layer, k_tensor(layer), k, off});
+                plan_.push_back({0, 0, (uint16_t)r, (uint16_t)layer, v_tensor(layer), v, off});
                 pagemap_[std::make_tuple((uint64_t)r, off, (uint64_t)layer)] = std::make_pair(k, v);
             }
         }
-        if (!err)
-            for (int r = 0; r < (int)cfg_.max_batch_size; r++) mapped_pages_[r]++;
+        if (!err) {
+            SharedGroup g;
+            for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
+                g.holders.emplace_back((uint32_t)r, mapped_pages_[r]);
+                mapped_pages_[r]++;
+            }
+            shared_.push_back(std::move(g));
+        }
     }
     rc = flush_sync();
     return err ? err : rc;
@@ -516,6 +650,7 @@ void PageManager::stats(vattn_stats* out) {
     std::lock_guard<std::mutex> e(exec_mu_);
     *out = st_;
     out->join_wait_ns = join_wait_ns_.load();
+    out->layer_wait_ns = layer_wait_ns_.load();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -538,11 +673,13 @@ int PageManager::ensure_created(uint32_t page) {   // exec_mu_ held
     return VATTN_OK;
 }
 
-int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async) {   // exec_mu_ held
+int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async, size_t* first_failed, bool layered) {   // exec_mu_ held
     const uint64_t t0 = now_ns();
     const uint64_t page = cfg_.page_size;
     const bool merge = !(cfg_.flags & VATTN_FLAG_NO_ACCESS_MERGE);
-    // pending set-access runs: (tensor, start offset, bytes); flushed before any unmap and at the end
+    if (first_failed) *first_failed = ops.size();
+    // pending set-access runs: (tensor, start offset, bytes); flushed before any unmap, at every layer boundary of a
+    // layer-ordered batch and at the end
     std::vector<std::tuple<uint32_t, uint64_t, uint64_t>> runs;
     auto flush_access = [&]() -> int {
         if (runs.empty()) return 0;
@@ -566,32 +703,66 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async) {   // e
         runs.clear();
         return 0;
     };
-    int rc = VATTN_OK;
-    bool unmapped = false;
-    for (const PhysOp& op : ops) {
+    auto publish_layer = [&](uint32_t ready) {
+        {
+            std::lock_guard<std::mutex> l(layer_mu_);
+            layers_ready_.store(ready, std::memory_order_release);
+        }
+        layer_cv_.notify_all();
+    };
+    int rc = VATTN_OK;          // first error
+    bool map_failed = false;    // a create / map failed: the remaining maps are skipped (and rolled back by the caller),
+                                // the remaining unmaps — whose bookkeeping is already applied — still run
+    bool unmapped = false, quiesced = false;
+    std::vector<uint8_t> fenced;    // slots whose fence this batch has already waited on
+    for (size_t i = 0; i < ops.size(); i++) {
+        const PhysOp& op = ops[i];
         if (op.kind == 0) {
-            rc = ensure_created(op.page);
-            if (rc) break;
-            if (be_.map(be_.ctx, bases_[op.tensor] + op.offset, page, handles_[op.page]) != 0) {
+            if (map_failed) continue;
+            if (layered && i > 0 && ops[i - 1].layer != op.layer) {
+                if (flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; fatal_ = rc; break; }
+                publish_layer(op.layer);     // every layer below op.layer is mapped and accessible
+            }
+            int e = ensure_created(op.page);
+            if (!e && be_.map(be_.ctx, bases_[op.tensor] + op.offset, page, handles_[op.page]) != 0) {
                 async_error_msg_ = "hipMemMap failed";
-                rc = VATTN_ERR_DRIVER;
-                break;
+                e = VATTN_ERR_DRIVER;
+            }
+            if (e) {
+                rc = e;
+                map_failed = true;
+                if (first_failed) *first_failed = i;
+                continue;
             }
             st_.map_calls++;
             st_.pages_mapped_now++;
             runs.emplace_back(op.tensor, op.offset, page);
         } else {
-            if (flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; break; }
-            if (!unmapped && be_.quiesce) {
-                // first unmap of the batch: kernels launched earlier may still read the pages being reclaimed
-                const uint64_t q0 = now_ns();
-                if (be_.quiesce(be_.ctx) != 0) { async_error_msg_ = "device synchronisation before unmap failed"; rc = VATTN_ERR_DRIVER; break; }
-                st_.quiesce_calls++;
-                st_.quiesce_ns += now_ns() - q0;
+            if (flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; fatal_ = rc; break; }
+            if (op.need_fence && !quiesced) {
+                // kernels launched before the slot was freed may still read the page: wait for the slot's fence, or, if the
+                // engine recorded none, for the whole device (once per batch)
+                if (fenced.size() <= op.slot) fenced.resize((size_t)op.slot + 1, 0);
+                if (!fenced[op.slot]) {
+                    const uint64_t q0 = now_ns();
+                    int fr = be_.fence_wait ? be_.fence_wait(be_.ctx, op.slot) : 1;
+                    if (fr == 0) {
+                        st_.fence_waits++;
+                        st_.fence_wait_ns += now_ns() - q0;
+                    } else if (fr > 0 && be_.quiesce) {
+                        if (be_.quiesce(be_.ctx) != 0) fr = -1;
+                        quiesced = true;
+                        st_.quiesce_calls++;
+                        st_.quiesce_ns += now_ns() - q0;
+                    }
+                    if (fr < 0) { async_error_msg_ = "device synchronisation before unmap failed"; rc = VATTN_ERR_DRIVER; fatal_ = rc; break; }
+                    fenced[op.slot] = 1;
+                }
             }
             if (be_.unmap(be_.ctx, bases_[op.tensor] + op.offset, page) != 0) {
                 async_error_msg_ = "hipMemUnmap failed";
                 rc = VATTN_ERR_DRIVER;
+                fatal_ = rc;
                 break;
             }
             st_.unmap_calls++;
@@ -599,39 +770,104 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async) {   // e
             unmapped = true;
         }
     }
-    if (!rc && flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; }
+    if (!fatal_ && flush_access() != 0) { async_error_msg_ = "hipMemSetAccess failed"; rc = VATTN_ERR_DRIVER; fatal_ = rc; }
     if (unmapped && be_.tlb_flush) {
         // stale GPU translations of the unmapped pages must be gone before anyone may rely on this batch
         const uint64_t f0 = now_ns();
-        if (be_.tlb_flush(be_.ctx) != 0 && !rc) { async_error_msg_ = "TLB invalidation after unmap failed"; rc = VATTN_ERR_DRIVER; }
+        if (be_.tlb_flush(be_.ctx) != 0) {
+            if (!rc) { async_error_msg_ = "TLB invalidation after unmap failed"; rc = VATTN_ERR_DRIVER; }
+            fatal_ = VATTN_ERR_DRIVER;
+        }
         st_.tlb_flushes++;
         st_.tlb_flush_ns += now_ns() - f0;
+    }
+    if (layered) {
+        if (rc) layered_error_.store(rc);
+        {
+            std::lock_guard<std::mutex> l(layer_mu_);
+            layers_ready_.store(cfg_.num_layers, std::memory_order_release);
+            layered_pending_.store(0, std::memory_order_release);
+        }
+        layer_cv_.notify_all();
     }
     const uint64_t dt = now_ns() - t0;
     if (is_async) { st_.async_batches++; st_.async_ns += dt; } else { st_.sync_batches++; st_.sync_ns += dt; }
     return rc;
 }
 
+// A create / map failed at ops[first_failed]: every page-group that contains a map at or after that op is taken back —
+// executed maps of those groups are unmapped, their pages return to the pool, the page map and the per-slot counts are
+// restored — so bookkeeping equals the driver state again and the manager stays usable (the reference exits the process
+// on any driver error, cudaInternal.h:1-13).  state_mu_ held; takes exec_mu_ for the unmaps.
+void PageManager::rollback_maps(const std::vector<PhysOp>& ops, size_t first_failed) {
+    std::vector<std::pair<uint16_t, uint64_t>> groups;      // (slot, page position) to revert
+    auto pos_of = [&](const PhysOp& op) { return (op.offset - (uint64_t)op.slot * virt_per_req_) / cfg_.page_size; };
+    for (size_t j = first_failed; j < ops.size(); j++) {
+        if (ops[j].kind != 0) continue;
+        const auto g = std::make_pair(ops[j].slot, pos_of(ops[j]));
+        if (std::find(groups.begin(), groups.end(), g) == groups.end()) groups.push_back(g);
+    }
+    if (groups.empty()) return;
+    std::lock_guard<std::mutex> e(exec_mu_);
+    for (size_t jj = ops.size(); jj-- > 0;) {
+        const PhysOp& op = ops[jj];
+        if (op.kind != 0) continue;
+        const auto g = std::make_pair(op.slot, pos_of(op));
+        if (std::find(groups.begin(), groups.end(), g) == groups.end()) continue;
+        if (jj < first_failed) {                             // this one reached the driver: take it out again
+            if (be_.unmap(be_.ctx, bases_[op.tensor] + op.offset, cfg_.page_size) == 0) {
+                st_.unmap_calls++;
+                st_.pages_mapped_now--;
+            } else {
+                fatal_ = VATTN_ERR_DRIVER;
+            }
+        }
+        pagemap_.erase(std::make_tuple((uint64_t)op.slot, op.offset, (uint64_t)op.layer));
+        drop_mapping(op.page);
+    }
+    for (auto& g : groups) {
+        if (mapped_pages_[g.first] > g.second) mapped_pages_[g.first] = g.second;    // the reverted groups are a slot's tail
+        if (!shared_.empty()) forget_shared_holder(g.first, g.second);
+    }
+    st_.rollbacks++;
+}
+
 int PageManager::wait_locked_free() {   // state_mu_ held; joins every queued background batch
     const uint64_t t0 = now_ns();
-    std::unique_lock<std::mutex> q(q_mu_);
-    done_cv_.wait(q, [this] { return inflight_ == 0; });
-    join_wait_ns_ += now_ns() - t0;
-    if (async_error_) {
-        int e = async_error_;
-        last_error_ = async_error_msg_;
-        return e;
+    std::vector<PhysOp> failed;
+    size_t failed_at = 0;
+    int e = 0;
+    {
+        std::unique_lock<std::mutex> q(q_mu_);
+        done_cv_.wait(q, [this] { return inflight_ == 0; });
+        join_wait_ns_ += now_ns() - t0;
+        if (have_failed_) {
+            failed.swap(failed_ops_);
+            failed_at = failed_at_;
+            have_failed_ = false;
+        }
+        e = async_error_;
+        if (e) last_error_ = async_error_msg_;
+        if (!fatal_) async_error_ = 0;          // reported once; bookkeeping is consistent again after the rollback below
     }
-    return VATTN_OK;
+    if (!failed.empty()) rollback_maps(failed, failed_at);
+    return e;
 }
 
 int PageManager::flush_sync() {   // state_mu_ held, mapper idle (callers join first)
     if (plan_.empty()) return VATTN_OK;
     std::vector<PhysOp> ops;
     ops.swap(plan_);
-    std::lock_guard<std::mutex> e(exec_mu_);
-    int rc = execute(ops, false);
-    if (rc) last_error_ = async_error_msg_;
+    size_t failed_at = ops.size();
+    int rc;
+    {
+        fg_waiting_.fetch_add(1);
+        std::lock_guard<std::mutex> e(exec_mu_);
+        fg_waiting_.fetch_sub(1);
+        rc = execute(ops, false, &failed_at);
+        if (rc) last_error_ = async_error_msg_;
+    }
+    if (rc && failed_at < ops.size()) rollback_maps(ops, failed_at);
     return rc;
 }
 
@@ -640,14 +876,22 @@ void PageManager::flush_async() {   // state_mu_ held
     std::vector<PhysOp> ops;
     ops.swap(plan_);
     if (cfg_.flags & VATTN_FLAG_NO_MAPPER_THREAD) {
-        std::lock_guard<std::mutex> e(exec_mu_);
-        int rc = execute(ops, true);
-        if (rc) async_error_ = rc;
+        size_t failed_at = ops.size();
+        int rc;
+        {
+            std::lock_guard<std::mutex> e(exec_mu_);
+            rc = execute(ops, true, &failed_at);
+        }
+        if (rc) {
+            async_error_ = rc;
+            if (failed_at < ops.size()) rollback_maps(ops, failed_at);
+        }
         return;
     }
     {
         std::lock_guard<std::mutex> q(q_mu_);
         queue_.push_back(std::move(ops));
+        queue_layered_.push_back(0);
         inflight_++;
     }
     q_cv_.notify_all();
@@ -661,29 +905,40 @@ void PageManager::mapper_main() {
         if (stop_) return;
         if (!queue_.empty()) {
             std::vector<PhysOp> ops = std::move(queue_.front());
+            const bool layered = queue_layered_.front() != 0;
             queue_.pop_front();
+            queue_layered_.pop_front();
             q.unlock();
             int rc;
+            size_t failed_at = ops.size();
             {
                 std::lock_guard<std::mutex> e(exec_mu_);
-                rc = execute(ops, true);
+                rc = execute(ops, true, &failed_at, layered);
             }
             q.lock();
             if (rc && !async_error_) async_error_ = rc;
+            if (rc && failed_at < ops.size() && !have_failed_) {      // the joiner rolls the unexecuted maps back
+                failed_ops_ = std::move(ops);
+                failed_at_ = failed_at;
+                have_failed_ = true;
+            }
             inflight_--;
             if (inflight_ == 0) done_cv_.notify_all();
             continue;
         }
-        // idle: materialise a few physical handles ahead of demand (lazy pool)
+        // idle: materialise physical handles ahead of demand (lazy pool).  ONE handle per acquisition of
+        // exec_mu_ (a create costs ~1 ms at 100 k live handles) and none while a foreground flush is waiting for the mutex
+        // (std::mutex is not fair), so step()/step_async() never queue behind a slice of creations.
         q.unlock();
-        {
+        if (fg_waiting_.load() == 0) {
             std::lock_guard<std::mutex> e(exec_mu_);
-            for (uint64_t i = 0; i < kPrecreateSlice; i++) {
-                const uint64_t left = precreate_left_.load();
-                if (left == 0 || left <= precreate_floor()) break;          // window full: wait until the pool is consumed further
-                if (left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) { precreate_left_.store(0); break; }
-                precreate_left_.store(left - 1);
+            const uint64_t left = precreate_left_.load();
+            if (left != 0 && left > precreate_floor()) {
+                if (left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) precreate_left_.store(0);
+                else precreate_left_.store(left - 1);
             }
+        } else {
+            std::this_thread::yield();
         }
         q.lock();
     }

@@ -25,8 +25,11 @@ namespace vattn {
 
 struct PhysOp {
     uint8_t kind;        // 0 = map page at (tensor, offset), 1 = unmap (tensor, offset)
+    uint8_t need_fence;  // unmap of a FREED slot's page: kernels launched before the free may still read it (fence / quiesce first)
+    uint16_t slot;       // request slot the page belongs to
+    uint16_t layer;      // layer of the page (0 with megacache)
     uint32_t tensor;
-    uint32_t page;       // physical page id (index into handles_), map only
+    uint32_t page;       // physical page id (index into handles_)
     uint64_t offset;     // byte offset inside the tensor's virtual range
 };
 
@@ -45,7 +48,10 @@ public:
     int step_async(const uint64_t* lens, uint32_t n);
     int wait();
     int alloc_new_batch_idx(uint64_t seqlen);
-    int free_batch_idx(int slot);
+    int free_batch_idx(int slot, void* stream = nullptr, bool with_fence = false);
+    int wait_layer(uint32_t layer);
+    uint32_t layers_ready();
+    int set_sync_layers(uint32_t n);
     uint64_t num_free_kvblocks();
     int set_deferred_reclamation(bool on);
     int set_verbose(bool on);
@@ -59,6 +65,7 @@ public:
     void stats(vattn_stats* out);
     void counts(uint64_t out[4]);
     const char* last_error() const { return last_error_.c_str(); }
+    void set_error(const std::string& msg) { last_error_ = msg; }
 
 private:
     // ---- configuration (vattention.cu:38-74) ----
@@ -74,6 +81,15 @@ private:
     std::map<std::tuple<uint64_t, uint64_t, uint64_t>, std::pair<uint32_t, uint32_t>> pagemap_;
     bool deferred_reclaim_ = true, verbose_ = false;
     uint64_t num_pages_ = 0;                                      // page ids handed out so far
+    // Prefix sharing (map_common_pages aliases one physical pair into several slots): a page returns to the pool when its
+    // LAST mapping goes (the reference pushes it once per slot, mux.h:51-66 — duplicate ids in the pool, the same physical
+    // page then backs two different (slot, layer) ranges).  refcnt_[page] = live mappings; shared_ lists the aliased
+    // page-groups and who still holds them, so that num_free_kvblocks counts a shared group once, and only when every
+    // holder could release it.
+    std::vector<uint32_t> refcnt_;
+    struct SharedGroup { std::vector<std::pair<uint32_t, uint64_t>> holders; };   // (slot, page position inside the slot)
+    std::vector<SharedGroup> shared_;
+    std::atomic<int> fatal_{0};                                   // sticky: a failed unmap / set-access / TLB invalidation
     std::mutex state_mu_;
     std::vector<PhysOp> plan_;
     std::string last_error_;
@@ -90,6 +106,9 @@ private:
     // ---- planners (each mirrors one reference routine) ----
     int plan_map_pair(int r, uint32_t layer, uint64_t off);
     void plan_unmap_pair(int r, uint32_t layer, uint64_t off);
+    void drop_mapping(uint32_t page);          // refcount--, back to the pool at zero
+    void forget_shared_holder(int r, uint64_t pos);
+    void rollback_maps(const std::vector<PhysOp>& ops, size_t first_failed);   // state_mu_ held
     void unmap_req_page_one(int r);
     void release_some(int r, uint64_t retain);
     int grow(int r, uint64_t nblocks, bool sync);
@@ -123,10 +142,25 @@ private:
     int async_error_ = 0;
     std::string async_error_msg_;
     vattn_stats st_{};
+    // a background batch whose map failed: the joiner rolls its unexecuted maps back (bookkeeping is guarded by state_mu_,
+    // which the mapper never takes)
+    std::vector<PhysOp> failed_ops_;
+    size_t failed_at_ = 0;
+    bool have_failed_ = false;
+    std::atomic<int> fg_waiting_{0};             // a foreground flush wants exec_mu_: the idle pre-creation loop backs off
+    // VATTN_FLAG_LAYERED_ASYNC
+    uint32_t sync_layers_ = 2;
+    std::atomic<uint32_t> layers_ready_{0};      // layers of the current step whose pages are mapped
+    std::atomic<int> layered_pending_{0};
+    std::atomic<int> layered_error_{0};
+    std::atomic<uint64_t> layer_wait_ns_{0};
+    std::mutex layer_mu_;
+    std::condition_variable layer_cv_;
+    std::deque<uint8_t> queue_layered_;          // parallel to queue_: 1 = ops are sorted by layer, publish progress
 
     int flush_sync();
     void flush_async();
-    int execute(const std::vector<PhysOp>& ops, bool is_async);
+    int execute(const std::vector<PhysOp>& ops, bool is_async, size_t* first_failed, bool layered = false);
     void note_popped(uint32_t lowest);
     int ensure_created(uint32_t page);
     void mapper_main();

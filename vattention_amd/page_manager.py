@@ -79,8 +79,21 @@ class PageManager:
     def alloc_new_batch_idx(self, seqlen: int) -> int:
         return self._lib.vattn_alloc_new_batch_idx(self._h, int(seqlen))
 
-    def free_batch_idx(self, slot: int) -> None:
-        self._check(self._lib.vattn_free_batch_idx(self._h, int(slot)))
+    def free_batch_idx(self, slot: int, stream: Optional[int] = None) -> None:
+        """`stream` (a raw hipStream_t, 0 = the default stream): also records the slot's fence there (include/vattn.h)."""
+        if stream is None:
+            self._check(self._lib.vattn_free_batch_idx(self._h, int(slot)))
+        else:
+            self._check(self._lib.vattn_free_batch_idx_on_stream(self._h, int(slot), C.c_void_p(stream)))
+
+    def wait_layer(self, layer: int) -> None:
+        self._check(self._lib.vattn_wait_layer(self._h, int(layer)))
+
+    def layers_ready(self) -> int:
+        return int(self._lib.vattn_layers_ready(self._h))
+
+    def set_sync_layers(self, n: int) -> None:
+        self._check(self._lib.vattn_set_sync_layers(self._h, int(n)))
 
     def num_free_kvblocks(self) -> int:
         return int(self._lib.vattn_num_free_kvblocks(self._h))
