@@ -1,5 +1,6 @@
-"""Parity at BASELINE.json's FULL sizes, where the CPU oracle would take hours: size-independent properties of the operator
-(configs[1]: Yi-6B heads, 32 702-token prompt, batch-16 decode at 32 k; configs[3]: 128 k context).
+"""Size-independent properties of the operator at BASELINE.json's FULL sizes (configs[1]: Yi-6B heads, 32 702-token prompt,
+batch-16 decode at 32 k; configs[3]: 128 k context) — they cover EVERY output element of the full-size launches, complementing
+the direct oracle comparison of tests/test_gpu_full_size_parity.py (full decode batches, sampled query blocks of the prefills).
   * rows of softmax sum to one:           V = 1            ->  O = 1
   * linearity in V:                        O(V1 + V2)       =  O(V1) + O(V2)
   * chunked prefill == whole-prompt prefill (the reference's Sarathi vs vLLM scheduling of the same request)

@@ -22,6 +22,8 @@ from typing import Optional, Tuple
 
 import torch
 
+from .. import vattention as _vattention
+
 from .vattention_flashattention_wrapper import VAttentionFlashAttentionWrapper
 
 
@@ -70,6 +72,8 @@ class VAttentionFlashAttentionStreamsWrapper(VAttentionFlashAttentionWrapper):
             return torch.zeros_like(query)
         if not self._overlap:                        # not a hybrid batch, or splitting the prefill beats overlapping it
             return super().forward(query, key, value, kv_cache, softmax_scale, layer_id)
+        if layer_id is not None:
+            _vattention.wait_layer(layer_id)         # layer-ordered page mapping (see the base wrapper)
         output = torch.empty_like(query)
         main = torch.cuda.current_stream(self.device)
         side = self.decode_stream

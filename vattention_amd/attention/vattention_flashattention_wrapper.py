@@ -22,6 +22,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
+from .. import vattention as _vattention
 from ..cache_ops import cache_flat
 from ..flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
 from .base_attention_wrapper import BaseAttentionWrapper
@@ -99,6 +100,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         assert self.is_metadata_initialized, "Metadata is not initialized."
         if self.is_profiling_iteration:
             return torch.zeros_like(query)       # memory-profiling pass: no attention (model_runner.py:192-201)
+        if layer_id is not None:
+            _vattention.wait_layer(layer_id)     # layer-ordered page mapping: this layer's pages must be mapped by now
         output = torch.empty_like(query)
         tok = self._forward_prefills(query, key, value, kv_cache, softmax_scale, layer_id, output)
         if self.decode_batch_size:

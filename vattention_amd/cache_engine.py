@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Tuple
 
+import os
+
 import torch
 
 from . import vattention
@@ -57,6 +59,9 @@ class vATTNCacheEngine:
         return vattention.num_free_kvblocks()
 
     def allocate_gpu_cache(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        # layer-ordered mapping of new prompts needs the wrapper to gate each layer (wait_layer): this package's wrappers do
+        vattention.enable_layered_async(self.vattn_async and not self.vattn_mega_cache and
+                                        os.environ.get("VATTN_LAYERED_ASYNC", "1") != "0")
         kv = vattention.init_kvcache(self.num_layers, self.num_heads, self.head_size, self.max_batch_size,
                                      self.max_model_seq_len, self.device_idx, self.dtype, self.page_size,
                                      self.vattn_mega_cache)

@@ -182,7 +182,8 @@ class HotPathRunner:
                 self.stats.decode_tokens += 1
         if self.sample_kv_util:
             self._sample_util()
-        self.engine.on_step_completion(mds)
+        with torch.cuda.stream(self.stream):         # free_batch_idx records the slot's fence on the stream the kernels ran on
+            self.engine.on_step_completion(mds)
         self.stats.iterations += 1
         return out
 

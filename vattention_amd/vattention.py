@@ -21,6 +21,7 @@ _tensors: List[torch.Tensor] = []
 _verbose = False
 _deferred = True
 _default_flags = 0
+_layered_pending = False     # a layer-ordered mapping batch of the current step may still be running (see wait_layer)
 
 
 def _vtensor():
@@ -76,7 +77,11 @@ def step(seq_lens: List[int], eager_reclaim: bool) -> None:
 def step_async(seq_lens: List[int]) -> None:
     """apis.h:31-35: maps what this iteration needs before returning, plans and hands the look-ahead
     mapping to the mapper thread; the GIL is released for the duration of the native call."""
-    _require().step_async(seq_lens)
+    global _layered_pending
+    pm = _require()
+    pm.step_async(seq_lens)
+    if pm.cfg.flags & L.FLAG_LAYERED_ASYNC:
+        _layered_pending = pm.layers_ready() < pm.cfg.num_layers
 
 
 def alloc_new_batch_idx(seqlen: int) -> int:
@@ -84,7 +89,10 @@ def alloc_new_batch_idx(seqlen: int) -> int:
 
 
 def free_batch_idx(reqId: int) -> None:
-    _require().free_batch_idx(reqId)
+    """apis.h:57-59.  Also marks, on torch's current stream, the point after the kernels launched so far: a later reclaim of the
+    slot's pages waits for that point instead of synchronising the device (include/vattn.h, vattn_free_batch_idx_on_stream)."""
+    pm = _require()
+    pm.free_batch_idx(reqId, stream=torch.cuda.current_stream(pm.cfg.device).cuda_stream)
 
 
 def num_free_kvblocks() -> int:
@@ -134,6 +142,26 @@ def release_kvcache_physical() -> None:
 
 
 # ---- MI355X extensions (not in the reference surface) ----
+def enable_layered_async(on: bool = True) -> None:
+    """The next init_kvcache maps new prompts LAYER-ORDERED (VATTN_FLAG_LAYERED_ASYNC): step_async returns after the first
+    layers' pages are mapped, the mapper thread maps the rest while those layers run.  The caller MUST then call
+    wait_layer(layer_id) before launching each layer (the fa_vattn wrapper of this package does; the reference's does not, so
+    this stays opt-in)."""
+    global _default_flags
+    _default_flags = (_default_flags | L.FLAG_LAYERED_ASYNC) if on else (_default_flags & ~L.FLAG_LAYERED_ASYNC)
+
+
+def wait_layer(layer_id: int) -> None:
+    """Block until the pages the current step needs are mapped for `layer_id` (no-op unless a layered batch is pending)."""
+    global _layered_pending
+    if not _layered_pending or _pm is None:
+        return
+    _pm.wait_layer(layer_id)
+    if layer_id + 1 >= _pm.cfg.num_layers:
+        _layered_pending = False
+
+
+
 def wait() -> None:
     """Join outstanding background mapping (the next step()/step_async() does this implicitly)."""
     _require().wait()
