@@ -86,8 +86,9 @@ int vattn_cache_flat(const void* key, const void* value, void* k_cache, void* v_
                      int64_t key_stride, int64_t value_stride, int64_t k_cache_stride, int64_t v_cache_stride,
                      int32_t itemsize, void* stream);
 
-/* Device-side self-tests of the hardware layout assumptions (MFMA fragment maps, LDS transpose
- * read); 0 = all assumptions hold.  Used by tests/test_hw_layouts.py on the GPU box. */
+/* Device-side self-tests of the hardware layout assumptions (MFMA fragment maps, LDS transpose read, LDS-DMA lane
+ * mapping); 0 = all assumptions hold.  detail_out[0..5] are per-assumption failure flags, detail_out[6] reports what
+ * an out-of-range LDS-DMA lane does to its LDS bytes (0 zeros, 1 untouched).  Used by tests/test_gpu_hw_and_vmm.py. */
 int vattn_selftest_layouts(void* stream, int32_t* detail_out /* int32[8] host buffer */);
 
 /* Times `iters` launches of the kernel family last used by vattn_flash_attn_with_kvcache with HIP

@@ -63,7 +63,7 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
         assert torch.equal(kgi.cpu(), kc1) and torch.equal(vgi.cpu(), vc1)     # in-place append, bit-exact, nothing else touched
 
 
-@pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved"])
+@pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12, 14], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved", "w4q2_dma_pipelined"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("n,c,Hq,Hkv", [
     (128, 0, 8, 2), (1, 5, 4, 4), (200, 0, 4, 1), (77, 333, 8, 4), (512, 1000, 4, 2), (130, 62, 2, 2), (64, 64, 4, 2),
@@ -113,7 +113,7 @@ def test_prefill_workgroup_orders(Hq, Hkv):
     ref64 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
     ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     outs = []
-    for variant in (32, 64, 0, 96, 12):
+    for variant in (32, 64, 0, 96, 12, 14, 14 | 32, 14 | 64):
         out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
                                       causal=True, _variant=variant)
         torch.cuda.synchronize()
@@ -166,7 +166,7 @@ def test_head_dim_64(Hq, Hkv, dtype):
         _check(out, r64, r32, dtype, "d64 prefill variant=%d" % variant)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 8, 1], ids=["default", "w8", "w4", "plain_reads"])
+@pytest.mark.parametrize("variant", [0, 2, 8, 1, 14], ids=["default", "w8", "w4", "plain_reads", "w4q2_dma_pipelined"])
 @pytest.mark.parametrize("causal", [True, False], ids=["causal", "full"])
 def test_prefill_kv_split(causal, variant):
     """KV-split prefill (the key range of a work item divided over workgroups, fp32 partials merged by combine_kernel):
@@ -214,7 +214,7 @@ def test_prefill_kv_split_heuristic_engages():
     assert (a.float() - b.float()).abs().max().item() <= 2e-3
 
 
-@pytest.mark.parametrize("variant,splits", [(0, 0), (2, 0), (8, 0), (0, 3), (2, 2)], ids=["default", "w8", "w4", "default_split3", "w8_split2"])
+@pytest.mark.parametrize("variant,splits", [(0, 0), (2, 0), (8, 0), (0, 3), (2, 2), (14, 0), (14, 3)], ids=["default", "w8", "w4", "default_split3", "w8_split2", "dma64", "dma64_split3"])
 def test_batched_variable_length_prefill(variant, splits):
     """One launch for the chunks of several sequences with different lengths (flash_attn_varlen_with_kvcache): every entry
     must equal the single-sequence call bit for bit and match the oracle; entries shorter than the grid's block count, an
@@ -280,6 +280,35 @@ def test_online_softmax_rescale_is_exercised():
     out = flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
     torch.cuda.synchronize()
     _check(out, ref64, ref32, torch.float16, "spiked keys")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_deferred_rescale_of_the_pipelined_kernel(dtype):
+    """prefill64_kernel keeps the running maximum until a tile exceeds it by more than 2^6 and then rescales O, l and the pending
+    S' once (cdna guide T13 + rule 26): spiked keys at late tiles for individual rows (branch taken by one row of a wave while the
+    others are not), a spike in the FIRST tile (large initial maximum: later tiles sit far below it), growth just below and just
+    above the threshold, all against fp64; and the result must not depend on the threshold being crossed (same data scaled)."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(17)
+    n, Lk, H = 320, 1100, 2
+    q = torch.randn(1, n, H, 128).to(dtype)
+    k = (torch.randn(1, Lk, H, 128) * 0.3).to(dtype)
+    v = torch.randn(1, Lk, H, 128).to(dtype)
+    unit = lambda x: (x.float() / x.float().norm()).to(dtype)
+    k[0, 900, 0] = (unit(q[0, 319, 0]) * 6.0).to(dtype)       # one row's score jumps far above its running max at tile 14
+    k[0, 5, 1] = (unit(q[0, 100, 1]) * 8.0).to(dtype)         # first tile carries a large maximum for row 100 of head 1
+    k[0, 700, 1] = (unit(q[0, 250, 1]) * 3.0).to(dtype)       # moderate growth (around the 2^6 threshold after scaling)
+    k[0, 701, 1] = (unit(q[0, 251, 1]) * 3.6).to(dtype)
+    cl = torch.tensor([Lk], dtype=torch.int32)
+    ref64 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=cl, causal=True)
+    ref32 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=cl, causal=True, math="f32")
+    outs = {}
+    for variant in (14, 0):
+        out = flash_attn_with_kvcache(q.to(DEV), k.to(DEV), v.to(DEV), cache_seqlens=cl.to(DEV), causal=True, _variant=variant)
+        torch.cuda.synchronize()
+        _check(out, ref64, ref32, dtype, "deferred rescale variant %d" % variant)
+        outs[variant] = out.float().cpu()
+    assert (outs[14] - outs[0]).abs().max().item() <= (4e-3 if dtype == torch.float16 else 3e-2)
 
 
 def test_cache_flat_edge_cases():

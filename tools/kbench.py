@@ -143,7 +143,7 @@ if __name__ == "__main__":
     torch.zeros(1, device=DEV)
     if "prefill" in what:
         for v in VARIANTS:
-            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3], {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups"}[(v >> 1) & 7]))
+            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3], {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups", 7: "4 waves x 64 rows, LDS-DMA ring, in-wave software pipeline (prefill64)"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
         decode(variant)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "vattention_amd")
 CSRC = os.path.join(PKG, "csrc")
 ARCH = "gfx950"
-LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "vmm_selfcheck.hip", "attn_api.hip", "prefill_kernels.hip", "decode_kernels.hip",
+LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "vmm_selfcheck.hip", "attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "decode_kernels.hip",
                "cache_kernels.hip")
 
 
@@ -39,7 +39,7 @@ def build_lib(force=False):
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-unused-value"] + os.environ.get("VATTN_CXXFLAGS", "").split()
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-inline-asm"] + os.environ.get("VATTN_CXXFLAGS", "").split()
         objdir = os.path.join(ROOT, "build", "obj")
         os.makedirs(objdir, exist_ok=True)
         objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]
@@ -92,11 +92,23 @@ def build_reference_oracle():
     return True
 
 
+def build_reference_pyref():
+    """oracle/_ref/pyref: the reference's own wrapper / cache-engine Python files byte-compiled where they lie (oracle/build_pyref.py),
+    so the GPU box can execute them (tests/ref_loader.py).  Only where /root/reference exists."""
+    ref = os.environ.get("VATTN_REFERENCE_DIR", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "sarathi-lean")):
+        print("[build] reference sources absent: oracle/_ref/pyref not rebuilt")
+        return None
+    _run([sys.executable, os.path.join(ROOT, "oracle", "build_pyref.py")])
+    return True
+
+
 def build_all(force=False):
     build_lib(force)
     build_vtensor(force)
     build_fake_backend(force)
     build_reference_oracle()
+    build_reference_pyref()
 
 
 if __name__ == "__main__":

@@ -23,7 +23,11 @@ namespace vattn_k {
 //      addressed by lanes 4*j + (i>>2), j = 0..3, of the same group
 //  [3] A/B operands: lane (x = lane&31, g = lane>>5) contributes row/col x with k-slots (g, 0..7) (32x32x16)
 //  [4] same for 16x16x32 with g = lane>>4
-__global__ void selftest_kernel(int* res) {
+//  [5] LDS-DMA (`buffer_load_dwordx4 ... lds`, prefill64_kernels.hip): lane i's 16 bytes land at LDS address M0 + 16*i, whatever
+//      global offset the lane fetched from (the K-tile swizzle is applied on the global side)
+//  [6] (informational, not a failure) what a lane beyond the descriptor's bound does to its 16 LDS bytes:
+//      0 = writes zeros, 1 = leaves them untouched, 2 = something else
+__global__ void selftest_kernel(int* res, const unsigned* gsrc) {
     __shared__ __attribute__((aligned(16))) short lds[64 * 4];
     const int lane = threadIdx.x;
     // [0],[3]: A = one-hot rows, B = one-hot cols with distinct values -> C[m][n] = sum_k A[m][k]B[k][n]
@@ -95,6 +99,43 @@ __global__ void selftest_kernel(int* res) {
         }
         if (bad) atomicOr(&res[2], 1);
     }
+    {
+        __shared__ __attribute__((aligned(16))) unsigned dst[2 * 256];      // two 1-KiB pieces
+        for (int e = 0; e < 8; e++) dst[lane * 8 + e] = 0xABABABABu;
+        __syncthreads();
+        // gsrc[w] = w for 512 dwords (2 KiB).  piece 0: lane i fetches 16-byte chunk (i ^ 5); piece 1: descriptor bounded at 512
+        // bytes, lane i fetches chunk i (lanes >= 32 are out of range)
+        const unsigned long long a = (unsigned long long)gsrc;
+        u32x4 r0, r1;
+        r0[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        r0[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+        r0[2] = 2048u;
+        r0[3] = 0x00020000u;
+        r1 = r0;
+        r1[2] = 512u;
+        const unsigned l0 = (unsigned)(size_t)LDS_PTR(unsigned, dst), l1 = l0 + 1024u;
+        const unsigned v0 = (unsigned)((lane ^ 5) * 16), v1 = (unsigned)(lane * 16);
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(l0), "s"(r0), "v"(v0) : "memory", "m0");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(l1), "s"(r1), "v"(v1) : "memory", "m0");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int bad = 0;
+        for (int e = 0; e < 4; e++)
+            if (dst[lane * 4 + e] != (unsigned)((lane ^ 5) * 4 + e)) bad = 1;
+        if (lane < 32)
+            for (int e = 0; e < 4; e++)
+                if (dst[256 + lane * 4 + e] != (unsigned)(lane * 4 + e)) bad = 1;
+        if (bad) atomicOr(&res[5], 1);
+        if (lane >= 32) {
+            int code = 0;
+            for (int e = 0; e < 4; e++) {
+                const unsigned x = dst[256 + lane * 4 + e];
+                if (x == 0xABABABABu) code |= 1;
+                else if (x != 0u) code |= 2;
+            }
+            if (code) atomicOr(&res[6], code);
+        }
+    }
 }
 
 thread_local std::string g_err;
@@ -158,16 +199,22 @@ int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
     int* d = nullptr;
     if (hipMalloc(&d, 8 * sizeof(int)) != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed");
     hipMemsetAsync(d, 0, 8 * sizeof(int), st);
-    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d);
+    unsigned* gsrc = nullptr;
+    unsigned hsrc[512];
+    for (int i = 0; i < 512; i++) hsrc[i] = (unsigned)i;
+    if (hipMalloc(&gsrc, sizeof(hsrc)) != hipSuccess) { hipFree(d); return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed"); }
+    hipMemcpyAsync(gsrc, hsrc, sizeof(hsrc), hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d, (const unsigned*)gsrc);
     int h[8] = {0};
     hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hipFree(d);
+    hipFree(gsrc);
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     int bad = 0;
     for (int i = 0; i < 8; i++) {
         if (detail_out) detail_out[i] = h[i];
-        bad |= h[i];
+        if (i != 6) bad |= h[i];           // [6] reports the out-of-range behaviour of LDS-DMA, it is not an assumption
     }
     return bad ? fail(VATTN_K_ERR_INVALID, "hardware layout assumption violated") : VATTN_K_OK;
 }

@@ -82,11 +82,64 @@ template <typename P> __device__ __forceinline__ const P* uniform_ptr(const P* p
     return (const P*)(((unsigned long long)hi << 32) | lo);
 }
 
+// ---- prefill form: pieces shared by prefill_kernels.hip and prefill64_kernels.hip ----
+constexpr int PF_BN = 64;              // keys per tile
+template <int HD> struct PfSmem {
+    static constexpr int kRowBytes = HD * 2;
+    static constexpr int kTileBytes = PF_BN * HD * 2;           // K tile == V tile size
+    static constexpr int kBufBytes = 2 * kTileBytes;            // K + V
+    static constexpr int kTotal = 2 * kBufBytes;                // double buffered
+    static constexpr int kVSubBytes = PF_BN * 64;               // one [64 keys][32 d] sub-tile
+};
+
+// Workgroup -> (batch entry, head, query block).  The dispatcher hands consecutive workgroup ids to consecutive XCDs
+// (id & 7), each with its own L2, and starts them in id order.  order 2 (default) makes every XCD stream ONE kv head (its
+// L2 then holds a single K/V stream that the G query heads x neighbouring query blocks running there share) and walks the
+// query blocks heaviest-first across ALL heads, so the workgroups running at any time have near-equal lengths and move
+// down K/V in step.  order 1: heaviest-first across heads without the XCD grouping.  order 0: grid (query block, head,
+// batch) - block-major per head (its tail is one head's heaviest blocks: 20-40 % slower on whole-prompt shapes).
+// Returns false for the padding workgroups of the 1-D grids.
+// KV-split (nsplit > 1, 1-D grids only): the grid is nsplit times larger; every run of 8 consecutive base ids (one per XCD) is
+// repeated nsplit times, so the splits of a work item stay on its XCD and start together.
+__device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order, int nqb, int nsplit, int& b, int& h, int& qb, int& split) {
+    split = 0;
+    if (order == 0) {
+        b = blockIdx.z; h = blockIdx.y; qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+        return true;
+    }
+    int L = blockIdx.x;
+    if (nsplit > 1) {
+        const int grp = L >> 3;
+        split = grp % nsplit;
+        L = ((grp / nsplit) << 3) | (L & 7);
+    }
+    const int G = p.h / p.h_k;
+    if (order == 2) {
+        const int per = 8 / p.h_k;                         // XCDs per kv head (launch guarantees 8 % h_k == 0)
+        const int xcd = L & 7;
+        int t = (L >> 3) * per + xcd / p.h_k;
+        const int g = t % G; t /= G;
+        b = t % p.b;
+        const int qbr = t / p.b;
+        if (qbr >= nqb) return false;
+        h = (xcd % p.h_k) * G + g;
+        qb = nqb - 1 - qbr;
+        return true;
+    }
+    h = L % p.h;
+    const int t = L / p.h;
+    b = t % p.b;
+    qb = nqb - 1 - t / p.b;
+    return t / p.b < nqb;
+}
+
+
 // ---- host-side pieces shared by the translation units ----
 int fail(int code, const char* msg);                                    // attn_api.hip: records the message for vattn_kernels_last_error
 void launch_append(const vattn_attn_params* p, hipStream_t st);         // cache_kernels.hip
 int launch_prefill_form(const vattn_attn_params* p, hipStream_t st);    // prefill_kernels.hip (seqlen_q > 1)
 size_t prefill_workspace_bytes(const vattn_attn_params* p);
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit);   // prefill64_kernels.hip (d = 128)
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
 size_t decode_workspace_bytes(const vattn_attn_params* p);
 

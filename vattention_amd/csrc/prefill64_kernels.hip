@@ -1,0 +1,517 @@
+// Prefill form of flash_attn_with_kvcache, second-generation kernel for head dimension 128 (gfx950):
+//   * a workgroup is 4 waves = one 256-row query block; every wave owns 64 query rows (two 32-row blocks) and a whole SIMD
+//     (one wave per SIMD, 512 registers): each K fragment and each V^T fragment read from LDS feeds TWO MFMAs, halving the
+//     LDS fragment traffic per flop of the 8 x 32-row kernel (prefill_kernels.hip);
+//   * K / V tiles (64 keys) travel HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, one 1-KiB piece per wave
+//     instruction), no staging registers: the K image is row-major with the 16-byte chunk index XOR-swizzled by the row (the
+//     swizzle is applied on the GLOBAL side: lane i fetches the chunk that belongs at its LDS position), the V image is
+//     [d/32][key][32 d] sub-tiles for `ds_read_b64_tr_b16`; a 2-deep ring per tensor (K one tile ahead of V), one barrier
+//     per tile, counted `vmcnt` (the DMA is issued by inline asm, the compiler's wait-count pass never sees it);
+//   * software pipeline inside the wave: phase A  S(t+1) = K(t+1).Q^T  ||  P(t) = exp2(S(t)), row sums;
+//                                        phase B  O += V(t)^T.P(t)^T   ||  row max of S(t+1), f16 packing of P(t);
+//     so the softmax VALU work of a tile is issued between the MFMAs of its neighbours by the same wave;
+//   * Q is pre-scaled by softmax_scale*log2(e) when it is loaded, and the running maximum enters the S^T accumulator as the
+//     C operand of the first MFMA of each chain (S' = K.Q^T - m): one v_exp per score, no fma; the running maximum is only
+//     moved when a tile's maximum exceeds it by more than 2^kDeferLog2 (deferred rescale, cdna guide T13) — O, l and the
+//     pending S(t+1) are rescaled exactly once in that (rare) branch.
+// Semantics as prefill_kernels.hip: /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, mask.h:164-196
+// (bottom-right causal), softmax.h:69-157 (fp32 max/sum via exp2, P rounded to the I/O dtype before PV),
+// flash_fwd_kernel.h:57-499 (the operator's non-split kernel), :1116-1297 (split combine, here combine_rows_kernel).
+// Every K/V access is bounded by a buffer descriptor that ends at the sequence's visible length.
+#include "attn_common.h"
+
+namespace vattn_k {
+
+constexpr float kDeferLog2 = 6.0f;      // P stays below 2^6 between rescales (f16 / bf16 keep their relative precision)
+
+// ---- LDS-DMA: one 1-KiB piece (64 lanes x 16 bytes) of a K or V tile per call ----
+// lds_addr: wave-uniform LDS byte address of the piece; rsrc: buffer descriptor of the tile, bounded at the visible rows; voff:
+// per-lane byte offset inside the tile.  A lane whose offset lies beyond the descriptor fetches nothing (zeros).  s_nop 0 after
+// the M0 write is the M0 -> LDS-DMA hazard; the _first form opens with s_nop 4 for a descriptor whose SGPRs were written by a
+// VALU readfirstlane (cdna guide §5.7).  The compiler's wait-count pass does not see these loads: waits are counted by hand.
+__device__ __forceinline__ void dma_piece(unsigned lds_addr, u32x4 rsrc, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(lds_addr), "s"(rsrc), "v"(voff) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_piece_first(unsigned lds_addr, u32x4 rsrc, unsigned voff) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(lds_addr), "s"(rsrc), "v"(voff) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4 tile_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;     // stride 0, no swizzle
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);                             // num_records (bytes): the bound
+    r[3] = 0x00020000u;                                                       // raw buffer, 32-bit data format
+    return r;
+}
+
+// ---- matrix instructions with the register FILE of every operand fixed by the constraint (cdna guide §5.7) ----
+// S^T accumulators live in architectural VGPRs (the softmax VALU reads them), O^T accumulators and the Q^T fragments in the
+// accumulator half of the 512-entry file; hipcc's own allocation of a 512-register kernel shuttles all of them through
+// v_accvgpr_read/write (measured: 2 700 copies and 324 spills in the builtin version of this kernel).
+// hipcc does not pad hazards around inline asm: callers keep MFMA results away from VALU readers by program order (an 8-pass
+// MFMA result is readable >= 12 states later) and use the _NOP forms when an A/B/C operand was just written by the VALU.
+template <typename T> struct Mfma;
+#define VATTN_MFMA_STRUCT(TYPE, MNEM)                                                                                              \
+    template <> struct Mfma<TYPE> {                                                                                                \
+        using V8 = typename Tr<TYPE>::v8;                                                                                          \
+        /* D(vgpr) = A(vgpr) x B(agpr) + C(vgpr), D distinct from C */                                                             \
+        static __device__ __forceinline__ void qk_first(f32x16& d, V8 a, V8 b, const f32x16& c) {                                  \
+            asm volatile(MNEM " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));                                              \
+        }                                                                                                                          \
+        static __device__ __forceinline__ void qk_first_nop(f32x16& d, V8 a, V8 b, const f32x16& c) {                              \
+            asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));                                \
+        }                                                                                                                          \
+        static __device__ __forceinline__ void qk_acc(f32x16& d, V8 a, V8 b) {                                                     \
+            asm volatile(MNEM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));                                                       \
+        }                                                                                                                          \
+        /* O(agpr) += A(vgpr) x B(vgpr) */                                                                                         \
+        static __device__ __forceinline__ void pv(f32x16& o, V8 a, V8 b) {                                                         \
+            asm volatile(MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                                       \
+        }                                                                                                                          \
+        static __device__ __forceinline__ void pv_nop(f32x16& o, V8 a, V8 b) {                                                     \
+            asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                         \
+        }                                                                                                                          \
+    };
+VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16")
+VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16")
+#undef VATTN_MFMA_STRUCT
+// one scalar f32 add that the SLP vectoriser cannot pack into v_pk_add_f32 (packed f32 VALU beside MFMAs costs more than two
+// plain adds, MI355X_MICROARCH "price of one filler")
+__device__ __forceinline__ float add1(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// exp2 IN PLACE: the S' register becomes the P register (the builtin form lets the allocator give P fresh registers, and a
+// second copy of the tile's 64 scores does not fit the architectural half of the register file)
+// two scores -> probabilities in place + their sum into `acc`, one statement: the trans -> VALU wait state is written out
+#define EXP2_PAIR_SUM(x0, x1, acc) \
+    asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\tv_add_f32 %2, %2, %0\n\tv_add_f32 %2, %2, %1" : "+v"(x0), "+v"(x1), "+v"(acc))
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
+    using X = Tr<T>;
+    using V8 = typename X::v8;
+    constexpr int HD = 128;
+    using S = PfSmem<HD>;
+    constexpr int BM = 256;
+    constexpr int KK = HD / 16;        // k-steps of the S^T MFMA chain
+    constexpr int DB = HD / 32;        // 32-wide d blocks of O^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring [2][16 KiB] then V ring [2][16 KiB]; LDS address 0
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+
+    int b, h, qb, split;
+    if (!wg_to_work(p, order, nqb, nsplit, b, h, qb, split)) return;
+    const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
+    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+    int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+    Lk = Lk > p.seqlen_k ? p.seqlen_k : Lk;                    // never beyond the cache view's rows
+    const int Sq = p.q_lens ? __builtin_amdgcn_readfirstlane(p.q_lens[b]) : p.seqlen_q;
+    const int64_t q_first = p.q_start ? (int64_t)__builtin_amdgcn_readfirstlane(p.q_start[b]) : 0;
+    const bool causal = p.is_causal != 0;
+    const int off = Lk - Sq;                                   // bottom-right alignment (mask.h:164-196)
+    const int q_wg0 = qb * BM;
+    if (q_wg0 >= Sq) return;                                   // shorter chunk than the grid was sized for (before any barrier)
+    const int qw0 = q_wg0 + wave * 64;                         // first query row of this wave
+
+    int n_end = Lk;
+    if (causal) n_end = min(Lk, q_wg0 + BM + off);             // last key any row of this block may see, +1
+    if (n_end < 0) n_end = 0;
+    const int nt_all = (n_end + PF_BN - 1) / PF_BN;
+    int tb = 0, nt = nt_all;                                   // this workgroup's key tiles [tb, nt)
+    if (nsplit > 1) {
+        const int per = (nt_all + nsplit - 1) / nsplit;
+        tb = min(nt_all, split * per);
+        nt = min(nt_all, tb + per);
+    }
+    const T* kbase = uniform_ptr((const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride);
+    const T* vbase = uniform_ptr((const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride);
+    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
+
+    // ---- DMA addressing (tile-invariant per-lane offsets) ----
+    // K piece pc = 4*wave + j holds rows 4*pc .. 4*pc+3: lane i -> row 4*pc + (i >> 4), LDS chunk i & 15 <- global chunk (i & 15) ^ (row & 15)
+    // V piece pc = 4*wave + j = (d block wave, keys 16*j .. 16*j+15): lane i -> key 16*j + (i >> 2), global chunk 4*wave + (i & 3)
+    unsigned koff[4], voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = 4 * (4 * wave + j) + (lane >> 4);
+        koff[j] = (unsigned)row * k_rs_bytes + (unsigned)(((lane & 15) ^ (row & 15)) << 4);
+        const int key = 16 * j + (lane >> 2);
+        voff[j] = (unsigned)key * v_rs_bytes + (unsigned)((4 * wave + (lane & 3)) << 4);
+    }
+    using M = Mfma<T>;
+    const unsigned k_lds_wave = (unsigned)(wave * 4096);                       // this wave's four K pieces inside a K slot
+    const unsigned v_lds_wave = (unsigned)(2 * S::kTileBytes + wave * 4096);   // ... and V pieces inside a V slot
+    auto k_rsrc = [&](int t) -> u32x4 {
+        int rem = Lk - t * PF_BN;
+        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
+        return tile_rsrc(kbase + (int64_t)t * PF_BN * p.k_row_stride, (unsigned)rem * k_rs_bytes);
+    };
+    auto v_rsrc = [&](int t) -> u32x4 {
+        int rem = Lk - t * PF_BN;
+        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
+        return tile_rsrc(vbase + (int64_t)t * PF_BN * p.v_row_stride, (unsigned)rem * v_rs_bytes);
+    };
+    auto dma_k_all = [&](int t) {      // K(t) -> K slot t & 1, this wave's four pieces
+        const u32x4 r = k_rsrc(t);
+        const unsigned l0 = k_lds_wave + (unsigned)((t & 1) * S::kTileBytes);
+        dma_piece_first(l0, r, koff[0]);
+        dma_piece(l0 + 1024, r, koff[1]);
+        dma_piece(l0 + 2048, r, koff[2]);
+        dma_piece(l0 + 3072, r, koff[3]);
+    };
+    auto dma_v_all = [&](int t) {
+        const u32x4 r = v_rsrc(t);
+        const unsigned l0 = v_lds_wave + (unsigned)((t & 1) * S::kTileBytes);
+        dma_piece_first(l0, r, voff[0]);
+        dma_piece(l0 + 1024, r, voff[1]);
+        dma_piece(l0 + 2048, r, voff[2]);
+        dma_piece(l0 + 3072, r, voff[3]);
+    };
+
+    // ---- prologue ----
+    // the V ring starts zeroed: a key row past the sequence's end that the DMA leaves untouched must hold finite data (its
+    // probability is exactly 0, and 0 x NaN would poison O)
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < (2 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + 2 * S::kTileBytes + (i * 256 + tid) * 16) = z;
+    }
+    __syncthreads();
+    dma_k_all(tb);
+    dma_v_all(tb);
+    dma_k_all(tb + 1);
+
+    // Q^T fragments (B operand of S^T = K.Q^T): slot (g, j) <-> d = 16*kk + 8*g + j; pre-scaled into the log2 domain
+    const float qscale = p.softmax_scale * kLog2e;
+    V8 qf[2][KK];
+#pragma unroll
+    for (int qc = 0; qc < 2; qc++) {
+        const int my_q = qw0 + 32 * qc + l31;
+        const T* qptr = (const T*)p.q + (p.q_start ? 0 : (int64_t)b * p.q_batch_stride) + (q_first + my_q) * p.q_row_stride + (int64_t)h * p.q_head_stride;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+            const V8 raw = as_v8<V8>(v);
+            V8 sc8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) sc8[j] = X::cvt((float)raw[j] * qscale);
+            qf[qc][kk] = sc8;
+            asm volatile("" : "+a"(qf[qc][kk]));       // materialise the fragment as ONE 4-register accumulator tuple, here
+        }
+    }
+
+    f32x16 o[DB][2];
+#pragma unroll
+    for (int i = 0; i < DB; i++)
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 negm[2];     // every element = -(running max) of the lane's query (log2 domain); C operand of the S^T chains
+    float l_run[2];     // lane-local partial row sums (the other half-lane holds the other 32 keys of every tile)
+#pragma unroll
+    for (int qc = 0; qc < 2; qc++) {
+        negm[qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        l_run[qc] = 0.f;
+    }
+
+    // LDS fragment addressing: one lane-dependent base per tensor + immediate offsets
+    const unsigned kfrag_lane = (unsigned)(l31 * S::kRowBytes);
+    const unsigned kswz = (unsigned)(l31 & 15);
+    auto kfrag = [&](const char* ksm, int f) -> V8 {                  // f = 2*kk + kb: K rows 32*kb + l31, d = 16*kk + 8*g ..
+        const int kk = f >> 1, kb = f & 1;
+        return *(const V8*)(ksm + kb * 32 * S::kRowBytes + kfrag_lane + (((unsigned)(2 * kk + g) ^ kswz) << 4));
+    };
+    const int i16 = lane & 15, dh = (lane >> 4) & 1;
+    const unsigned vfrag_lane = (unsigned)((4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2);
+    auto vfrag = [&](const char* vsm, int f) -> V8 {                  // f = 4*ks + db: keys 16*ks .. 16*ks+15, d block db
+        const int ks = f >> 2, db = f & 3;
+        const char* a1 = vsm + db * S::kVSubBytes + (16 * ks) * 64 + vfrag_lane;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
+        return join_tr<V8>(lo, hi);
+    };
+    // masks tile tt's scores in place (ragged end of the sequence / causal diagonal) — wave-uniform decision by the caller
+    auto mask_tile = [&](int tt, f32x16 (&s)[2][2]) {
+        const int n0 = tt * PF_BN;
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) {
+            const int my_q = qw0 + 32 * qc + l31;
+            const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;     // last visible key of this query
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = n0 + 32 * kb + 8 * (r >> 2) + 4 * g + (r & 3);
+                    if (key > lim) s[kb][qc][r] = -INFINITY;
+                }
+        }
+    };
+    auto needs_mask = [&](int tt) -> bool {
+        const int n0 = tt * PF_BN;
+        return (n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off));
+    };
+    auto row_max = [&](const f32x16 (&s)[2][2], int qc) -> float {
+        float m0 = fmaxf(s[0][qc][0], s[1][qc][0]);
+#pragma unroll
+        for (int r = 1; r < 16; r++) m0 = fmaxf(fmaxf(m0, s[0][qc][r]), s[1][qc][r]);     // v_max3_f32
+        return fmaxf(m0, swap_halves(m0));
+    };
+    // moves the running maximum of query block qc up by delta >= 0 (per lane): everything still at the old scale — O, l and the
+    // not yet exponentiated S' of the tile that triggered it — is rescaled exactly once (cdna guide T13)
+    auto raise_max = [&](int qc, float delta, f32x16 (&s)[2][2]) {
+        const float alpha = fast_exp2(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            negm[qc][r] -= delta;
+            s[0][qc][r] -= delta;
+            s[1][qc][r] -= delta;
+        }
+#pragma unroll
+        for (int i = 0; i < DB; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha;
+        l_run[qc] *= alpha;
+    };
+    // P(t) -> the PV B-operand fragment of key slice ks for query block qc: slot (g, j) <-> P registers 8*(ks&1) + j of key block ks>>1
+    auto pack_p = [&](const f32x16 (&pt)[2][2], int ks, int qc) -> V8 {
+        V8 r;
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = X::cvt(pt[ks >> 1][qc][8 * (ks & 1) + j]);
+        return r;
+    };
+
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's pieces of K(tb) landed; V(tb), K(tb+1) may still fly
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 sc[2][2];      // S'(t): scores of the current tile minus the running max, log2 domain; becomes P(t) in place
+    f32x16 sd[2][2];
+    {
+        const char* ksm = smem + (tb & 1) * S::kTileBytes;
+#pragma unroll
+        for (int f = 0; f < 2 * KK; f++) {
+            const V8 a = kfrag(ksm, f);
+#pragma unroll
+            for (int qc = 0; qc < 2; qc++) {
+                if (f < 2) M::qk_first_nop(sc[f & 1][qc], a, qf[qc][f >> 1], negm[qc]);
+                else M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // the last MFMA results are VALU-readable from here
+        SCHED_FENCE();
+        if (needs_mask(tb)) mask_tile(tb, sc);
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) {
+            const float mx = row_max(sc, qc);
+            const float delta = (mx == -INFINITY) ? 0.f : mx;       // softmax.h: a fully masked row keeps a zero reference
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                negm[qc][r] = -delta;
+                sc[0][qc][r] -= delta;
+                sc[1][qc][r] -= delta;
+            }
+        }
+    }
+
+    // One tile step of the wave.  cur holds S'(t) on entry and P(t) afterwards, nxt receives S'(t+1).
+    auto step = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) {
+        // K(t+1) and V(t) were issued one iteration ago; after the barrier every wave has finished reading K(t) and V(t-1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* ksm = smem + ((t + 1) & 1) * S::kTileBytes;
+        const char* vsm = smem + 2 * S::kTileBytes + (t & 1) * S::kTileBytes;
+        const u32x4 rk = k_rsrc(t + 2);      // -> slot of K(t);   past the last tile: zero-record descriptor, nothing is fetched
+        const u32x4 rv = v_rsrc(t + 1);      // -> slot of V(t-1)
+        const unsigned lk0 = k_lds_wave + (unsigned)((t & 1) * S::kTileBytes);
+        const unsigned lv0 = v_lds_wave + (unsigned)(((t + 1) & 1) * S::kTileBytes);
+        {
+            // Every wave runs the SAME straight-line body for every tile of the workgroup (the barrier makes the waves wait for each
+            // other anyway): a tile that lies wholly beyond a wave's causal limit is masked to -inf, contributes P = 0, and
+            // leaves the running maximum alone; past the last tile S'(t+1) is computed from a zero-filled K slot and never used.
+            // ---------------- 64 groups of { MFMA ; fragment read ahead ; a slice of softmax VALU } ----------------
+            // phase A: S'(t+1) = K(t+1).Q^T - m   (32 MFMAs: k-step kk = i>>2, key block (i>>1)&1, query block i&1)
+            //          || P(t) = exp2(S'(t)) for the first 48 of the 64 scores of the lane, row sums, the tile's DMA issue
+            V8 kf[3];
+            kf[0] = kfrag(ksm, 0);
+            kf[1] = kfrag(ksm, 1);
+            float ps0 = 0.f, ps1 = 0.f;
+            auto exp_pair = [&](int e) {         // scores 2e, 2e+1 in PV consumption order: key block e>>4, query block (e>>3)&1 ... see below
+                // order: [kb][half][qc][4 pairs]: registers 8*half + 2*q4 .. +1 of cur[kb][qc]
+                const int kb = e >> 4, half = (e >> 3) & 1, qc = (e >> 2) & 1, q4 = e & 3;
+                const int r0 = 8 * half + 2 * q4;
+                if (qc == 0) EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps0);
+                else EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps1);
+            };
+            SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int f = i >> 1, qc = i & 1;
+                if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1], negm[qc]);
+                else M::qk_acc(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1]);
+                if ((i & 1) == 0 && f + 2 < 2 * KK) kf[(f + 2) % 3] = kfrag(ksm, f + 2);
+                if (i == 0) dma_piece_first(lk0, rk, koff[0]);
+                if (i == 1) dma_piece(lk0 + 1024, rk, koff[1]);
+                if (i == 2) dma_piece(lk0 + 2048, rk, koff[2]);
+                if (i == 3) dma_piece(lk0 + 3072, rk, koff[3]);
+                if (i == 4) dma_piece_first(lv0, rv, voff[0]);
+                if (i == 5) dma_piece(lv0 + 1024, rv, voff[1]);
+                if (i == 6) dma_piece(lv0 + 2048, rv, voff[2]);
+                if (i == 7) dma_piece(lv0 + 3072, rv, voff[3]);
+                if (i < 24) exp_pair(i);                 // pairs 0..23: all of key block 0, the first half of key block 1
+                SCHED_FENCE();
+            }
+            // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
+            //          || the remaining 16 scores, f16 packing of P(t) one key slice ahead, row max of S'(t+1)
+            V8 vf[3];
+            V8 pf[2][2];
+            vf[0] = vfrag(vsm, 0);
+            vf[1] = vfrag(vsm, 1);
+            pf[0][0] = pack_p(cur, 0, 0);
+            pf[0][1] = pack_p(cur, 0, 1);
+            float mx0 = -INFINITY, mx1 = -INFINITY;
+            SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const int f = j >> 1, ks = j >> 3, qc = j & 1;
+                if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
+                else M::pv(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);
+                if ((j & 1) == 0 && f + 2 < 16) vf[(f + 2) % 3] = vfrag(vsm, f + 2);
+                if (j < 8) exp_pair(24 + j);             // pairs 24..31: the second half of key block 1 (consumed by key slice 3)
+                // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 2..5 of a slice)
+                if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
+                if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
+                // row max of S'(t+1): 2 chains x 16 v_max3, from group 6 on (>= 6 MFMAs after the last S^T MFMA was issued)
+                if (j >= 8 && j < 24) {
+                    const int r = j - 8;
+                    mx0 = fmaxf(fmaxf(mx0, nxt[0][0][r]), nxt[1][0][r]);
+                    mx1 = fmaxf(fmaxf(mx1, nxt[0][1][r]), nxt[1][1][r]);
+                }
+                SCHED_FENCE();
+            }
+            l_run[0] = add1(l_run[0], ps0);
+            l_run[1] = add1(l_run[1], ps1);
+            mx0 = fmaxf(mx0, swap_halves(mx0));
+            mx1 = fmaxf(mx1, swap_halves(mx1));
+            if (needs_mask(t + 1)) {                     // ragged end / causal diagonal: wave-uniform, the last tiles only
+                mask_tile(t + 1, nxt);
+                mx0 = row_max(nxt, 0);
+                mx1 = row_max(nxt, 1);
+            }
+            if (__builtin_amdgcn_ballot_w64(fmaxf(mx0, mx1) > kDeferLog2) != 0) {      // rare: a row's maximum grew by > 2^6
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");                        // every PV result has landed in O
+                SCHED_FENCE();
+                raise_max(0, fmaxf(mx0, 0.f), nxt);
+                raise_max(1, fmaxf(mx1, 0.f), nxt);
+                SCHED_FENCE();
+                asm volatile("s_nop 3" ::: "memory");                                    // accvgpr writes -> next MFMA read
+            }
+        }
+    };
+    for (int t = tb; t < nt; t += 2) {
+        step(t, sc, sd);
+        if (t + 1 < nt) step(t + 1, sd, sc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // trailing DMA retired (nothing may land in LDS of
+    SCHED_FENCE();                                                                // a later workgroup); last PV results readable
+
+    // ---- epilogue: O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
+    const float sc_ln = p.softmax_scale;
+#pragma unroll
+    for (int qc = 0; qc < 2; qc++) {
+        const int my_q = qw0 + 32 * qc + l31;
+        const float l_tot = l_run[qc] + swap_halves(l_run[qc]);
+        const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+        const float m_log2 = -negm[qc][0];                    // running max of softmax_scale*log2e*q.k
+        if (my_q < Sq && nsplit > 1) {
+            // KV-split: normalised fp32 partial + its log2-domain LSE; combine_rows_kernel merges the nsplit partials of a row
+            const int64_t row = (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
+            float* opart = (float*)p.workspace + row * HD;
+            float* lpart = (float*)p.workspace + (int64_t)nsplit * p.b * p.seqlen_q * p.h * HD;
+#pragma unroll
+            for (int db = 0; db < DB; db++)
+#pragma unroll
+                for (int tq = 0; tq < 4; tq++) {
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
+                    *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                }
+            if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_log2 + __log2f(l_tot));
+        } else if (my_q < Sq) {
+            T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + my_q) * p.o_row_stride + (int64_t)h * p.o_head_stride;
+            if (((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0) {
+                // 16-byte stores: half-lane pairs exchange 8-byte groups through v_permlane32_swap (see prefill_kernels.hip)
+#pragma unroll
+                for (int db = 0; db < DB; db++)
+#pragma unroll
+                    for (int pr = 0; pr < 2; pr++) {
+                        typename X::v4 we, wo;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            we[e] = X::cvt(o[db][qc][4 * (2 * pr) + e] * inv);
+                            wo[e] = X::cvt(o[db][qc][4 * (2 * pr + 1) + e] * inv);
+                        }
+                        uint2 ue, uo;
+                        __builtin_memcpy(&ue, &we, 8);
+                        __builtin_memcpy(&uo, &wo, 8);
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
+                        *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+            } else {
+#pragma unroll
+                for (int db = 0; db < DB; db++)
+#pragma unroll
+                    for (int tq = 0; tq < 4; tq++) {
+                        typename X::v4 w;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][qc][4 * tq + e] * inv);
+                        *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+                    }
+            }
+            if (p.softmax_lse && g == 0) {
+                // natural-log LSE of scale*QK^T; +inf for fully masked rows (flash convention)
+                const float lse = (l_tot == 0.f) ? INFINITY : (m_log2 + __log2f(l_tot)) * 0.6931471805599453f;
+                p.softmax_lse[((int64_t)b * p.h + h) * p.seqlen_q + my_q] = lse;
+            }
+        }
+    }
+    (void)sc_ln;
+}
+
+// host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
+dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
+
+template <typename T> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+    const int nqb = (p->seqlen_q + 255) / 256;
+    int order;
+    dim3 grid = prefill_grid(p, nqb, &order);
+    if (nsplit > 1) {
+        if (order == 0) {
+            vattn_attn_params q = *p;
+            q.variant = (p->variant & ~(3 << 5)) | (2 << 5);
+            grid = prefill_grid(&q, nqb, &order);
+        }
+        grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
+    }
+    static const bool once = [] {
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((prefill64_kernel<T>), grid, dim3(256), PfSmem<128>::kTotal, st, *p, order, nqb, nsplit);
+}
+
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+    if (p->dtype == VATTN_DTYPE_F16) launch64_t<_Float16>(p, st, nsplit);
+    else launch64_t<__bf16>(p, st, nsplit);
+}
+
+}  // namespace vattn_k

@@ -15,7 +15,6 @@ namespace vattn_k {
 // prefill
 // ============================================================================================
 
-constexpr int PF_BN = 64;              // keys per tile
 // Debug-only ablation switch for tools/kbench.py (cdna guide §5.4: "ablate before optimizing"); the product
 // build leaves it at 0.  1: exp2 replaced by a multiply; 2: V^T fragments not read from LDS; 3: K fragments
 // not read from LDS; 4: no global loads / LDS stores of the next tile; 5: no per-tile barrier; 6: no softmax VALU at all
@@ -26,55 +25,6 @@ constexpr int PF_BN = 64;              // keys per tile
 #define VATTN_ABLATE_MASK (VATTN_ABLATE ? (1 << VATTN_ABLATE) : 0)
 #endif
 #define ABL(k) ((VATTN_ABLATE_MASK >> (k)) & 1)
-
-template <int HD> struct PfSmem {
-    static constexpr int kRowBytes = HD * 2;
-    static constexpr int kTileBytes = PF_BN * HD * 2;           // K tile == V tile size
-    static constexpr int kBufBytes = 2 * kTileBytes;            // K + V
-    static constexpr int kTotal = 2 * kBufBytes;                // double buffered
-    static constexpr int kVSubBytes = PF_BN * 64;               // one [64 keys][32 d] sub-tile
-};
-
-// Workgroup -> (batch entry, head, query block).  The dispatcher hands consecutive workgroup ids to consecutive XCDs
-// (id & 7), each with its own L2, and starts them in id order.  order 2 (default) makes every XCD stream ONE kv head (its
-// L2 then holds a single K/V stream that the G query heads x neighbouring query blocks running there share) and walks the
-// query blocks heaviest-first across ALL heads, so the workgroups running at any time have near-equal lengths and move
-// down K/V in step.  order 1: heaviest-first across heads without the XCD grouping.  order 0: grid (query block, head,
-// batch) - block-major per head (its tail is one head's heaviest blocks: 20-40 % slower on whole-prompt shapes).
-// Returns false for the padding workgroups of the 1-D grids.
-// KV-split (nsplit > 1, 1-D grids only): the grid is nsplit times larger; every run of 8 consecutive base ids (one per XCD) is
-// repeated nsplit times, so the splits of a work item stay on its XCD and start together.
-__device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order, int nqb, int nsplit, int& b, int& h, int& qb, int& split) {
-    split = 0;
-    if (order == 0) {
-        b = blockIdx.z; h = blockIdx.y; qb = (int)gridDim.x - 1 - (int)blockIdx.x;
-        return true;
-    }
-    int L = blockIdx.x;
-    if (nsplit > 1) {
-        const int grp = L >> 3;
-        split = grp % nsplit;
-        L = ((grp / nsplit) << 3) | (L & 7);
-    }
-    const int G = p.h / p.h_k;
-    if (order == 2) {
-        const int per = 8 / p.h_k;                         // XCDs per kv head (launch guarantees 8 % h_k == 0)
-        const int xcd = L & 7;
-        int t = (L >> 3) * per + xcd / p.h_k;
-        const int g = t % G; t /= G;
-        b = t % p.b;
-        const int qbr = t / p.b;
-        if (qbr >= nqb) return false;
-        h = (xcd % p.h_k) * G + g;
-        qb = nqb - 1 - qbr;
-        return true;
-    }
-    h = L % p.h;
-    const int t = L / p.h;
-    b = t % p.b;
-    qb = nqb - 1 - t / p.b;
-    return t / p.b < nqb;
-}
 
 // WAVES waves per workgroup, each owning QC blocks of 32 query rows (BM = 32*QC*WAVES rows per workgroup).
 // QC = 2 halves the LDS fragment traffic per flop (each K / V^T fragment read feeds two MFMAs) at the price
@@ -780,7 +730,8 @@ dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out) {
 }
 
 // Prefill plan: tiling and KV split, decided on the host from the shapes (used by the launch and by the workspace query).
-//  tiling  0/1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows, 4 = 4 waves x 32 rows, 6 = hand-interleaved 8-wave kernel.
+//  tiling  0/1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows (compiler-allocated, spills), 4 = 4 waves x 32 rows, 6 = hand-interleaved
+//          8-wave kernel, 7 = prefill64_kernel (prefill64_kernels.hip: 4 waves x 64 rows, LDS-DMA ring, in-wave software pipeline).
 //  nsplit  > 1 when the grid would leave CUs idle (tensor-parallel shards with few heads, short chunks): every work item's
 //          key range is divided over nsplit workgroups, fp32 partials go through the workspace, combine_kernel merges them.
 struct PrefillPlan { int tiling; int nsplit; };
@@ -791,7 +742,7 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     const bool auto_tiling = pl.tiling == 0;
     // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
     // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
-    if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6))) pl.tiling = 1;
+    if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6 || pl.tiling == 7))) pl.tiling = 1;
     if (pl.tiling == 6 && p->q_lens) pl.tiling = 1;                  // the interleaved kernel has no batched-chunk form
     if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
     // keys an average query block sees; without a host-side length only the chunk itself is certain
@@ -886,7 +837,10 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     if (pl.nsplit > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "KV-split prefill needs a workspace (vattn_attn_workspace_bytes)");
     bool launched = false;
     if constexpr (HD == 128) {
-        if (pl.tiling == 2) {
+        if (pl.tiling == 7) {
+            launch_prefill64(p, st, pl.nsplit);
+            launched = true;
+        } else if (pl.tiling == 2) {
             launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);
             launched = true;
         } else if (pl.tiling == 6) {
