@@ -118,9 +118,10 @@ def test_prefill_workgroup_orders(Hq, Hkv):
                                       causal=True, _variant=variant)
         torch.cuda.synchronize()
         _check(out, ref64, ref32, torch.float16, "order variant %d" % variant)
-        outs.append(out.cpu())
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
+        outs.append((variant, out.cpu()))
+    for v, o in outs[1:]:      # the mapping must not change a single bit: same kernel, same per-row arithmetic (12 / 14 are other kernels)
+        base = next(x for vv, x in outs if (vv & 14) == (v & 14))
+        assert torch.equal(o, base), "variant %d" % v
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])

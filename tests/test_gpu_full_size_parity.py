@@ -35,7 +35,7 @@ def _decode_case(B, ctx, Hq, Hkv, seed):
     vn = torch.randn(B, 1, Hkv, D).half()
     # the reference's decode call: ragged lengths near the context limit, slots picked by cache_batch_idx, [:, :max_len] view
     lens = torch.tensor([ctx - 1 - 37 * i for i in range(B)], dtype=torch.int32)
-    idx = torch.tensor([(3 * i + 1) % slots for i in range(B)], dtype=torch.int32)
+    idx = torch.randperm(slots)[:B].to(torch.int32)                                      # distinct slots, shuffled
     assert len(set(idx.tolist())) == B
     max_len = int(lens.max()) + 1
     kg, vg = kc.to(DEV), vc.to(DEV)

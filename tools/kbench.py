@@ -58,7 +58,7 @@ def prefill(variant):
                                 ("llama70b/tp8 chunk2k@30k", 8, 1, 2048, 30720), ("llama70b/tp8 chunk512@16k", 8, 1, 512, 15872),
                                 ("yi34b/tp2 chunk1k@64k", 28, 4, 1024, 64512), ("llama70b/tp8 4k", 8, 1, 4096, 0),
                                 ("llama70b/tp8 2k", 8, 1, 2048, 0), ("llama8b chunk512@8k", 32, 8, 512, 7680)]:
-        if ONLY and ONLY not in name:
+        if ONLY and not any(o in name for o in ONLY.split(",")):
             continue
         torch.manual_seed(0)
         q = torch.randn(1, n, Hq, 128, device=DEV, dtype=DTYPE)
@@ -143,7 +143,7 @@ if __name__ == "__main__":
     torch.zeros(1, device=DEV)
     if "prefill" in what:
         for v in VARIANTS:
-            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3], {0: "8 waves x 32 rows (default)", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups", 7: "4 waves x 64 rows, LDS-DMA ring, in-wave software pipeline (prefill64)"}[(v >> 1) & 7]))
+            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3] + (", prefill64 build %d" % ((v >> 8) & 15) if (v >> 8) & 15 else ""), {0: "default plan", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups", 7: "4 waves x 64 rows, LDS-DMA ring, in-wave software pipeline (prefill64)"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
         decode(variant)

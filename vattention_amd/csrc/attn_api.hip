@@ -138,6 +138,35 @@ __global__ void selftest_kernel(int* res, const unsigned* gsrc) {
     }
 }
 
+// [7] (informational) LDS-DMA into an LDS address beyond 64 KiB (the destination base travels in M0): 1 KiB is sent to byte offset
+// 72 KiB of a 96-KiB dynamic allocation; reports 1 + the KiB offset the data is found at (73 = where it was sent), 0 = nowhere
+__global__ void selftest_dma_high_kernel(int* res, const unsigned* gsrc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned big[];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < (96 << 10) / 4; i += 64) big[i] = 0xCDCDCDCDu;
+    __syncthreads();
+    const unsigned long long a = (unsigned long long)gsrc;
+    u32x4 r0;
+    r0[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r0[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+    r0[2] = 2048u;
+    r0[3] = 0x00020000u;
+    const unsigned l0 = (unsigned)(size_t)LDS_PTR(unsigned, big) + (72u << 10);
+    const unsigned v0 = (unsigned)(lane * 16);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(l0), "s"(r0), "v"(v0) : "memory", "m0");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) {
+        int found = 0;
+        for (int kib = 0; kib < 96; kib++) {
+            bool ok = true;
+            for (int w = 0; w < 256 && ok; w++) ok = big[kib * 256 + w] == (unsigned)w;
+            if (ok) { found = kib + 1; break; }
+        }
+        res[7] = found;
+    }
+}
+
 thread_local std::string g_err;
 int fail(int code, const char* msg) {
     g_err = msg;
@@ -205,6 +234,8 @@ int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
     if (hipMalloc(&gsrc, sizeof(hsrc)) != hipSuccess) { hipFree(d); return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed"); }
     hipMemcpyAsync(gsrc, hsrc, sizeof(hsrc), hipMemcpyHostToDevice, st);
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d, (const unsigned*)gsrc);
+    (void)hipFuncSetAttribute((const void*)selftest_dma_high_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
+    hipLaunchKernelGGL(selftest_dma_high_kernel, dim3(1), dim3(64), 96 << 10, st, d, (const unsigned*)gsrc);
     int h[8] = {0};
     hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -214,7 +245,7 @@ int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
     int bad = 0;
     for (int i = 0; i < 8; i++) {
         if (detail_out) detail_out[i] = h[i];
-        if (i != 6) bad |= h[i];           // [6] reports the out-of-range behaviour of LDS-DMA, it is not an assumption
+        if (i < 6) bad |= h[i];            // [6], [7] report LDS-DMA behaviour (out-of-range lanes, destinations beyond 64 KiB)
     }
     return bad ? fail(VATTN_K_ERR_INVALID, "hardware layout assumption violated") : VATTN_K_OK;
 }

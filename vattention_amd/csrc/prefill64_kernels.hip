@@ -88,9 +88,22 @@ __device__ __forceinline__ float add1(float a, float b) {
 // two scores -> probabilities in place + their sum into `acc`, one statement: the trans -> VALU wait state is written out
 #define EXP2_PAIR_SUM(x0, x1, acc) \
     asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\tv_add_f32 %2, %2, %0\n\tv_add_f32 %2, %2, %1" : "+v"(x0), "+v"(x1), "+v"(acc))
+// the same with the softmax scale applied first (EXACT mode); sc is wave-uniform
+#define EXP2_PAIR_SUM_SCALED(x0, x1, acc, sc)                                                                                     \
+    asm("v_mul_f32 %0, %3, %0\n\tv_mul_f32 %1, %3, %1\n\tv_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\tv_add_f32 %2, %2, %0\n\t" \
+        "v_add_f32 %2, %2, %1"                                                                                                     \
+        : "+v"(x0), "+v"(x1), "+v"(acc)                                                                                            \
+        : "s"(sc))
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <typename T>
+// ABL (timing ablations for tools/kbench.py, results are WRONG when non-zero; the product instantiates 0): bit 0 no LDS-DMA in the
+// steady state, bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the
+// first MFMAs of a phase, bit 5 no f16 packing.
+// NA: exp2 pairs (of the tile's 32) evaluated in phase A, the rest in phase B.
+// EXACT: Q is NOT pre-scaled; the scale is applied to S' in fp32 before exp2 (one more VALU per score), exactly the reference's
+// exp2((s - m) * scale * log2e) (softmax.h:69-94).  Pre-scaling rounds softmax_scale*log2e*q to the I/O dtype: one more
+// half-ulp error on q, measured 2.2x the reference-numerics error on a 410-key case against a 2x allowance.
+template <typename T, int ABL, int NA, bool EXACT>
 __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
     using X = Tr<T>;
     using V8 = typename X::v8;
@@ -190,7 +203,9 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     dma_k_all(tb + 1);
 
     // Q^T fragments (B operand of S^T = K.Q^T): slot (g, j) <-> d = 16*kk + 8*g + j; pre-scaled into the log2 domain
-    const float qscale = p.softmax_scale * kLog2e;
+    const float qscale = EXACT ? 1.0f : p.softmax_scale * kLog2e;
+    const float escale = EXACT ? p.softmax_scale * kLog2e : 1.0f;      // applied to S' before exp2
+    const float defer_thr = kDeferLog2 / escale;                        // the deferral threshold in the units of S'
     V8 qf[2][KK];
 #pragma unroll
     for (int qc = 0; qc < 2; qc++) {
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             const V8 raw = as_v8<V8>(v);
             V8 sc8;
 #pragma unroll
-            for (int j = 0; j < 8; j++) sc8[j] = X::cvt((float)raw[j] * qscale);
+            for (int j = 0; j < 8; j++) sc8[j] = EXACT ? raw[j] : X::cvt((float)raw[j] * qscale);
             qf[qc][kk] = sc8;
             asm volatile("" : "+a"(qf[qc][kk]));       // materialise the fragment as ONE 4-register accumulator tuple, here
         }
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // moves the running maximum of query block qc up by delta >= 0 (per lane): everything still at the old scale — O, l and the
     // not yet exponentiated S' of the tile that triggered it — is rescaled exactly once (cdna guide T13)
     auto raise_max = [&](int qc, float delta, f32x16 (&s)[2][2]) {
-        const float alpha = fast_exp2(-delta);
+        const float alpha = fast_exp2(-delta * escale);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             negm[qc][r] -= delta;
@@ -323,8 +338,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // One tile step of the wave.  cur holds S'(t) on entry and P(t) afterwards, nxt receives S'(t+1).
     auto step = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) {
         // K(t+1) and V(t) were issued one iteration ago; after the barrier every wave has finished reading K(t) and V(t-1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 8)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         const char* ksm = smem + ((t + 1) & 1) * S::kTileBytes;
         const char* vsm = smem + 2 * S::kTileBytes + (t & 1) * S::kTileBytes;
         const u32x4 rk = k_rsrc(t + 2);      // -> slot of K(t);   past the last tile: zero-record descriptor, nothing is fetched
@@ -346,8 +363,14 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 // order: [kb][half][qc][4 pairs]: registers 8*half + 2*q4 .. +1 of cur[kb][qc]
                 const int kb = e >> 4, half = (e >> 3) & 1, qc = (e >> 2) & 1, q4 = e & 3;
                 const int r0 = 8 * half + 2 * q4;
-                if (qc == 0) EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps0);
-                else EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps1);
+                if (ABL & 2) return;
+                if (EXACT) {
+                    if (qc == 0) EXP2_PAIR_SUM_SCALED(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps0, escale);
+                    else EXP2_PAIR_SUM_SCALED(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps1, escale);
+                } else {
+                    if (qc == 0) EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps0);
+                    else EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps1);
+                }
             };
             SCHED_FENCE();
 #pragma unroll
@@ -355,16 +378,21 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 const int f = i >> 1, qc = i & 1;
                 if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1], negm[qc]);
                 else M::qk_acc(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1]);
-                if ((i & 1) == 0 && f + 2 < 2 * KK) kf[(f + 2) % 3] = kfrag(ksm, f + 2);
-                if (i == 0) dma_piece_first(lk0, rk, koff[0]);
-                if (i == 1) dma_piece(lk0 + 1024, rk, koff[1]);
-                if (i == 2) dma_piece(lk0 + 2048, rk, koff[2]);
-                if (i == 3) dma_piece(lk0 + 3072, rk, koff[3]);
-                if (i == 4) dma_piece_first(lv0, rv, voff[0]);
-                if (i == 5) dma_piece(lv0 + 1024, rv, voff[1]);
-                if (i == 6) dma_piece(lv0 + 2048, rv, voff[2]);
-                if (i == 7) dma_piece(lv0 + 3072, rv, voff[3]);
-                if (i < 24) exp_pair(i);                 // pairs 0..23: all of key block 0, the first half of key block 1
+                if ((i & 1) == 0 && f + 2 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + 2) % 3] = kfrag(ksm, f + 2);
+                if (!(ABL & 1)) {
+                    if (i == 0) dma_piece_first(lk0, rk, koff[0]);
+                    if (i == 1) dma_piece(lk0 + 1024, rk, koff[1]);
+                    if (i == 2) dma_piece(lk0 + 2048, rk, koff[2]);
+                    if (i == 3) dma_piece(lk0 + 3072, rk, koff[3]);
+                    if (i == 4) dma_piece_first(lv0, rv, voff[0]);
+                    if (i == 5) dma_piece(lv0 + 1024, rv, voff[1]);
+                    if (i == 6) dma_piece(lv0 + 2048, rv, voff[2]);
+                    if (i == 7) dma_piece(lv0 + 3072, rv, voff[3]);
+                }
+                // exp2 pairs 0 .. NA-1 spread evenly over the 32 groups of this phase (pair e must be done before key slice e>>3 is packed)
+#pragma unroll
+                for (int e = 0; e < NA; e++)
+                    if ((e * 32) / NA == i) exp_pair(e);
                 SCHED_FENCE();
             }
             // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
@@ -382,13 +410,23 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 const int f = j >> 1, ks = j >> 3, qc = j & 1;
                 if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
                 else M::pv(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);
-                if ((j & 1) == 0 && f + 2 < 16) vf[(f + 2) % 3] = vfrag(vsm, f + 2);
-                if (j < 8) exp_pair(24 + j);             // pairs 24..31: the second half of key block 1 (consumed by key slice 3)
-                // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 2..5 of a slice)
-                if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
-                if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
-                // row max of S'(t+1): 2 chains x 16 v_max3, from group 6 on (>= 6 MFMAs after the last S^T MFMA was issued)
-                if (j >= 8 && j < 24) {
+                if ((j & 1) == 0 && f + 2 < 16 && !((ABL & 16) && f >= 1)) vf[(f + 2) % 3] = vfrag(vsm, f + 2);
+                // the remaining exp2 pairs NA .. 31: pair e belongs to key slice e >> 3, whose P fragments are packed in groups
+                // 8*(e>>3) - 4 and - 2, so the pairs of slice s are spread over the groups before 8*s - 4
+                {
+                    constexpr int NB = 32 - NA;          // pairs left for this phase, spread over its first 20 groups (slice 3 is packed
+                    constexpr int G_END = 20;            // in groups 20 and 22; earlier slices come first because pairs go in order)
+#pragma unroll
+                    for (int e = NA; e < 32; e++)
+                        if (((e - NA) * G_END) / (NB > 0 ? NB : 1) == j) exp_pair(e);
+                }
+                // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
+                if (!(ABL & 32)) {
+                    if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
+                    if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
+                }
+                // row max of S'(t+1): 2 chains x 16 v_max3, from group 8 on (>= 8 MFMAs after the last S^T MFMA was issued)
+                if (!(ABL & 4) && j >= 8 && j < 24) {
                     const int r = j - 8;
                     mx0 = fmaxf(fmaxf(mx0, nxt[0][0][r]), nxt[1][0][r]);
                     mx1 = fmaxf(fmaxf(mx1, nxt[0][1][r]), nxt[1][1][r]);
@@ -404,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 mx0 = row_max(nxt, 0);
                 mx1 = row_max(nxt, 1);
             }
-            if (__builtin_amdgcn_ballot_w64(fmaxf(mx0, mx1) > kDeferLog2) != 0) {      // rare: a row's maximum grew by > 2^6
+            if (__builtin_amdgcn_ballot_w64(fmaxf(mx0, mx1) > defer_thr) != 0) {      // rare: a row's maximum grew by > 2^6
                 asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");                        // every PV result has landed in O
                 SCHED_FENCE();
                 raise_max(0, fmaxf(mx0, 0.f), nxt);
@@ -428,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         const int my_q = qw0 + 32 * qc + l31;
         const float l_tot = l_run[qc] + swap_halves(l_run[qc]);
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-        const float m_log2 = -negm[qc][0];                    // running max of softmax_scale*log2e*q.k
+        const float m_log2 = -negm[qc][0] * escale;           // running max of softmax_scale*log2e*q.k
         if (my_q < Sq && nsplit > 1) {
             // KV-split: normalised fp32 partial + its log2-domain LSE; combine_rows_kernel merges the nsplit partials of a row
             const int64_t row = (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
@@ -489,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 // host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
-template <typename T> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+template <typename T, int ABL, int NA, bool EXACT> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -502,16 +540,35 @@ template <typename T> static void launch64_t(const vattn_attn_params* p, hipStre
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T>), grid, dim3(256), PfSmem<128>::kTotal, st, *p, order, nqb, nsplit);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, EXACT>), grid, dim3(256), PfSmem<128>::kTotal, st, *p, order, nqb, nsplit);
 }
 
+// variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1 = pre-scaled Q (one VALU less per score, 2.2x the
+// reference-numerics error on short contexts); 2 / 3 = 20 / 16 of the 32 exp2 pairs in phase A; 4.. = timing ablations (wrong results)
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
-    if (p->dtype == VATTN_DTYPE_F16) launch64_t<_Float16>(p, st, nsplit);
-    else launch64_t<__bf16>(p, st, nsplit);
+    const int sel = (p->variant >> 8) & 15;
+    if (p->dtype == VATTN_DTYPE_BF16) {
+        if (sel == 1) launch64_t<__bf16, 0, 24, false>(p, st, nsplit);
+        else launch64_t<__bf16, 0, 24, true>(p, st, nsplit);
+        return;
+    }
+    switch (sel) {
+        case 1: launch64_t<_Float16, 0, 24, false>(p, st, nsplit); break;
+        case 2: launch64_t<_Float16, 0, 20, true>(p, st, nsplit); break;
+        case 3: launch64_t<_Float16, 0, 16, true>(p, st, nsplit); break;
+        case 4: launch64_t<_Float16, 1, 24, true>(p, st, nsplit); break;          // no LDS-DMA in the steady state
+        case 5: launch64_t<_Float16, 2, 24, true>(p, st, nsplit); break;          // no exp2 / row sums
+        case 6: launch64_t<_Float16, 8, 24, true>(p, st, nsplit); break;          // no per-tile wait + barrier
+        case 7: launch64_t<_Float16, 16, 24, true>(p, st, nsplit); break;         // no LDS fragment reads
+        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32, 24, true>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
+        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32, 24, true>(p, st, nsplit); break;   // MFMAs only
+        case 10: launch64_t<_Float16, 0, 28, true>(p, st, nsplit); break;
+        default: launch64_t<_Float16, 0, 24, true>(p, st, nsplit); break;
+    }
 }
 
 }  // namespace vattn_k

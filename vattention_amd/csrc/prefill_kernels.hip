@@ -839,6 +839,10 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     if constexpr (HD == 128) {
         if (pl.tiling == 7) {
             launch_prefill64(p, st, pl.nsplit);
+            if (pl.nsplit > 1) {
+                const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
+                hipLaunchKernelGGL((combine_rows_kernel<T, 128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, pl.nsplit, p->seqlen_q, rows);
+            }
             launched = true;
         } else if (pl.tiling == 2) {
             launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);

@@ -137,6 +137,7 @@ class HotPathRunner:
         self._bufs = {}
         self.stats = ReplayStats()
         self.sample_kv_util = True
+        self.iter_hook = None       # called once per iteration right after engine.step (bench.py: the TP control-plane exchange)
         # Compute runs on a NON-BLOCKING stream: on ROCm 7.2 hipMemMap / hipMemUnmap wait for work queued on
         # the legacy default stream (and every blocking stream) but not for non-blocking streams
         # (tools/vmm_probe.cpp, profiles/r01_vmm_probe.md), so this is what lets page mapping — on the
@@ -164,6 +165,8 @@ class HotPathRunner:
         q, k, v = self._qkv(T)
         with torch.cuda.stream(self.stream):
             self.engine.step(mds)
+            if self.iter_hook is not None:
+                self.iter_hook(self)
             self.wrapper.begin_forward(mds)
             out = None
             for layer in range(self.L):
