@@ -129,3 +129,44 @@ def check_append_shapes(seqlen_q_effective: int, seqlen_k_cache: int) -> None:
     cache's seqlen dimension.  SURVEY §A.2: the product's shim does not raise there."""
     if seqlen_q_effective > seqlen_k_cache:
         raise RuntimeError(APPEND_ERR)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RoPE (SURVEY §8 f3): the reference applies it to q and k BEFORE the attention wrapper
+# (sarathi/model_executor/models/yi.py:172-173 -> layers/rotary_embedding.py:86-101 -> csrc/pos_encoding_kernels.cu)
+# ---------------------------------------------------------------------------------------------------------------------
+def make_cos_sin_cache(rotary_dim: int, max_position: int, base: float = 10000.0, dtype=torch.float16) -> torch.Tensor:
+    """rotary_embedding.py:55-84: [max_position, rotary_dim] = cat(cos, sin) of t x inv_freq, computed in float and cast to the
+    model dtype (the cache is an INPUT of the rotary kernel; tests hand the same cache to the oracle and to the GPU path)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))
+    t = torch.arange(max_position, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+
+
+def rotary_embedding_ref(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                         cos_sin_cache: torch.Tensor, is_neox: bool = True) -> None:
+    """pos_encoding_kernels.cu:9-77, in place on query [T, Hq*hs] and key [T, Hkv*hs].  NeoX style pairs element i with element
+    i + rot_dim/2 (:18-23), GPT-J style pairs 2i with 2i+1 (:24-30).  The arithmetic is carried in the tensors' own dtype
+    (`scalar_t`, :32-35): every product and the final sum are rounded to it — restated as float ops each rounded to the dtype."""
+    dt = query.dtype
+    rot_dim = cos_sin_cache.shape[1]
+    e = rot_dim // 2
+    cs = cos_sin_cache[positions.long()]                       # [T, rot_dim]
+    cos, sin = cs[:, :e].float().unsqueeze(1), cs[:, e:].float().unsqueeze(1)      # [T, 1, e]
+    rnd = lambda x: x.to(dt).float()
+    for arr in (query, key):
+        T = arr.shape[0]
+        a = arr.view(T, -1, head_size)
+        if is_neox:
+            x, y = a[..., :e].float(), a[..., e:rot_dim].float()
+        else:
+            x, y = a[..., 0:rot_dim:2].float(), a[..., 1:rot_dim:2].float()
+        nx = rnd(rnd(x * cos) - rnd(y * sin))
+        ny = rnd(rnd(y * cos) + rnd(x * sin))
+        if is_neox:
+            a[..., :e] = nx.to(dt)
+            a[..., e:rot_dim] = ny.to(dt)
+        else:
+            a[..., 0:rot_dim:2] = nx.to(dt)
+            a[..., 1:rot_dim:2] = ny.to(dt)

@@ -54,7 +54,10 @@ __global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel
     }
     const int G = p.h / p.h_k;
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
-    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+    int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+    // never beyond the rows of the cache VIEW: the append skips such rows, and the rows behind them may be another slot's or sit on
+    // unmapped virtual pages (the wrapper asserts cache_len + new <= rows on the host, where it knows the lengths)
+    Lk = Lk > p.seqlen_k ? p.seqlen_k : Lk;
 
     // each sequence divides ITS OWN length evenly over the splits (balanced for ragged batches)
     const int ntiles_total = (Lk + DC_BN - 1) / DC_BN;

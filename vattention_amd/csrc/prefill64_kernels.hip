@@ -55,12 +55,9 @@ template <typename T> struct Mfma;
 #define VATTN_MFMA_STRUCT(TYPE, MNEM)                                                                                              \
     template <> struct Mfma<TYPE> {                                                                                                \
         using V8 = typename Tr<TYPE>::v8;                                                                                          \
-        /* D(vgpr) = A(vgpr) x B(agpr) + C(vgpr), D distinct from C */                                                             \
-        static __device__ __forceinline__ void qk_first(f32x16& d, V8 a, V8 b, const f32x16& c) {                                  \
-            asm volatile(MNEM " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));                                              \
-        }                                                                                                                          \
-        static __device__ __forceinline__ void qk_first_nop(f32x16& d, V8 a, V8 b, const f32x16& c) {                              \
-            asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));                                \
+        /* S'(vgpr) += A(vgpr) x B(agpr); the accumulator was pre-filled with -max */                                              \
+        static __device__ __forceinline__ void qk_acc_nop(f32x16& d, V8 a, V8 b) {                                                 \
+            asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));                                         \
         }                                                                                                                          \
         static __device__ __forceinline__ void qk_acc(f32x16& d, V8 a, V8 b) {                                                     \
             asm volatile(MNEM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));                                                       \
@@ -85,15 +82,6 @@ __device__ __forceinline__ float add1(float a, float b) {
 }
 // exp2 IN PLACE: the S' register becomes the P register (the builtin form lets the allocator give P fresh registers, and a
 // second copy of the tile's 64 scores does not fit the architectural half of the register file)
-// two scores -> probabilities in place + their sum into `acc`, one statement: the trans -> VALU wait state is written out
-#define EXP2_PAIR_SUM(x0, x1, acc) \
-    asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\tv_add_f32 %2, %2, %0\n\tv_add_f32 %2, %2, %1" : "+v"(x0), "+v"(x1), "+v"(acc))
-// the same with the softmax scale applied first (EXACT mode); sc is wave-uniform
-#define EXP2_PAIR_SUM_SCALED(x0, x1, acc, sc)                                                                                     \
-    asm("v_mul_f32 %0, %3, %0\n\tv_mul_f32 %1, %3, %1\n\tv_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\tv_add_f32 %2, %2, %0\n\t" \
-        "v_add_f32 %2, %2, %1"                                                                                                     \
-        : "+v"(x0), "+v"(x1), "+v"(acc)                                                                                            \
-        : "s"(sc))
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // ABL (timing ablations for tools/kbench.py, results are WRONG when non-zero; the product instantiates 0): bit 0 no LDS-DMA in the
@@ -112,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     constexpr int BM = 256;
     constexpr int KK = HD / 16;        // k-steps of the S^T MFMA chain
     constexpr int DB = HD / 32;        // 32-wide d blocks of O^T
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring [2][16 KiB] then V ring [2][16 KiB]; LDS address 0
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring [2][16 KiB], then V ring [3][16 KiB]; LDS address 0
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -182,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     };
     auto dma_v_all = [&](int t) {
         const u32x4 r = v_rsrc(t);
-        const unsigned l0 = v_lds_wave + (unsigned)((t & 1) * S::kTileBytes);
+        const unsigned l0 = v_lds_wave + (unsigned)((t % 3) * S::kTileBytes);
         dma_piece_first(l0, r, voff[0]);
         dma_piece(l0 + 1024, r, voff[1]);
         dma_piece(l0 + 2048, r, voff[2]);
@@ -195,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < (2 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + 2 * S::kTileBytes + (i * 256 + tid) * 16) = z;
+        for (int i = 0; i < (3 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + 2 * S::kTileBytes + (i * 256 + tid) * 16) = z;
     }
     __syncthreads();
     dma_k_all(tb);
@@ -229,12 +217,19 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     for (int i = 0; i < DB; i++)
 #pragma unroll
         for (int qc = 0; qc < 2; qc++) o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 negm[2];     // every element = -(running max) of the lane's query (log2 domain); C operand of the S^T chains
-    float l_run[2];     // lane-local partial row sums (the other half-lane holds the other 32 keys of every tile)
+    // -(running max) of the lane's query, in the units of S'.  It enters S' = K.Q^T - m through the ACCUMULATOR: the registers
+    // that will receive S'(t+2) are filled with it during the bare groups of step t (a separate 16-register broadcast block
+    // per query block as MFMA C operand would cost 32 of the 256 architectural registers)
+    float negm[2];
+    // lane-local partial row sums (the other half-lane holds the other 32 keys of every tile), TWO independent accumulators per
+    // query block, each touched once per MFMA group at most: with one wave per SIMD a dependent VALU chain stalls the wave, and a
+    // stalled wave issues no MFMA either
+    float l_acc[2][2];
 #pragma unroll
     for (int qc = 0; qc < 2; qc++) {
-        negm[qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        l_run[qc] = 0.f;
+        negm[qc] = 0.f;
+#pragma unroll
+        for (int a4 = 0; a4 < 2; a4++) l_acc[qc][a4] = 0.f;
     }
 
     // LDS fragment addressing: one lane-dependent base per tensor + immediate offsets
@@ -281,19 +276,22 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     };
     // moves the running maximum of query block qc up by delta >= 0 (per lane): everything still at the old scale — O, l and the
     // not yet exponentiated S' of the tile that triggered it — is rescaled exactly once (cdna guide T13)
-    auto raise_max = [&](int qc, float delta, f32x16 (&s)[2][2]) {
+    auto raise_max = [&](int qc, float delta, f32x16 (&s)[2][2], f32x16 (&pre)[2][2]) {
         const float alpha = fast_exp2(-delta * escale);
+        negm[qc] -= delta;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            negm[qc][r] -= delta;
             s[0][qc][r] -= delta;
             s[1][qc][r] -= delta;
+            pre[0][qc][r] -= delta;       // the accumulators already holding -m for the tile after next
+            pre[1][qc][r] -= delta;
         }
 #pragma unroll
         for (int i = 0; i < DB; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha;
-        l_run[qc] *= alpha;
+#pragma unroll
+        for (int a4 = 0; a4 < 2; a4++) l_acc[qc][a4] *= alpha;
     };
     // P(t) -> the PV B-operand fragment of key slice ks for query block qc: slot (g, j) <-> P registers 8*(ks&1) + j of key block ks>>1
     auto pack_p = [&](const f32x16 (&pt)[2][2], int ks, int qc) -> V8 {
@@ -315,8 +313,12 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             const V8 a = kfrag(ksm, f);
 #pragma unroll
             for (int qc = 0; qc < 2; qc++) {
-                if (f < 2) M::qk_first_nop(sc[f & 1][qc], a, qf[qc][f >> 1], negm[qc]);
-                else M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
+                if (f < 2) {
+                    sc[f & 1][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    M::qk_acc_nop(sc[f & 1][qc], a, qf[qc][f >> 1]);
+                } else {
+                    M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
+                }
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // the last MFMA results are VALU-readable from here
@@ -326,147 +328,164 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         for (int qc = 0; qc < 2; qc++) {
             const float mx = row_max(sc, qc);
             const float delta = (mx == -INFINITY) ? 0.f : mx;       // softmax.h: a fully masked row keeps a zero reference
+            negm[qc] = -delta;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                negm[qc][r] = -delta;
                 sc[0][qc][r] -= delta;
                 sc[1][qc][r] -= delta;
+                sd[0][qc][r] = -delta;      // S'(tb+1) accumulates on top of -m
+                sd[1][qc][r] = -delta;
             }
         }
     }
 
-    // One tile step of the wave.  cur holds S'(t) on entry and P(t) afterwards, nxt receives S'(t+1).
-    auto step = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) {
-        // K(t+1) and V(t) were issued one iteration ago; after the barrier every wave has finished reading K(t) and V(t-1)
-        if (!(ABL & 8)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        const char* ksm = smem + ((t + 1) & 1) * S::kTileBytes;
-        const char* vsm = smem + 2 * S::kTileBytes + (t & 1) * S::kTileBytes;
-        const u32x4 rk = k_rsrc(t + 2);      // -> slot of K(t);   past the last tile: zero-record descriptor, nothing is fetched
-        const u32x4 rv = v_rsrc(t + 1);      // -> slot of V(t-1)
-        const unsigned lk0 = k_lds_wave + (unsigned)((t & 1) * S::kTileBytes);
-        const unsigned lv0 = v_lds_wave + (unsigned)(((t + 1) & 1) * S::kTileBytes);
-        {
-            // Every wave runs the SAME straight-line body for every tile of the workgroup (the barrier makes the waves wait for each
-            // other anyway): a tile that lies wholly beyond a wave's causal limit is masked to -inf, contributes P = 0, and
-            // leaves the running maximum alone; past the last tile S'(t+1) is computed from a zero-filled K slot and never used.
-            // ---------------- 64 groups of { MFMA ; fragment read ahead ; a slice of softmax VALU } ----------------
-            // phase A: S'(t+1) = K(t+1).Q^T - m   (32 MFMAs: k-step kk = i>>2, key block (i>>1)&1, query block i&1)
-            //          || P(t) = exp2(S'(t)) for the first 48 of the 64 scores of the lane, row sums, the tile's DMA issue
-            V8 kf[3];
-            kf[0] = kfrag(ksm, 0);
-            kf[1] = kfrag(ksm, 1);
-            float ps0 = 0.f, ps1 = 0.f;
-            auto exp_pair = [&](int e) {         // scores 2e, 2e+1 in PV consumption order: key block e>>4, query block (e>>3)&1 ... see below
-                // order: [kb][half][qc][4 pairs]: registers 8*half + 2*q4 .. +1 of cur[kb][qc]
-                const int kb = e >> 4, half = (e >> 3) & 1, qc = (e >> 2) & 1, q4 = e & 3;
-                const int r0 = 8 * half + 2 * q4;
-                if (ABL & 2) return;
-                if (EXACT) {
-                    if (qc == 0) EXP2_PAIR_SUM_SCALED(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps0, escale);
-                    else EXP2_PAIR_SUM_SCALED(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps1, escale);
-                } else {
-                    if (qc == 0) EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps0);
-                    else EXP2_PAIR_SUM(cur[kb][qc][r0], cur[kb][qc][r0 + 1], ps1);
-                }
-            };
-            SCHED_FENCE();
+    // ---- software pipeline of the softmax VALU work, in units of PAIRS of scores (pair e: key block e>>4, half (e>>3)&1, query
+    // block (e>>2)&1, registers 8*half + 2*(e&3), +1 — the order in which the P.V key slices consume them).  Stage E (two
+    // v_exp) of pair e sits in group GE(e) of the tile's 64 MFMA groups, stage M (EXACT: two v_mul) one group earlier, stage A
+    // (two v_add into two of the four accumulators) one group later: no instruction waits for the one before it.
+    auto GE = [](int e) { return e < NA ? 1 + (e * 30) / NA : 33 + ((e - NA) * 17) / (32 - NA); };
+#define P64_X0(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3)]
+#define P64_X1(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3) + 1]
+    auto softmax_stages = [&](int G, f32x16 (&cur)[2][2]) {
+        if (ABL & 2) return;
 #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const int f = i >> 1, qc = i & 1;
-                if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1], negm[qc]);
-                else M::qk_acc(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1]);
-                if ((i & 1) == 0 && f + 2 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + 2) % 3] = kfrag(ksm, f + 2);
-                if (!(ABL & 1)) {
-                    if (i == 0) dma_piece_first(lk0, rk, koff[0]);
-                    if (i == 1) dma_piece(lk0 + 1024, rk, koff[1]);
-                    if (i == 2) dma_piece(lk0 + 2048, rk, koff[2]);
-                    if (i == 3) dma_piece(lk0 + 3072, rk, koff[3]);
-                    if (i == 4) dma_piece_first(lv0, rv, voff[0]);
-                    if (i == 5) dma_piece(lv0 + 1024, rv, voff[1]);
-                    if (i == 6) dma_piece(lv0 + 2048, rv, voff[2]);
-                    if (i == 7) dma_piece(lv0 + 3072, rv, voff[3]);
-                }
-                // exp2 pairs 0 .. NA-1 spread evenly over the 32 groups of this phase (pair e must be done before key slice e>>3 is packed)
-#pragma unroll
-                for (int e = 0; e < NA; e++)
-                    if ((e * 32) / NA == i) exp_pair(e);
-                SCHED_FENCE();
-            }
-            // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
-            //          || the remaining 16 scores, f16 packing of P(t) one key slice ahead, row max of S'(t+1)
-            V8 vf[3];
-            V8 pf[2][2];
-            vf[0] = vfrag(vsm, 0);
-            vf[1] = vfrag(vsm, 1);
-            pf[0][0] = pack_p(cur, 0, 0);
-            pf[0][1] = pack_p(cur, 0, 1);
-            float mx0 = -INFINITY, mx1 = -INFINITY;
-            SCHED_FENCE();
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const int f = j >> 1, ks = j >> 3, qc = j & 1;
-                if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
-                else M::pv(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);
-                if ((j & 1) == 0 && f + 2 < 16 && !((ABL & 16) && f >= 1)) vf[(f + 2) % 3] = vfrag(vsm, f + 2);
-                // the remaining exp2 pairs NA .. 31: pair e belongs to key slice e >> 3, whose P fragments are packed in groups
-                // 8*(e>>3) - 4 and - 2, so the pairs of slice s are spread over the groups before 8*s - 4
-                {
-                    constexpr int NB = 32 - NA;          // pairs left for this phase, spread over its first 20 groups (slice 3 is packed
-                    constexpr int G_END = 20;            // in groups 20 and 22; earlier slices come first because pairs go in order)
-#pragma unroll
-                    for (int e = NA; e < 32; e++)
-                        if (((e - NA) * G_END) / (NB > 0 ? NB : 1) == j) exp_pair(e);
-                }
-                // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
-                if (!(ABL & 32)) {
-                    if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
-                    if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
-                }
-                // row max of S'(t+1): 2 chains x 16 v_max3, from group 8 on (>= 8 MFMAs after the last S^T MFMA was issued)
-                if (!(ABL & 4) && j >= 8 && j < 24) {
-                    const int r = j - 8;
-                    mx0 = fmaxf(fmaxf(mx0, nxt[0][0][r]), nxt[1][0][r]);
-                    mx1 = fmaxf(fmaxf(mx1, nxt[0][1][r]), nxt[1][1][r]);
-                }
-                SCHED_FENCE();
-            }
-            l_run[0] = add1(l_run[0], ps0);
-            l_run[1] = add1(l_run[1], ps1);
-            mx0 = fmaxf(mx0, swap_halves(mx0));
-            mx1 = fmaxf(mx1, swap_halves(mx1));
-            if (needs_mask(t + 1)) {                     // ragged end / causal diagonal: wave-uniform, the last tiles only
-                mask_tile(t + 1, nxt);
-                mx0 = row_max(nxt, 0);
-                mx1 = row_max(nxt, 1);
-            }
-            if (__builtin_amdgcn_ballot_w64(fmaxf(mx0, mx1) > defer_thr) != 0) {      // rare: a row's maximum grew by > 2^6
-                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");                        // every PV result has landed in O
-                SCHED_FENCE();
-                raise_max(0, fmaxf(mx0, 0.f), nxt);
-                raise_max(1, fmaxf(mx1, 0.f), nxt);
-                SCHED_FENCE();
-                asm volatile("s_nop 3" ::: "memory");                                    // accvgpr writes -> next MFMA read
-            }
+        for (int e = 0; e < 32; e++) {
+            const int qc = (e >> 2) & 1, a0 = 0;
+            if (EXACT && GE(e) - 1 == G) asm("v_mul_f32 %0, %2, %0\n\tv_mul_f32 %1, %2, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale));
+            if (GE(e) == G) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
+            if (GE(e) + 1 == G)
+                asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][a0]), "+v"(l_acc[qc][a0 + 1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
         }
     };
+
+    // One tile step of the wave.  cur holds S'(t) on entry and P(t) afterwards, nxt receives S'(t+1); kf0 / kf1 hold the first two
+    // K(t+1) fragments on entry (read before the previous step ended) and the first two of K(t+2) on exit.
+    // Invariants at entry: K(t+1) and V(t) have landed and every wave knows it (the barrier of step t-1); K(t+2) and V(t+1) are
+    // in flight.  The barrier of this step sits in phase B after group 23: by then every wave has finished reading K(t+1)
+    // (phase A) and V(t-1) (step t-1), so K(t+3) -> slot of K(t+1) and V(t+2) -> slot of V(t-1) are issued right behind it, one
+    // piece per group in the eight groups that carry no softmax work.
+    auto step = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1) {
+        const char* ksm = smem + ((t + 1) & 1) * S::kTileBytes;
+        const char* ksm_next = smem + (t & 1) * S::kTileBytes;                  // K(t+2)
+        const char* vsm = smem + 2 * S::kTileBytes + (t % 3) * S::kTileBytes;
+        const u32x4 rk = k_rsrc(t + 3);      // past the last tile: zero-record descriptor, nothing is fetched
+        const u32x4 rv = v_rsrc(t + 2);
+        const unsigned lk0 = k_lds_wave + (unsigned)(((t + 1) & 1) * S::kTileBytes);
+        const unsigned lv0 = v_lds_wave + (unsigned)(((t + 2) % 3) * S::kTileBytes);
+        // Every wave runs the SAME straight-line body for every tile of the workgroup (the barrier makes the waves wait for each other
+        // anyway): a tile that lies wholly beyond a wave's causal limit is masked to -inf, contributes P = 0, and leaves the running
+        // maximum alone; past the last tile S'(t+1) is computed from a zero-filled K slot and never used.
+        // ---------------- 64 groups of { MFMA ; fragment read ahead ; a slice of softmax VALU } ----------------
+        // phase A: S'(t+1) = K(t+1).Q^T - m   (32 MFMAs: k-step kk = i>>2, key block (i>>1)&1, query block i&1)
+        V8 kf[3];
+        kf[0] = kf0;
+        kf[1] = kf1;
+        SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int f = i >> 1, qc = i & 1;
+            M::qk_acc(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1]);       // nxt was pre-filled with -m one step ago
+            if ((i & 1) == 0 && f + 2 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + 2) % 3] = kfrag(ksm, f + 2);
+            softmax_stages(i, cur);
+            SCHED_FENCE();
+        }
+        // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
+        V8 vf[3];
+        V8 pf[2][2];
+        vf[0] = vfrag(vsm, 0);
+        vf[1] = vfrag(vsm, 1);
+        pf[0][0] = pack_p(cur, 0, 0);
+        pf[0][1] = pack_p(cur, 0, 1);
+        float mx0 = -INFINITY, mx1 = -INFINITY;
+        SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const int f = j >> 1, ks = j >> 3, qc = j & 1;
+            if (j == 24 && !(ABL & 8)) {
+                // this wave's pieces of K(t+2) and V(t+1) (issued one step ago) have landed; behind the barrier everyone's have, and
+                // every wave is past its reads of K(t+1) and V(t-1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
+            else M::pv(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);
+            if ((j & 1) == 0 && f + 2 < 16 && !((ABL & 16) && f >= 1)) vf[(f + 2) % 3] = vfrag(vsm, f + 2);
+            softmax_stages(32 + j, cur);
+            // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
+            if (!(ABL & 32)) {
+                if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
+                if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
+            }
+            // row max of S'(t+1): 2 chains x 16 v_max3, groups 8..23 (>= 8 MFMAs after the last S^T MFMA was issued)
+            if (!(ABL & 4) && j >= 8 && j < 24) {
+                const int r = j - 8;
+                mx0 = fmaxf(fmaxf(mx0, nxt[0][0][r]), nxt[1][0][r]);
+                mx1 = fmaxf(fmaxf(mx1, nxt[0][1][r]), nxt[1][1][r]);
+            }
+            if (!(ABL & 1)) {
+                if (j == 24) dma_piece_first(lk0, rk, koff[0]);
+                if (j == 25) dma_piece(lk0 + 1024, rk, koff[1]);
+                if (j == 26) dma_piece(lk0 + 2048, rk, koff[2]);
+                if (j == 27) dma_piece(lk0 + 3072, rk, koff[3]);
+                if (j == 28) dma_piece_first(lv0, rv, voff[0]);
+                if (j == 29) dma_piece(lv0 + 1024, rv, voff[1]);
+                if (j == 30) dma_piece(lv0 + 2048, rv, voff[2]);
+                if (j == 31) dma_piece(lv0 + 3072, rv, voff[3]);
+            }
+            if (j >= 24) {
+                // P(t) is dead (last packed in group 22): its registers become the accumulators of S'(t+2), pre-filled with -m
+                const int kb = (j >> 2) & 1, qq = (j >> 1) & 1, hf = j & 1;
+                // (asm volatile: as plain assignments hipcc sinks the 64 moves out of the MFMA groups into the block behind the loop body)
+                asm volatile("v_mov_b32 %0, %8\n\tv_mov_b32 %1, %8\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %8\n\tv_mov_b32 %5, %8\n\t"
+                             "v_mov_b32 %6, %8\n\tv_mov_b32 %7, %8"
+                             : "=v"(cur[kb][qq][8 * hf + 0]), "=v"(cur[kb][qq][8 * hf + 1]), "=v"(cur[kb][qq][8 * hf + 2]), "=v"(cur[kb][qq][8 * hf + 3]),
+                               "=v"(cur[kb][qq][8 * hf + 4]), "=v"(cur[kb][qq][8 * hf + 5]), "=v"(cur[kb][qq][8 * hf + 6]), "=v"(cur[kb][qq][8 * hf + 7])
+                             : "v"(negm[qq]));
+            }
+            if (j == 28) kf0 = kfrag(ksm_next, 0);          // the next step's first K fragments: K(t+2) is behind the barrier
+            if (j == 29) kf1 = kfrag(ksm_next, 1);
+            SCHED_FENCE();
+        }
+        mx0 = fmaxf(mx0, swap_halves(mx0));
+        mx1 = fmaxf(mx1, swap_halves(mx1));
+        if (needs_mask(t + 1)) {                     // ragged end / causal diagonal: wave-uniform, the last tiles only
+            mask_tile(t + 1, nxt);
+            mx0 = row_max(nxt, 0);
+            mx1 = row_max(nxt, 1);
+        }
+        if (__builtin_amdgcn_ballot_w64(fmaxf(mx0, mx1) > defer_thr) != 0) {      // rare: a row's maximum grew by > 2^6
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");                        // every PV result has landed in O
+            SCHED_FENCE();
+            raise_max(0, fmaxf(mx0, 0.f), nxt, cur);
+            raise_max(1, fmaxf(mx1, 0.f), nxt, cur);
+            SCHED_FENCE();
+            asm volatile("s_nop 3" ::: "memory");                                    // accvgpr writes -> next MFMA read
+        }
+    };
+    // the loop's entry invariants: K(tb+1), V(tb) landed and known to; K(tb+2), V(tb+1) in flight; first fragments of K(tb+1) read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // also: every wave is done with K(tb) (the prologue's S')
+    dma_k_all(tb + 2);
+    dma_v_all(tb + 1);
+    V8 kfa = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 0), kfb = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 1);
     for (int t = tb; t < nt; t += 2) {
-        step(t, sc, sd);
-        if (t + 1 < nt) step(t + 1, sd, sc);
+        step(t, sc, sd, kfa, kfb);
+        if (t + 1 < nt) step(t + 1, sd, sc, kfa, kfb);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // trailing DMA retired (nothing may land in LDS of
     SCHED_FENCE();                                                                // a later workgroup); last PV results readable
+#undef P64_X0
+#undef P64_X1
 
     // ---- epilogue: O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
     const float sc_ln = p.softmax_scale;
 #pragma unroll
     for (int qc = 0; qc < 2; qc++) {
         const int my_q = qw0 + 32 * qc + l31;
-        const float l_tot = l_run[qc] + swap_halves(l_run[qc]);
+        const float l_loc = l_acc[qc][0] + l_acc[qc][1];
+        const float l_tot = l_loc + swap_halves(l_loc);
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-        const float m_log2 = -negm[qc][0] * escale;           // running max of softmax_scale*log2e*q.k
+        const float m_log2 = -negm[qc] * escale;              // running max of softmax_scale*log2e*q.k
         if (my_q < Sq && nsplit > 1) {
             // KV-split: normalised fp32 partial + its log2-domain LSE; combine_rows_kernel merges the nsplit partials of a row
             const int64_t row = (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
@@ -540,15 +559,15 @@ template <typename T, int ABL, int NA, bool EXACT> static void launch64_t(const 
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * PfSmem<128>::kTileBytes);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, EXACT>), grid, dim3(256), PfSmem<128>::kTotal, st, *p, order, nqb, nsplit);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, EXACT>), grid, dim3(256), 5 * PfSmem<128>::kTileBytes, st, *p, order, nqb, nsplit);
 }
 
 // variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1 = pre-scaled Q (one VALU less per score, 2.2x the
-// reference-numerics error on short contexts); 2 / 3 = 20 / 16 of the 32 exp2 pairs in phase A; 4.. = timing ablations (wrong results)
+// reference-numerics error on short contexts); 4.. = timing ablations (wrong results)
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int sel = (p->variant >> 8) & 15;
     if (p->dtype == VATTN_DTYPE_BF16) {
@@ -558,15 +577,12 @@ void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     }
     switch (sel) {
         case 1: launch64_t<_Float16, 0, 24, false>(p, st, nsplit); break;
-        case 2: launch64_t<_Float16, 0, 20, true>(p, st, nsplit); break;
-        case 3: launch64_t<_Float16, 0, 16, true>(p, st, nsplit); break;
         case 4: launch64_t<_Float16, 1, 24, true>(p, st, nsplit); break;          // no LDS-DMA in the steady state
         case 5: launch64_t<_Float16, 2, 24, true>(p, st, nsplit); break;          // no exp2 / row sums
         case 6: launch64_t<_Float16, 8, 24, true>(p, st, nsplit); break;          // no per-tile wait + barrier
         case 7: launch64_t<_Float16, 16, 24, true>(p, st, nsplit); break;         // no LDS fragment reads
         case 8: launch64_t<_Float16, 1 | 2 | 4 | 32, 24, true>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
         case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32, 24, true>(p, st, nsplit); break;   // MFMAs only
-        case 10: launch64_t<_Float16, 0, 28, true>(p, st, nsplit); break;
         default: launch64_t<_Float16, 0, 24, true>(p, st, nsplit); break;
     }
 }

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
     const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
     // loaded values are wave-uniform; readfirstlane makes that provable (descriptors must live in SGPRs)
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
-    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+    const int Lk = min(p.seqlen_k, __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew));   // never beyond the cache view
     // batched chunks of different lengths: entry b owns rows [q_first, q_first + Sq) of the flattened q / out
     const int Sq = p.q_lens ? __builtin_amdgcn_readfirstlane(p.q_lens[b]) : p.seqlen_q;
     const int64_t q_first = p.q_start ? (int64_t)__builtin_amdgcn_readfirstlane(p.q_start[b]) : 0;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void prefill_ilv_kernel(vattn_attn_params p
     if (!wg_to_work(p, order, nqb, 1, b, h, qb, split_unused)) return;
     const int hk = h / (p.h / p.h_k);
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
-    const int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+    const int Lk = min(p.seqlen_k, __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew));   // never beyond the cache view
     const int Sq = p.seqlen_q;
     const bool causal = p.is_causal != 0;
     const int off = Lk - Sq;
