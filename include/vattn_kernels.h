@@ -69,6 +69,16 @@ typedef struct vattn_attn_params {
     int32_t variant;                  /* 0 = default; debug variants select alternative operand paths   */
     int32_t max_seqlen_k_hint;        /* host-side upper bound of cache_seqlens[b] + seqlen_knew, or 0: unknown (seqlen_k is
                                          only the cache tensor's row count); used to size the prefill KV split            */
+    /* Fused rotary position embedding (MI355X extension): when rotary_cos_sin != NULL the launch rotates q — and
+     * k_new before it is appended / attended — in registers, NeoX style, with the arithmetic of the reference's stand-alone
+     * kernel (/root/reference/sarathi-lean/csrc/pos_encoding_kernels.cu:9-77, every product and the sum rounded to the I/O
+     * dtype).  Layout = the reference's cos_sin_cache: row `pos` holds cos[0 .. rotary_dim/2) then sin[0 .. rotary_dim/2), I/O
+     * dtype, rows rotary_row_stride elements apart.  Token i of batch entry b sits at position cache_seqlens[b] + i (new keys)
+     * resp. (visible keys - seqlen_q) + i (queries), i.e. the call-site convention of the wrapper.  rotary_dim must equal d. */
+    const void* rotary_cos_sin;
+    int64_t rotary_row_stride;
+    int32_t rotary_dim;
+    int32_t rotary_reserved;
 } vattn_attn_params;
 
 /* Bytes of split-KV workspace the call will need: the decode form's partials, or the prefill form's when its grid
@@ -85,6 +95,20 @@ int vattn_cache_flat(const void* key, const void* value, void* k_cache, void* v_
                      int64_t num_tokens, int32_t num_heads, int32_t head_size,
                      int64_t key_stride, int64_t value_stride, int64_t k_cache_stride, int64_t v_cache_stride,
                      int32_t itemsize, void* stream);
+
+/* cache_flat with the rotary embedding of the KEY rows fused in: k_cache[t] = rope(key[t], position pos0 + t),
+ * v_cache[t] = value[t]; one pass over the new K/V instead of the reference's rotary kernel + cache_flat.  2-byte dtypes, NeoX
+ * style, rotary_dim == head_size.  dtype = VATTN_DTYPE_*. */
+int vattn_cache_flat_rope(const void* key, const void* value, void* k_cache, void* v_cache, int64_t num_tokens,
+                          int32_t num_heads, int32_t head_size, int64_t key_stride, int64_t value_stride, int64_t k_cache_stride,
+                          int64_t v_cache_stride, int32_t dtype, const void* cos_sin, int64_t cos_sin_row_stride, int64_t pos0,
+                          void* stream);
+
+/* The reference's stand-alone rotary kernel (pos_encoding_kernels.cu:39-77, rotary_embedding): in place on query [T, Hq*hs]
+ * and key [T, Hkv*hs], positions int64[T].  Provided for the UNFUSED path (what the fused launches are measured against). */
+int vattn_rotary_embedding(const int64_t* positions, void* query, void* key, int64_t num_tokens, int32_t num_q_heads,
+                           int32_t num_kv_heads, int32_t head_size, int64_t query_stride, int64_t key_stride, int32_t dtype,
+                           const void* cos_sin, int64_t cos_sin_row_stride, int32_t rot_dim, int32_t is_neox, void* stream);
 
 /* Device-side self-tests of the hardware layout assumptions (MFMA fragment maps, LDS transpose read, LDS-DMA lane
  * mapping); 0 = all assumptions hold.  detail_out[0..5] are per-assumption failure flags, detail_out[6] reports what

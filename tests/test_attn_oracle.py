@@ -138,3 +138,28 @@ def test_against_a_scalar_python_restatement():
                     for d in range(D):
                         assert abs(float(got[b, i, h, d]) - want[d]) < 1e-9, (causal, b, i, h, d)
         assert torch.equal(k2, ke) and torch.equal(v2, ve)       # the append itself
+
+
+def test_rotary_oracle_matches_scalar_half_arithmetic_and_is_a_rotation():
+    """oracle/attn.py rotary_embedding_ref vs a scalar evaluation of pos_encoding_kernels.cu:9-37 in torch half scalars (each
+    operator rounds to half), NeoX and GPT-J pairings; position 0 is the identity; norms are preserved to rounding."""
+    from oracle.attn import make_cos_sin_cache, rotary_embedding_ref
+    torch.manual_seed(0)
+    hs, T = 64, 9
+    cs = make_cos_sin_cache(hs, 256)
+    pos = torch.tensor([0, 1, 2, 17, 100, 255, 3, 3, 8])
+    for neox in (True, False):
+        q, k = torch.randn(T, 3 * hs).half(), torch.randn(T, 2 * hs).half()
+        q0, k0 = q.clone(), k.clone()
+        rotary_embedding_ref(pos, q, k, hs, cs, neox)
+        e = hs // 2
+        for arr, arr0, nh in ((q, q0, 3), (k, k0, 2)):
+            for t in range(T):
+                for h in range(nh):
+                    for i in (0, 1, 13, e - 1):
+                        xi, yi = (i, e + i) if neox else (2 * i, 2 * i + 1)
+                        x, y = arr0[t, h * hs + xi], arr0[t, h * hs + yi]
+                        c, s = cs[pos[t], i], cs[pos[t], e + i]
+                        assert arr[t, h * hs + xi] == x * c - y * s and arr[t, h * hs + yi] == y * c + x * s
+        assert torch.equal(q[0], q0[0])
+        assert torch.allclose(q.float().view(T, 3, hs).norm(dim=-1), q0.float().view(T, 3, hs).norm(dim=-1), rtol=3e-3)

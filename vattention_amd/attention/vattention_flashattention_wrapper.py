@@ -23,7 +23,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from .. import vattention as _vattention
-from ..cache_ops import cache_flat
+from ..cache_ops import cache_flat, cache_flat_rope
 from ..flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
 from .base_attention_wrapper import BaseAttentionWrapper
 from .timers import OperationMetrics
@@ -36,7 +36,15 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         super().init(model_config, parallel_config, block_size, device)
         self.is_metadata_initialized = False
         self.is_profiling_iteration = False
+        self._rotary = None
         self._reset()
+
+    def set_fused_rotary(self, cos_sin_cache: Optional[torch.Tensor]) -> None:
+        """MI355X extension: hand the wrapper the model's rotary table ([max_position, rotary_dim],
+        rotary_embedding.py:75-84) and pass UN-rotated q / k to forward(): RoPE is then applied inside the attention and
+        cache-append launches (q and the new k rows in registers, the rotated k lands in the cache) instead of by a separate
+        kernel before the wrapper (models/yi.py:172-173).  None switches back to the reference's dataflow."""
+        self._rotary = cos_sin_cache
 
     def _reset(self):
         self.prefill_query_lens: List[int] = []
@@ -121,14 +129,18 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
             with self.get_timer(OperationMetrics.ATTN_KV_CACHE_SAVE, layer_id):
                 for i, (c_len, q_len) in enumerate(zip(self.prefill_cache_lens, self.prefill_query_lens)):
                     slot = self._batch_index_host[i]
-                    cache_flat(key[tok:tok + q_len].view(q_len, Hkv, D), value[tok:tok + q_len].view(q_len, Hkv, D),
-                               k_all[slot][c_len:], v_all[slot][c_len:], "auto")
+                    if self._rotary is not None:
+                        cache_flat_rope(key[tok:tok + q_len].view(q_len, Hkv, D), value[tok:tok + q_len].view(q_len, Hkv, D),
+                                        k_all[slot][c_len:], v_all[slot][c_len:], self._rotary, c_len)
+                    else:
+                        cache_flat(key[tok:tok + q_len].view(q_len, Hkv, D), value[tok:tok + q_len].view(q_len, Hkv, D),
+                                   k_all[slot][c_len:], v_all[slot][c_len:], "auto")
                     tok += q_len
             with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id):
                 flash_attn_varlen_with_kvcache(query[:tok].view(tok, Hq, D), k_all, v_all, self._prefill_starts, self._prefill_qlens,
                                                max(self.prefill_query_lens), self._prefill_totals, self.batch_index[:P],
                                                softmax_scale=softmax_scale, causal=True, out=output[:tok].view(tok, Hq, D),
-                                               num_splits=num_splits,
+                                               num_splits=num_splits, _rotary_cos_sin=self._rotary,
                                                _max_seqlen_k=max(c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)))
             return tok
         tok = 0
@@ -141,14 +153,17 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                 k_rows = k_all[slot]             # [max_ctx, kvh, D]: the slot's whole (virtual) row-block
                 v_rows = v_all[slot]
             with self.get_timer(OperationMetrics.ATTN_KV_CACHE_SAVE, layer_id):
-                cache_flat(k, v, k_rows[c_len:], v_rows[c_len:], "auto")
+                if self._rotary is not None:
+                    cache_flat_rope(k, v, k_rows[c_len:], v_rows[c_len:], self._rotary, c_len)
+                else:
+                    cache_flat(k, v, k_rows[c_len:], v_rows[c_len:], "auto")
             with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id):
                 # the kernel writes straight into this sequence's rows of `output` (no [q_len, Hq*D] copy afterwards)
                 flash_attn_with_kvcache(q, k_rows.unsqueeze(0), v_rows.unsqueeze(0),
                                         cache_seqlens=self.current_total_len_device_lst[i],
                                         causal=True, softmax_scale=softmax_scale,
                                         out=output[tok:tok + q_len].view(1, q_len, Hq, D), _max_seqlen_k=c_len + q_len,
-                                        num_splits=num_splits)
+                                        num_splits=num_splits, _rotary_cos_sin=self._rotary)
             tok += q_len
         return tok
 
@@ -166,4 +181,4 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                     cache_seqlens=self.decode_cache_lens, block_table=None,
                                     softmax_scale=softmax_scale, causal=True,
                                     cache_batch_idx=self.batch_index_gen,
-                                    out=output[tok:tok + nb].view(nb, 1, Hq, D))
+                                    out=output[tok:tok + nb].view(nb, 1, Hq, D), _rotary_cos_sin=self._rotary)

@@ -197,6 +197,11 @@ int validate(const vattn_attn_params* p) {
         if (s % 8 != 0) return fail(VATTN_K_ERR_UNSUPPORTED, "strides must be multiples of 8 elements (16-byte vector access)");
     if (((uintptr_t)p->q | (uintptr_t)p->k_cache | (uintptr_t)p->v_cache | (uintptr_t)p->out) & 15)
         return fail(VATTN_K_ERR_UNSUPPORTED, "tensor base pointers must be 16-byte aligned");
+    if (p->rotary_cos_sin) {
+        if (p->rotary_dim != p->d) return fail(VATTN_K_ERR_UNSUPPORTED, "fused rotary embedding needs rotary_dim == head dimension");
+        if ((p->rotary_row_stride & 7) || ((uintptr_t)p->rotary_cos_sin & 15))
+            return fail(VATTN_K_ERR_UNSUPPORTED, "rotary cos/sin rows must be 16-byte aligned");
+    }
     if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
         return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
     return VATTN_K_OK;

@@ -82,6 +82,27 @@ template <typename P> __device__ __forceinline__ const P* uniform_ptr(const P* p
     return (const P*)(((unsigned long long)hi << 32) | lo);
 }
 
+// ---- rotary position embedding, NeoX pairing (element i with element i + rot_dim/2), on 8-element fragments ----
+// Arithmetic of /root/reference/sarathi-lean/csrc/pos_encoding_kernels.cu:32-35 in `scalar_t`: x' = x*cos - y*sin, y' = y*cos + x*sin
+// with every product and the sum rounded to the I/O dtype (restated by oracle/attn.py rotary_embedding_ref; bit-exact).
+template <typename T> __device__ __forceinline__ void rope8(typename Tr<T>::v8& x, typename Tr<T>::v8& y, typename Tr<T>::v8 c, typename Tr<T>::v8 s) {
+    using X = Tr<T>;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float xf = (float)x[j], yf = (float)y[j], cf = (float)c[j], sf = (float)s[j];
+        const float p1 = (float)X::cvt(xf * cf), p2 = (float)X::cvt(yf * sf);
+        const float q1 = (float)X::cvt(yf * cf), q2 = (float)X::cvt(xf * sf);
+        x[j] = X::cvt(p1 - p2);
+        y[j] = X::cvt(q1 + q2);
+    }
+}
+// cos / sin fragments of row `pos` for elements [d0, d0 + 8) of the first half
+template <typename T> __device__ __forceinline__ void rope_load(const vattn_attn_params& p, int64_t pos, int d0, typename Tr<T>::v8& c, typename Tr<T>::v8& s) {
+    const T* row = (const T*)p.rotary_cos_sin + pos * p.rotary_row_stride;
+    c = as_v8<typename Tr<T>::v8>(*(const uint4*)(row + d0));
+    s = as_v8<typename Tr<T>::v8>(*(const uint4*)(row + p.rotary_dim / 2 + d0));
+}
+
 // ---- prefill form: pieces shared by prefill_kernels.hip and prefill64_kernels.hip ----
 constexpr int PF_BN = 64;              // keys per tile
 template <int HD> struct PfSmem {

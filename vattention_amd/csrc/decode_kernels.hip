@@ -86,6 +86,17 @@ __global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel
         if (row_valid) v = *(const uint4*)(qptr + 32 * kk + 8 * g4);
         qf[kk] = as_v8<V8>(v);
     }
+    // fused RoPE (include/vattn_kernels.h): the query token sits at position Lk - 1; slot (g4, j) of k-step kk is element
+    // d = 32*kk + 8*g4 + j, so element d and its partner d + HD/2 live in the SAME lane (k-steps kk and kk + KK/2)
+    const bool rope = p.rotary_cos_sin != nullptr;
+    if (rope) {
+#pragma unroll
+        for (int kk = 0; kk < KK / 2; kk++) {
+            V8 c, s;
+            rope_load<T>(p, (int64_t)(Lk - 1), 32 * kk + 8 * g4, c, s);
+            rope8<T>(qf[kk], qf[kk + KK / 2], c, s);
+        }
+    }
 
     f32x4 o[DB];
 #pragma unroll
@@ -126,9 +137,21 @@ __global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
                 if (k0 + 16 * kb + l15 == new_key) {
+                    V8 kn8[KK];
+#pragma unroll
+                    for (int kk = 0; kk < KK; kk++) kn8[kk] = as_v8<V8>(*(const uint4*)(kn + 32 * kk + 8 * g4));
+                    if (rope) {                  // the new key is rotated before it is attended and before it is stored
+#pragma unroll
+                        for (int kk = 0; kk < KK / 2; kk++) {
+                            V8 c, s;
+                            rope_load<T>(p, (int64_t)new_key, 32 * kk + 8 * g4, c, s);
+                            rope8<T>(kn8[kk], kn8[kk + KK / 2], c, s);
+                        }
+                    }
 #pragma unroll
                     for (int kk = 0; kk < KK; kk++) {
-                        const uint4 v = *(const uint4*)(kn + 32 * kk + 8 * g4);
+                        uint4 v;
+                        __builtin_memcpy(&v, &kn8[kk], 16);
                         kreg[kb][kk] = v;
                         if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(kc + 32 * kk + 8 * g4) = v;
                     }

@@ -199,14 +199,27 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     for (int qc = 0; qc < 2; qc++) {
         const int my_q = qw0 + 32 * qc + l31;
         const T* qptr = (const T*)p.q + (p.q_start ? 0 : (int64_t)b * p.q_batch_stride) + (q_first + my_q) * p.q_row_stride + (int64_t)h * p.q_head_stride;
+        V8 raw[KK];
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
-            const V8 raw = as_v8<V8>(v);
+            raw[kk] = as_v8<V8>(v);
+        }
+        if (p.rotary_cos_sin && my_q < Sq) {
+            // fused RoPE: query row i sits at position (visible keys - Sq) + i; an element and its partner d + 64 live in the same lane
+#pragma unroll
+            for (int kk = 0; kk < KK / 2; kk++) {
+                V8 c, s;
+                rope_load<T>(p, (int64_t)(off + my_q), 16 * kk + 8 * g, c, s);
+                rope8<T>(raw[kk], raw[kk + KK / 2], c, s);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
             V8 sc8;
 #pragma unroll
-            for (int j = 0; j < 8; j++) sc8[j] = EXACT ? raw[j] : X::cvt((float)raw[j] * qscale);
+            for (int j = 0; j < 8; j++) sc8[j] = EXACT ? raw[kk][j] : X::cvt((float)raw[kk][j] * qscale);
             qf[qc][kk] = sc8;
             asm volatile("" : "+a"(qf[qc][kk]));       // materialise the fragment as ONE 4-register accumulator tuple, here
         }

@@ -95,6 +95,16 @@ __global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void pre
             if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
             qf[qc][kk] = as_v8<V8>(v);
         }
+        if (p.rotary_cos_sin && my_q < Sq) {
+            // fused RoPE: query row i sits at position (visible keys - Sq) + i; slot (g, j) of k-step kk is element 16*kk + 8*g + j,
+            // so an element and its partner d + HD/2 live in the same lane (k-steps kk and kk + KK/2)
+#pragma unroll
+            for (int kk = 0; kk < KK / 2; kk++) {
+                V8 c, s;
+                rope_load<T>(p, (int64_t)(off + my_q), 16 * kk + 8 * g, c, s);
+                rope8<T>(qf[qc][kk], qf[qc][kk + KK / 2], c, s);
+            }
+        }
     }
     // Retire the Q loads HERE and make that visible to hipcc's wait-count pass: otherwise it keeps a conservative
     // "Q may still be in flight" state around the loop and puts a vmcnt wait in front of the first MFMA of every
@@ -743,7 +753,7 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
     // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
     if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6 || pl.tiling == 7))) pl.tiling = 1;
-    if (pl.tiling == 6 && p->q_lens) pl.tiling = 1;                  // the interleaved kernel has no batched-chunk form
+    if (pl.tiling == 6 && (p->q_lens || p->rotary_cos_sin)) pl.tiling = 1;      // the interleaved kernel has no batched-chunk / fused-RoPE form
     if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
     // keys an average query block sees; without a host-side length only the chunk itself is certain
     const long lk = p->max_seqlen_k_hint > 0 ? p->max_seqlen_k_hint : p->seqlen_q;

@@ -4,8 +4,15 @@
 
 Signature and semantics follow /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291;
 the work is done by the gfx950 kernels in libvattn_amd.so through the C ABI
-(include/vattn_kernels.h) on torch's current HIP stream.  Arguments this path never uses (rotary,
-paged block_table, alibi, sliding window, softcap, leftpad) raise NotImplementedError.
+(include/vattn_kernels.h) on torch's current HIP stream.  Arguments this path never uses (paged
+block_table, alibi, sliding window, softcap, leftpad) raise NotImplementedError.
+
+Rotary embedding (`rotary_cos` / `rotary_sin` [seqlen_ro, rotary_dim/2], or `_rotary_cos_sin` = the
+reference model's own cos_sin_cache [max_position, rotary_dim]) is FUSED into the launch:
+q and the new k are rotated in registers, the rotated k is what lands in the cache.  NeoX pairing only
+(`rotary_interleaved=False`), rotary_dim == head size, and the arithmetic is that of the reference's
+stand-alone kernel (sarathi-lean/csrc/pos_encoding_kernels.cu: products and sum rounded to the I/O dtype),
+because that is what this path's model code applies (models/yi.py:172-173), not FlashAttention's fp32 form.
 
 Deliberate difference: the reference raises "If key is supplied, it must have seqlen
 <= the seqlen of the KV cache" when the GQA-swapped seqlen_q exceeds the cache view (contexts shorter
@@ -23,6 +30,30 @@ from . import kernels as K
 
 APPEND_ERR = "If key is supplied, it must have seqlen <= the seqlen of the KV cache"
 _workspaces = {}
+_rotary_cat = {}      # (cos ptr, sin ptr) -> the [S, rotary_dim] cat(cos, sin) tensor the kernels read
+
+
+def _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q):
+    if _rotary_cos_sin is None and rotary_cos is None and rotary_sin is None:
+        return None
+    if rotary_interleaved:
+        raise NotImplementedError("fused rotary embedding implements the NeoX pairing only (pass rotary_interleaved=False)")
+    if _rotary_cos_sin is None:
+        if rotary_cos is None or rotary_sin is None:
+            raise RuntimeError("rotary_cos and rotary_sin must be given together")
+        key = (rotary_cos.data_ptr(), rotary_sin.data_ptr(), tuple(rotary_cos.shape))
+        t = _rotary_cat.get(key)
+        if t is None:
+            if len(_rotary_cat) > 8:
+                _rotary_cat.clear()
+            t = _rotary_cat[key] = torch.cat((rotary_cos, rotary_sin), dim=-1).to(q.dtype).contiguous()
+        _rotary_cos_sin = t
+    t = _rotary_cos_sin
+    if t.dtype != q.dtype or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError("rotary cos/sin table must be a [positions, rotary_dim] GPU tensor of the query's dtype")
+    if t.shape[1] != q.shape[-1]:
+        raise NotImplementedError("fused rotary embedding needs rotary_dim == head size")
+    return t
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -64,9 +95,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             cache_batch_idx: Optional[torch.Tensor] = None, cache_leftpad=None, block_table=None,
                             softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                             rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
-                            out=None, _variant=0, _max_seqlen_k: int = 0):
-    if rotary_cos is not None or rotary_sin is not None:
-        raise NotImplementedError("rotary embedding inside flash_attn_with_kvcache is not used by the vAttention path")
+                            out=None, _variant=0, _max_seqlen_k: int = 0, _rotary_cos_sin=None):
+    rot = _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q)
     if block_table is not None:
         raise NotImplementedError("paged KV (block_table) is what vAttention replaces; not supported")
     if alibi_slopes is not None or cache_leftpad is not None or tuple(window_size) != (-1, -1) or softcap != 0.0:
@@ -140,6 +170,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.softmax_scale = float(softmax_scale)
     p.variant = int(_variant)
     p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
+    if rot is not None:
+        p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
     _launch(p, dev)
     return (out, lse) if return_softmax_lse else out
 
@@ -155,7 +187,8 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
 
 def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q_lens: torch.Tensor, max_q_len: int,
                                    cache_seqlens: torch.Tensor, cache_batch_idx: Optional[torch.Tensor] = None,
-                                   softmax_scale=None, causal=True, out=None, num_splits=0, _variant=0, _max_seqlen_k: int = 0):
+                                   softmax_scale=None, causal=True, out=None, num_splits=0, _variant=0, _max_seqlen_k: int = 0,
+                                   _rotary_cos_sin=None):
     """MI355X extension (SURVEY §8f "batched multi-prefill"): ONE launch for the prefill chunks of several sequences with
     different lengths.  q / out are the flattened tokens [T, Hq, D]; entry i attends with rows [q_start[i], q_start[i] +
     q_lens[i]) over cache slot cache_batch_idx[i] (identity if None), keys [0, cache_seqlens[i]) — the chunk's own K/V must
@@ -204,5 +237,8 @@ def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q
     p.softmax_scale = float(softmax_scale)
     p.variant = int(_variant)
     p.max_seqlen_k_hint = min(int(_max_seqlen_k), Sk) if _max_seqlen_k > 0 else 0
+    if _rotary_cos_sin is not None:      # q rows of entry i are rotated at positions (cache_seqlens[i] - q_lens[i]) + row
+        rot = _rotary_table(None, None, _rotary_cos_sin, False, q)
+        p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
     _launch(p, dev)
     return out

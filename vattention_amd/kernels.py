@@ -26,6 +26,7 @@ class AttnParams(C.Structure):
         ("b", i32), ("seqlen_q", i32), ("seqlen_k", i32), ("seqlen_knew", i32), ("h", i32), ("h_k", i32), ("d", i32),
         ("is_causal", i32), ("dtype", i32), ("num_splits", i32), ("softmax_scale", C.c_float), ("variant", i32),
         ("max_seqlen_k_hint", i32),
+        ("rotary_cos_sin", vp), ("rotary_row_stride", i64), ("rotary_dim", i32), ("rotary_reserved", i32),
     ]
 
 
@@ -42,6 +43,10 @@ def klib():
         lib.vattn_flash_attn_with_kvcache.argtypes = [C.POINTER(AttnParams), vp]
         lib.vattn_cache_flat.restype = i32
         lib.vattn_cache_flat.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp]
+        lib.vattn_cache_flat_rope.restype = i32
+        lib.vattn_cache_flat_rope.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp, i64, i64, vp]
+        lib.vattn_rotary_embedding.restype = i32
+        lib.vattn_rotary_embedding.argtypes = [vp, vp, vp, i64, i32, i32, i32, i64, i64, i32, vp, i64, i32, i32, vp]
         lib.vattn_selftest_layouts.restype = i32
         lib.vattn_selftest_layouts.argtypes = [vp, C.POINTER(i32)]
         lib.vattn_time_attn.restype = C.c_float
