@@ -10,10 +10,12 @@
 //   * software pipeline inside the wave: phase A  S(t+1) = K(t+1).Q^T  ||  P(t) = exp2(S(t)), row sums;
 //                                        phase B  O += V(t)^T.P(t)^T   ||  row max of S(t+1), f16 packing of P(t);
 //     so the softmax VALU work of a tile is issued between the MFMAs of its neighbours by the same wave;
-//   * Q is pre-scaled by softmax_scale*log2(e) when it is loaded, and the running maximum enters the S^T accumulator as the
-//     C operand of the first MFMA of each chain (S' = K.Q^T - m): one v_exp per score, no fma; the running maximum is only
-//     moved when a tile's maximum exceeds it by more than 2^kDeferLog2 (deferred rescale, cdna guide T13) — O, l and the
-//     pending S(t+1) are rescaled exactly once in that (rare) branch.
+//   * softmax exactly as the reference states it (softmax.h:69-94): P = exp2(s*scale*log2e - m*scale*log2e) in fp32, one v_fma
+//     + one v_exp per score; the running maximum is only moved when a tile's maximum exceeds it by more than 2^kDeferLog2
+//     (deferred rescale, cdna guide T13) — O and l are rescaled exactly once in that (rare) branch, the pending S(t+1) is still
+//     raw and needs nothing.  [Measured and dropped: pre-scaling Q (rounds q once more: 2.2x the reference-numerics error on
+//     short contexts) and carrying -m in the accumulators (64 extra moves per tile) — with one wave per SIMD the kernel is bound
+//     by instruction ISSUE (about 8 slots per MFMA), so the instruction count per tile is what matters.]
 // Semantics as prefill_kernels.hip: /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, mask.h:164-196
 // (bottom-right causal), softmax.h:69-157 (fp32 max/sum via exp2, P rounded to the I/O dtype before PV),
 // flash_fwd_kernel.h:57-499 (the operator's non-split kernel), :1116-1297 (split combine, here combine_rows_kernel).
@@ -55,9 +57,9 @@ template <typename T> struct Mfma;
 #define VATTN_MFMA_STRUCT(TYPE, MNEM)                                                                                              \
     template <> struct Mfma<TYPE> {                                                                                                \
         using V8 = typename Tr<TYPE>::v8;                                                                                          \
-        /* S'(vgpr) += A(vgpr) x B(agpr); the accumulator was pre-filled with -max */                                              \
-        static __device__ __forceinline__ void qk_acc_nop(f32x16& d, V8 a, V8 b) {                                                 \
-            asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));                                         \
+        /* S(vgpr) = A(vgpr) x B(agpr) + 0: the first MFMA of a chain */                                                           \
+        static __device__ __forceinline__ void qk_first(f32x16& d, V8 a, V8 b) {                                                   \
+            asm volatile(MNEM " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));                                                       \
         }                                                                                                                          \
         static __device__ __forceinline__ void qk_acc(f32x16& d, V8 a, V8 b) {                                                     \
             asm volatile(MNEM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));                                                       \
@@ -87,11 +89,8 @@ __device__ __forceinline__ float add1(float a, float b) {
 // ABL (timing ablations for tools/kbench.py, results are WRONG when non-zero; the product instantiates 0): bit 0 no LDS-DMA in the
 // steady state, bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the
 // first MFMAs of a phase, bit 5 no f16 packing.
-// NA: exp2 pairs (of the tile's 32) evaluated in phase A, the rest in phase B.
-// EXACT: Q is NOT pre-scaled; the scale is applied to S' in fp32 before exp2 (one more VALU per score), exactly the reference's
-// exp2((s - m) * scale * log2e) (softmax.h:69-94).  Pre-scaling rounds softmax_scale*log2e*q to the I/O dtype: one more
-// half-ulp error on q, measured 2.2x the reference-numerics error on a 410-key case against a 2x allowance.
-template <typename T, int ABL, int NA, bool EXACT>
+// NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.
+template <typename T, int ABL, int NA>
 __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
     using X = Tr<T>;
     using V8 = typename X::v8;
@@ -191,9 +190,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     dma_k_all(tb + 1);
 
     // Q^T fragments (B operand of S^T = K.Q^T): slot (g, j) <-> d = 16*kk + 8*g + j; pre-scaled into the log2 domain
-    const float qscale = EXACT ? 1.0f : p.softmax_scale * kLog2e;
-    const float escale = EXACT ? p.softmax_scale * kLog2e : 1.0f;      // applied to S' before exp2
-    const float defer_thr = kDeferLog2 / escale;                        // the deferral threshold in the units of S'
+    const float escale = p.softmax_scale * kLog2e;                      // raw score -> log2 domain
     V8 qf[2][KK];
 #pragma unroll
     for (int qc = 0; qc < 2; qc++) {
@@ -219,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         for (int kk = 0; kk < KK; kk++) {
             V8 sc8;
 #pragma unroll
-            for (int j = 0; j < 8; j++) sc8[j] = EXACT ? raw[kk][j] : X::cvt((float)raw[kk][j] * qscale);
+            for (int j = 0; j < 8; j++) sc8[j] = raw[kk][j];
             qf[qc][kk] = sc8;
             asm volatile("" : "+a"(qf[qc][kk]));       // materialise the fragment as ONE 4-register accumulator tuple, here
         }
@@ -230,17 +227,15 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     for (int i = 0; i < DB; i++)
 #pragma unroll
         for (int qc = 0; qc < 2; qc++) o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // -(running max) of the lane's query, in the units of S'.  It enters S' = K.Q^T - m through the ACCUMULATOR: the registers
-    // that will receive S'(t+2) are filled with it during the bare groups of step t (a separate 16-register broadcast block
-    // per query block as MFMA C operand would cost 32 of the 256 architectural registers)
-    float negm[2];
+    // -(running max) * softmax_scale * log2e of the lane's query: the addend of the exp2 argument (softmax.h:86-94)
+    float nmsub[2];
     // lane-local partial row sums (the other half-lane holds the other 32 keys of every tile), TWO independent accumulators per
     // query block, each touched once per MFMA group at most: with one wave per SIMD a dependent VALU chain stalls the wave, and a
     // stalled wave issues no MFMA either
     float l_acc[2][2];
 #pragma unroll
     for (int qc = 0; qc < 2; qc++) {
-        negm[qc] = 0.f;
+        nmsub[qc] = 0.f;
 #pragma unroll
         for (int a4 = 0; a4 < 2; a4++) l_acc[qc][a4] = 0.f;
     }
@@ -287,18 +282,11 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         for (int r = 1; r < 16; r++) m0 = fmaxf(fmaxf(m0, s[0][qc][r]), s[1][qc][r]);     // v_max3_f32
         return fmaxf(m0, swap_halves(m0));
     };
-    // moves the running maximum of query block qc up by delta >= 0 (per lane): everything still at the old scale — O, l and the
-    // not yet exponentiated S' of the tile that triggered it — is rescaled exactly once (cdna guide T13)
-    auto raise_max = [&](int qc, float delta, f32x16 (&s)[2][2], f32x16 (&pre)[2][2]) {
-        const float alpha = fast_exp2(-delta * escale);
-        negm[qc] -= delta;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            s[0][qc][r] -= delta;
-            s[1][qc][r] -= delta;
-            pre[0][qc][r] -= delta;       // the accumulators already holding -m for the tile after next
-            pre[1][qc][r] -= delta;
-        }
+    // moves the running maximum of query block qc up by delta >= 0 (log2 units, per lane): everything accumulated at the old scale
+    // — O and l — is rescaled exactly once (cdna guide T13); scores not yet exponentiated are raw and take the new maximum
+    auto raise_max = [&](int qc, float delta) {
+        const float alpha = fast_exp2(-delta);
+        nmsub[qc] -= delta;
 #pragma unroll
         for (int i = 0; i < DB; i++)
 #pragma unroll
@@ -317,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's pieces of K(tb) landed; V(tb), K(tb+1) may still fly
     __builtin_amdgcn_s_barrier();
 
-    f32x16 sc[2][2];      // S'(t): scores of the current tile minus the running max, log2 domain; becomes P(t) in place
+    f32x16 sc[2][2];      // S(t): raw scores of the current tile; becomes P(t) in place
     f32x16 sd[2][2];
     {
         const char* ksm = smem + (tb & 1) * S::kTileBytes;
@@ -326,12 +314,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             const V8 a = kfrag(ksm, f);
 #pragma unroll
             for (int qc = 0; qc < 2; qc++) {
-                if (f < 2) {
-                    sc[f & 1][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    M::qk_acc_nop(sc[f & 1][qc], a, qf[qc][f >> 1]);
-                } else {
-                    M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
-                }
+                if (f < 2) M::qk_first(sc[f & 1][qc], a, qf[qc][f >> 1]);
+                else M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
             }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // the last MFMA results are VALU-readable from here
@@ -340,22 +324,15 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 #pragma unroll
         for (int qc = 0; qc < 2; qc++) {
             const float mx = row_max(sc, qc);
-            const float delta = (mx == -INFINITY) ? 0.f : mx;       // softmax.h: a fully masked row keeps a zero reference
-            negm[qc] = -delta;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc[0][qc][r] -= delta;
-                sc[1][qc][r] -= delta;
-                sd[0][qc][r] = -delta;      // S'(tb+1) accumulates on top of -m
-                sd[1][qc][r] = -delta;
-            }
+            nmsub[qc] = (mx == -INFINITY) ? 0.f : -mx * escale;     // softmax.h: a fully masked row keeps a zero reference
         }
     }
 
     // ---- software pipeline of the softmax VALU work, in units of PAIRS of scores (pair e: key block e>>4, half (e>>3)&1, query
     // block (e>>2)&1, registers 8*half + 2*(e&3), +1 — the order in which the P.V key slices consume them).  Stage E (two
-    // v_exp) of pair e sits in group GE(e) of the tile's 64 MFMA groups, stage M (EXACT: two v_mul) one group earlier, stage A
-    // (two v_add into two of the four accumulators) one group later: no instruction waits for the one before it.
+    // v_exp) of pair e sits in group GE(e) of the tile's 64 MFMA groups, stage M (two v_fma: s*scale*log2e - m*scale*log2e) one
+    // group earlier, stage A (two v_add into the two row-sum accumulators) one group later: no instruction waits for the one
+    // before it (one wave per SIMD: a stalled wave issues no MFMA either).
     auto GE = [](int e) { return e < NA ? 1 + (e * 30) / NA : 33 + ((e - NA) * 17) / (32 - NA); };
 #define P64_X0(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3)]
 #define P64_X1(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3) + 1]
@@ -363,21 +340,22 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         if (ABL & 2) return;
 #pragma unroll
         for (int e = 0; e < 32; e++) {
-            const int qc = (e >> 2) & 1, a0 = 0;
-            if (EXACT && GE(e) - 1 == G) asm("v_mul_f32 %0, %2, %0\n\tv_mul_f32 %1, %2, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale));
+            const int qc = (e >> 2) & 1;
+            if (GE(e) - 1 == G)
+                asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale), "v"(nmsub[qc]));
             if (GE(e) == G) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
             if (GE(e) + 1 == G)
-                asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][a0]), "+v"(l_acc[qc][a0 + 1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
+                asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][0]), "+v"(l_acc[qc][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
         }
     };
 
-    // One tile step of the wave.  cur holds S'(t) on entry and P(t) afterwards, nxt receives S'(t+1); kf0 / kf1 hold the first two
+    // One tile step of the wave.  cur holds S(t) on entry and P(t) afterwards, nxt receives S(t+1); kf0 / kf1 hold the first two
     // K(t+1) fragments on entry (read before the previous step ended) and the first two of K(t+2) on exit.
     // Invariants at entry: K(t+1) and V(t) have landed and every wave knows it (the barrier of step t-1); K(t+2) and V(t+1) are
     // in flight.  The barrier of this step sits in phase B after group 23: by then every wave has finished reading K(t+1)
     // (phase A) and V(t-1) (step t-1), so K(t+3) -> slot of K(t+1) and V(t+2) -> slot of V(t-1) are issued right behind it, one
     // piece per group in the eight groups that carry no softmax work.
-    auto step = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1) {
+    auto step = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2) {
         const char* ksm = smem + ((t + 1) & 1) * S::kTileBytes;
         const char* ksm_next = smem + (t & 1) * S::kTileBytes;                  // K(t+2)
         const char* vsm = smem + 2 * S::kTileBytes + (t % 3) * S::kTileBytes;
@@ -390,23 +368,26 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         // maximum alone; past the last tile S'(t+1) is computed from a zero-filled K slot and never used.
         // ---------------- 64 groups of { MFMA ; fragment read ahead ; a slice of softmax VALU } ----------------
         // phase A: S'(t+1) = K(t+1).Q^T - m   (32 MFMAs: k-step kk = i>>2, key block (i>>1)&1, query block i&1)
-        V8 kf[3];
+        V8 kf[4];            // ring of four, three fragments (six MFMAs) ahead of their use
         kf[0] = kf0;
         kf[1] = kf1;
+        kf[2] = kf2;
         SCHED_FENCE();
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const int f = i >> 1, qc = i & 1;
-            M::qk_acc(nxt[f & 1][qc], kf[f % 3], qf[qc][f >> 1]);       // nxt was pre-filled with -m one step ago
-            if ((i & 1) == 0 && f + 2 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + 2) % 3] = kfrag(ksm, f + 2);
+            if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f & 3], qf[qc][f >> 1]);
+            else M::qk_acc(nxt[f & 1][qc], kf[f & 3], qf[qc][f >> 1]);
+            if ((i & 1) == 0 && f + 3 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + 3) & 3] = kfrag(ksm, f + 3);
             softmax_stages(i, cur);
             SCHED_FENCE();
         }
         // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
-        V8 vf[3];
+        V8 vf[4];
         V8 pf[2][2];
         vf[0] = vfrag(vsm, 0);
         vf[1] = vfrag(vsm, 1);
+        vf[2] = vfrag(vsm, 2);
         pf[0][0] = pack_p(cur, 0, 0);
         pf[0][1] = pack_p(cur, 0, 1);
         float mx0 = -INFINITY, mx1 = -INFINITY;
@@ -420,9 +401,9 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
-            else M::pv(o[f & 3][qc], vf[f % 3], pf[ks & 1][qc]);
-            if ((j & 1) == 0 && f + 2 < 16 && !((ABL & 16) && f >= 1)) vf[(f + 2) % 3] = vfrag(vsm, f + 2);
+            if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f & 3], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
+            else M::pv(o[f & 3][qc], vf[f & 3], pf[ks & 1][qc]);
+            if ((j & 1) == 0 && f + 3 < 16 && !((ABL & 16) && f >= 1)) vf[(f + 3) & 3] = vfrag(vsm, f + 3);
             softmax_stages(32 + j, cur);
             // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
             if (!(ABL & 32)) {
@@ -445,18 +426,9 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 if (j == 30) dma_piece(lv0 + 2048, rv, voff[2]);
                 if (j == 31) dma_piece(lv0 + 3072, rv, voff[3]);
             }
-            if (j >= 24) {
-                // P(t) is dead (last packed in group 22): its registers become the accumulators of S'(t+2), pre-filled with -m
-                const int kb = (j >> 2) & 1, qq = (j >> 1) & 1, hf = j & 1;
-                // (asm volatile: as plain assignments hipcc sinks the 64 moves out of the MFMA groups into the block behind the loop body)
-                asm volatile("v_mov_b32 %0, %8\n\tv_mov_b32 %1, %8\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %8\n\tv_mov_b32 %5, %8\n\t"
-                             "v_mov_b32 %6, %8\n\tv_mov_b32 %7, %8"
-                             : "=v"(cur[kb][qq][8 * hf + 0]), "=v"(cur[kb][qq][8 * hf + 1]), "=v"(cur[kb][qq][8 * hf + 2]), "=v"(cur[kb][qq][8 * hf + 3]),
-                               "=v"(cur[kb][qq][8 * hf + 4]), "=v"(cur[kb][qq][8 * hf + 5]), "=v"(cur[kb][qq][8 * hf + 6]), "=v"(cur[kb][qq][8 * hf + 7])
-                             : "v"(negm[qq]));
-            }
-            if (j == 28) kf0 = kfrag(ksm_next, 0);          // the next step's first K fragments: K(t+2) is behind the barrier
-            if (j == 29) kf1 = kfrag(ksm_next, 1);
+            if (j == 27) kf0 = kfrag(ksm_next, 0);          // the next step's first K fragments: K(t+2) is behind the barrier
+            if (j == 28) kf1 = kfrag(ksm_next, 1);
+            if (j == 29) kf2 = kfrag(ksm_next, 2);
             SCHED_FENCE();
         }
         mx0 = fmaxf(mx0, swap_halves(mx0));
@@ -466,11 +438,13 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             mx0 = row_max(nxt, 0);
             mx1 = row_max(nxt, 1);
         }
-        if (__builtin_amdgcn_ballot_w64(fmaxf(mx0, mx1) > defer_thr) != 0) {      // rare: a row's maximum grew by > 2^6
+        // growth of the row maxima over the running maxima, log2 units (nmsub = -m*scale*log2e; -inf for rows that see nothing here)
+        const float g0 = __builtin_fmaf(mx0, escale, nmsub[0]), g1 = __builtin_fmaf(mx1, escale, nmsub[1]);
+        if (__builtin_amdgcn_ballot_w64(fmaxf(g0, g1) > kDeferLog2) != 0) {          // rare: a row's maximum grew by > 2^6
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");                        // every PV result has landed in O
             SCHED_FENCE();
-            raise_max(0, fmaxf(mx0, 0.f), nxt, cur);
-            raise_max(1, fmaxf(mx1, 0.f), nxt, cur);
+            raise_max(0, fmaxf(g0, 0.f));
+            raise_max(1, fmaxf(g1, 0.f));
             SCHED_FENCE();
             asm volatile("s_nop 3" ::: "memory");                                    // accvgpr writes -> next MFMA read
         }
@@ -480,10 +454,11 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     __builtin_amdgcn_s_barrier();                    // also: every wave is done with K(tb) (the prologue's S')
     dma_k_all(tb + 2);
     dma_v_all(tb + 1);
-    V8 kfa = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 0), kfb = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 1);
+    V8 kfa = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 0), kfb = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 1),
+       kfc = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 2);
     for (int t = tb; t < nt; t += 2) {
-        step(t, sc, sd, kfa, kfb);
-        if (t + 1 < nt) step(t + 1, sd, sc, kfa, kfb);
+        step(t, sc, sd, kfa, kfb, kfc);
+        if (t + 1 < nt) step(t + 1, sd, sc, kfa, kfb, kfc);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // trailing DMA retired (nothing may land in LDS of
     SCHED_FENCE();                                                                // a later workgroup); last PV results readable
@@ -498,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         const float l_loc = l_acc[qc][0] + l_acc[qc][1];
         const float l_tot = l_loc + swap_halves(l_loc);
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-        const float m_log2 = -negm[qc] * escale;              // running max of softmax_scale*log2e*q.k
+        const float m_log2 = -nmsub[qc];                      // running max of softmax_scale*log2e*q.k
         if (my_q < Sq && nsplit > 1) {
             // KV-split: normalised fp32 partial + its log2-domain LSE; combine_rows_kernel merges the nsplit partials of a row
             const int64_t row = (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
@@ -559,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 // host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
-template <typename T, int ABL, int NA, bool EXACT> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+template <typename T, int ABL, int NA> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -572,31 +547,28 @@ template <typename T, int ABL, int NA, bool EXACT> static void launch64_t(const 
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * PfSmem<128>::kTileBytes);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * PfSmem<128>::kTileBytes);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, EXACT>), grid, dim3(256), 5 * PfSmem<128>::kTileBytes, st, *p, order, nqb, nsplit);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA>), grid, dim3(256), 5 * PfSmem<128>::kTileBytes, st, *p, order, nqb, nsplit);
 }
 
-// variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1 = pre-scaled Q (one VALU less per score, 2.2x the
-// reference-numerics error on short contexts); 4.. = timing ablations (wrong results)
+// variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 4.. = timing ablations (wrong results)
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int sel = (p->variant >> 8) & 15;
     if (p->dtype == VATTN_DTYPE_BF16) {
-        if (sel == 1) launch64_t<__bf16, 0, 24, false>(p, st, nsplit);
-        else launch64_t<__bf16, 0, 24, true>(p, st, nsplit);
+        launch64_t<__bf16, 0, 24>(p, st, nsplit);
         return;
     }
     switch (sel) {
-        case 1: launch64_t<_Float16, 0, 24, false>(p, st, nsplit); break;
-        case 4: launch64_t<_Float16, 1, 24, true>(p, st, nsplit); break;          // no LDS-DMA in the steady state
-        case 5: launch64_t<_Float16, 2, 24, true>(p, st, nsplit); break;          // no exp2 / row sums
-        case 6: launch64_t<_Float16, 8, 24, true>(p, st, nsplit); break;          // no per-tile wait + barrier
-        case 7: launch64_t<_Float16, 16, 24, true>(p, st, nsplit); break;         // no LDS fragment reads
-        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32, 24, true>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
-        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32, 24, true>(p, st, nsplit); break;   // MFMAs only
-        default: launch64_t<_Float16, 0, 24, true>(p, st, nsplit); break;
+        case 4: launch64_t<_Float16, 1, 24>(p, st, nsplit); break;          // no LDS-DMA in the steady state
+        case 5: launch64_t<_Float16, 2, 24>(p, st, nsplit); break;          // no fma / exp2 / row sums
+        case 6: launch64_t<_Float16, 8, 24>(p, st, nsplit); break;          // no per-tile wait + barrier
+        case 7: launch64_t<_Float16, 16, 24>(p, st, nsplit); break;         // no LDS fragment reads
+        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32, 24>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
+        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32, 24>(p, st, nsplit); break;   // MFMAs only
+        default: launch64_t<_Float16, 0, 24>(p, st, nsplit); break;
     }
 }
 
