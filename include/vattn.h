@@ -73,7 +73,7 @@ typedef struct vattn_backend_ops {
     /* Make every earlier unmap visible to the GPU (TLB invalidation).  On ROCm 7.2 / gfx950 a kernel keeps
      * using the OLD translation of a virtual page after hipMemUnmap (+ hipMemMap of another handle at the
      * same address) until the driver next services an ordinary allocation (tools/remap_probe*.cpp,
-     * profiles/r01_vmm_probe.md); the manager therefore calls this once after every batch that unmapped
+     * profiles/r01_remap_probe3_raw.txt, r01_remap_probe4_raw.txt); the manager therefore calls this once after every batch that unmapped
      * anything, before the batch is reported complete.  May be NULL (no-op). */
     int (*tlb_flush)(void* ctx);
     /* Wait until every kernel already queued on the device has finished.  Called once per batch before its first

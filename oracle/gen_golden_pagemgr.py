@@ -4,7 +4,7 @@ Run in the build container (where /root/reference exists):
     bash oracle/build_ref.sh && python oracle/gen_golden_pagemgr.py
 Each file holds {"config", "ops", "expect": [per-op records from oracle/_ref]}; records carry the
 return value / error text, mapped_pages[], curr_seq_lengths[], pool size, pool handle order,
-the page map and the driver-call log.  tests/test_pagemgr_golden.py replays the ops on the
+the page map and the driver-call log.  tests/test_pagemgr_oracle.py and tests/test_page_manager_product.py replay the ops on the
 Python oracle and on the product's C++ manager and compares.  TEST INFRASTRUCTURE ONLY.
 """
 import gzip

@@ -120,3 +120,16 @@ def test_split_plans_from_the_workspace_query():
     assert 2 <= pf_splits(1024, 65536, 28, 4, 65536) <= 8
     assert pf_splits(2048, 32768, 8, 1, 32768, variant=12) == 1      # the interleaved kernel has no split epilogue
     assert pf_splits(300, 1400, 8, 2, 1200, splits=5) == 5           # forced
+
+
+def test_layout_policy_moves_huge_pools_to_megacache():
+    """vattention_amd/policy.py: > 100 k handles -> megacache + >= 8 MiB pages unless the configured layout is pinned."""
+    from vattention_amd.policy import choose_layout
+    assert choose_layout(2 << 20, False, 64 << 30) == (2 << 20, False, "configured")                 # 32 k handles
+    page, mega, what = choose_layout(2 << 20, False, 250 << 30)                                       # 128 k handles
+    assert (page, mega) == (8 << 20, True) and what.startswith("auto")
+    assert choose_layout(2 << 20, False, 250 << 30, keep=True) == (2 << 20, False, "configured")
+    page, mega, _ = choose_layout(64 << 10, False, 243 << 30)                                         # configs[2]: 4 M handles
+    assert (page, mega) == (8 << 20, True)
+    page, mega, _ = choose_layout(16 << 20, True, 2000 << 30)                                         # already large pages: kept, megacache on
+    assert (page, mega) == (16 << 20, True)

@@ -50,10 +50,24 @@ class vATTNCacheEngine:
         self.num_layers = model_config.get_num_layers(parallel_config)
         self.num_heads = model_config.get_num_kv_heads(parallel_config)
         self.dtype = model_config.dtype
+        self.layout_policy = self._apply_layout_policy(cache_config)
         self.block_size = getattr(cache_config, "block_size", None)
         self.num_gpu_blocks = getattr(cache_config, "num_gpu_blocks", None)
         self.curr_batch_idx = None
         self.gpu_cache = self.allocate_gpu_cache()
+
+    def _apply_layout_policy(self, cache_config) -> str:
+        """vattention_amd/policy.py: pools that would need > 100 k physical handles move to megacache + 8 MiB pages.  The layout is
+        internal to the engine (the wrapper gets per-layer (K, V) views either way)."""
+        from .policy import choose_layout
+        keep = bool(getattr(cache_config, "vattn_keep_layout", False)) or os.environ.get("VATTN_KEEP_LAYOUT", "0") == "1"
+        page, mega, what = choose_layout(self.page_size, self.vattn_mega_cache, self.cache_mem_size, keep)
+        if what != "configured":
+            import sys
+            print("[vattn] layout policy -> " + what + "; set cache_config.vattn_keep_layout / VATTN_KEEP_LAYOUT=1 to keep the configured layout",
+                  file=sys.stderr)
+        self.page_size, self.vattn_mega_cache = page, mega
+        return what
 
     def num_free_blocks(self) -> int:
         return vattention.num_free_kvblocks()

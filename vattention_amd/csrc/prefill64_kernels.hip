@@ -24,6 +24,7 @@
 
 namespace vattn_k {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float kDeferLog2 = 6.0f;      // P stays below 2^6 between rescales (f16 / bf16 keep their relative precision)
 
 // ---- LDS-DMA: one 1-KiB piece (64 lanes x 16 bytes) of a K or V tile per call ----
@@ -36,6 +37,18 @@ __device__ __forceinline__ void dma_piece(unsigned lds_addr, u32x4 rsrc, unsigne
 }
 __device__ __forceinline__ void dma_piece_first(unsigned lds_addr, u32x4 rsrc, unsigned voff) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(lds_addr), "s"(rsrc), "v"(voff) : "memory", "m0");
+}
+// descriptor from a running (wave-uniform) base pointer and remaining-row count: scalar min/max (the compiler's own clamp is a VALU
+// v_med3 + readfirstlane round trip)
+__device__ __forceinline__ u32x4 running_rsrc(unsigned long long ptr, int rem_rows, unsigned row_bytes) {
+    int r;
+    asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, 64" : "=s"(r) : "s"(rem_rows) : "scc");
+    u32x4 d;
+    d[0] = (unsigned)ptr;
+    d[1] = (unsigned)(ptr >> 32) & 0xffffu;
+    d[2] = (unsigned)r * row_bytes;
+    d[3] = 0x00020000u;
+    return d;
 }
 __device__ __forceinline__ u32x4 tile_rsrc(const void* base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -89,8 +102,9 @@ __device__ __forceinline__ float add1(float a, float b) {
 // ABL (timing ablations for tools/kbench.py, results are WRONG when non-zero; the product instantiates 0): bit 0 no LDS-DMA in the
 // steady state, bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the
 // first MFMAs of a phase, bit 5 no f16 packing.
-// NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.
-template <typename T, int ABL, int NA>
+// NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
+// (RING - 1 fragments ahead of their MFMA).
+template <typename T, int ABL, int NA, int RING>
 __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
     using X = Tr<T>;
     using V8 = typename X::v8;
@@ -344,11 +358,15 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             if (GE(e) - 1 == G)
                 asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale), "v"(nmsub[qc]));
             if (GE(e) == G) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
-            if (GE(e) + 1 == G)
+            if (GE(e) + 1 == G)      // (v_pk_add_f32 was tried: forming the register pairs costs more moves than the adds it saves)
                 asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][0]), "+v"(l_acc[qc][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
         }
     };
 
+    const unsigned long long k_tile_bytes = (unsigned long long)PF_BN * k_rs_bytes, v_tile_bytes = (unsigned long long)PF_BN * v_rs_bytes;
+    unsigned long long k_next_ptr = (unsigned long long)kbase + (unsigned long long)(tb + 3) * k_tile_bytes;
+    unsigned long long v_next_ptr = (unsigned long long)vbase + (unsigned long long)(tb + 2) * v_tile_bytes;
+    int k_next_rem = Lk - (tb + 3) * PF_BN, v_next_rem = Lk - (tb + 2) * PF_BN;
     // One tile step of the wave.  cur holds S(t) on entry and P(t) afterwards, nxt receives S(t+1); kf0 / kf1 hold the first two
     // K(t+1) fragments on entry (read before the previous step ended) and the first two of K(t+2) on exit.
     // Invariants at entry: K(t+1) and V(t) have landed and every wave knows it (the barrier of step t-1); K(t+2) and V(t+1) are
@@ -359,8 +377,14 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         const char* ksm = smem + ((t + 1) & 1) * S::kTileBytes;
         const char* ksm_next = smem + (t & 1) * S::kTileBytes;                  // K(t+2)
         const char* vsm = smem + 2 * S::kTileBytes + (t % 3) * S::kTileBytes;
-        const u32x4 rk = k_rsrc(t + 3);      // past the last tile: zero-record descriptor, nothing is fetched
-        const u32x4 rv = v_rsrc(t + 2);
+        // descriptors of K(t+3) and V(t+2): running base pointers and remaining-row counts, advanced one tile per step with a handful
+        // of SALU instructions (past the last tile the row count clamps to 0: nothing is fetched)
+        const u32x4 rk = running_rsrc(k_next_ptr, k_next_rem, k_rs_bytes);
+        const u32x4 rv = running_rsrc(v_next_ptr, v_next_rem, v_rs_bytes);
+        k_next_ptr += k_tile_bytes;
+        v_next_ptr += v_tile_bytes;
+        k_next_rem -= PF_BN;
+        v_next_rem -= PF_BN;
         const unsigned lk0 = k_lds_wave + (unsigned)(((t + 1) & 1) * S::kTileBytes);
         const unsigned lv0 = v_lds_wave + (unsigned)(((t + 2) % 3) * S::kTileBytes);
         // Every wave runs the SAME straight-line body for every tile of the workgroup (the barrier makes the waves wait for each other
@@ -368,26 +392,26 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         // maximum alone; past the last tile S'(t+1) is computed from a zero-filled K slot and never used.
         // ---------------- 64 groups of { MFMA ; fragment read ahead ; a slice of softmax VALU } ----------------
         // phase A: S'(t+1) = K(t+1).Q^T - m   (32 MFMAs: k-step kk = i>>2, key block (i>>1)&1, query block i&1)
-        V8 kf[4];            // ring of four, three fragments (six MFMAs) ahead of their use
+        V8 kf[RING];         // RING - 1 fragments (twice as many MFMAs) ahead of their use
         kf[0] = kf0;
         kf[1] = kf1;
-        kf[2] = kf2;
+        if (RING > 3) kf[2] = kf2;
         SCHED_FENCE();
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const int f = i >> 1, qc = i & 1;
-            if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f & 3], qf[qc][f >> 1]);
-            else M::qk_acc(nxt[f & 1][qc], kf[f & 3], qf[qc][f >> 1]);
-            if ((i & 1) == 0 && f + 3 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + 3) & 3] = kfrag(ksm, f + 3);
+            if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
+            else M::qk_acc(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
+            if ((i & 1) == 0 && f + RING - 1 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + RING - 1) % RING] = kfrag(ksm, f + RING - 1);
             softmax_stages(i, cur);
             SCHED_FENCE();
         }
         // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
-        V8 vf[4];
+        V8 vf[RING];
         V8 pf[2][2];
         vf[0] = vfrag(vsm, 0);
         vf[1] = vfrag(vsm, 1);
-        vf[2] = vfrag(vsm, 2);
+        if (RING > 3) vf[2] = vfrag(vsm, 2);
         pf[0][0] = pack_p(cur, 0, 0);
         pf[0][1] = pack_p(cur, 0, 1);
         float mx0 = -INFINITY, mx1 = -INFINITY;
@@ -401,9 +425,9 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f & 3], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
-            else M::pv(o[f & 3][qc], vf[f & 3], pf[ks & 1][qc]);
-            if ((j & 1) == 0 && f + 3 < 16 && !((ABL & 16) && f >= 1)) vf[(f + 3) & 3] = vfrag(vsm, f + 3);
+            if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
+            else M::pv(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
+            if ((j & 1) == 0 && f + RING - 1 < 16 && !((ABL & 16) && f >= 1)) vf[(f + RING - 1) % RING] = vfrag(vsm, f + RING - 1);
             softmax_stages(32 + j, cur);
             // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
             if (!(ABL & 32)) {
@@ -428,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             }
             if (j == 27) kf0 = kfrag(ksm_next, 0);          // the next step's first K fragments: K(t+2) is behind the barrier
             if (j == 28) kf1 = kfrag(ksm_next, 1);
-            if (j == 29) kf2 = kfrag(ksm_next, 2);
+            if (j == 29 && RING > 3) kf2 = kfrag(ksm_next, 2);
             SCHED_FENCE();
         }
         mx0 = fmaxf(mx0, swap_halves(mx0));
@@ -534,7 +558,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 // host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
-template <typename T, int ABL, int NA> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+template <typename T, int ABL, int NA, int RING> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -547,28 +571,33 @@ template <typename T, int ABL, int NA> static void launch64_t(const vattn_attn_p
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * PfSmem<128>::kTileBytes);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * PfSmem<128>::kTileBytes);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA>), grid, dim3(256), 5 * PfSmem<128>::kTileBytes, st, *p, order, nqb, nsplit);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), 5 * PfSmem<128>::kTileBytes, st, *p, order, nqb, nsplit);
 }
 
-// variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 4.. = timing ablations (wrong results)
+// variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1-3, 10-12 = schedule variants; 4-9 = timing
+// ablations (wrong results)
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int sel = (p->variant >> 8) & 15;
     if (p->dtype == VATTN_DTYPE_BF16) {
-        launch64_t<__bf16, 0, 24>(p, st, nsplit);
+        launch64_t<__bf16, 0, 24, 4>(p, st, nsplit);
         return;
     }
     switch (sel) {
-        case 4: launch64_t<_Float16, 1, 24>(p, st, nsplit); break;          // no LDS-DMA in the steady state
-        case 5: launch64_t<_Float16, 2, 24>(p, st, nsplit); break;          // no fma / exp2 / row sums
-        case 6: launch64_t<_Float16, 8, 24>(p, st, nsplit); break;          // no per-tile wait + barrier
-        case 7: launch64_t<_Float16, 16, 24>(p, st, nsplit); break;         // no LDS fragment reads
-        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32, 24>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
-        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32, 24>(p, st, nsplit); break;   // MFMAs only
-        default: launch64_t<_Float16, 0, 24>(p, st, nsplit); break;
+        case 1: launch64_t<_Float16, 0, 20, 4>(p, st, nsplit); break;
+        case 2: launch64_t<_Float16, 0, 16, 4>(p, st, nsplit); break;
+        case 3: launch64_t<_Float16, 0, 24, 3>(p, st, nsplit); break;
+        case 11: launch64_t<_Float16, 0, 20, 3>(p, st, nsplit); break;
+        case 4: launch64_t<_Float16, 1, 24, 4>(p, st, nsplit); break;          // no LDS-DMA in the steady state
+        case 5: launch64_t<_Float16, 2, 24, 4>(p, st, nsplit); break;          // no fma / exp2 / row sums
+        case 6: launch64_t<_Float16, 8, 24, 4>(p, st, nsplit); break;          // no per-tile wait + barrier
+        case 7: launch64_t<_Float16, 16, 24, 4>(p, st, nsplit); break;         // no LDS fragment reads
+        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32, 24, 4>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
+        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32, 24, 4>(p, st, nsplit); break;   // MFMAs only
+        default: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit); break;
     }
 }
 

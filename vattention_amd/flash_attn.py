@@ -36,9 +36,9 @@ _rotary_cat = {}      # (cos ptr, sin ptr) -> the [S, rotary_dim] cat(cos, sin) 
 def _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q):
     if _rotary_cos_sin is None and rotary_cos is None and rotary_sin is None:
         return None
-    if rotary_interleaved:
-        raise NotImplementedError("fused rotary embedding implements the NeoX pairing only (pass rotary_interleaved=False)")
     if _rotary_cos_sin is None:
+        if rotary_interleaved:      # (the model-side table `_rotary_cos_sin` is NeoX by construction: models/yi.py is_neox_style=True)
+            raise NotImplementedError("fused rotary embedding implements the NeoX pairing only (pass rotary_interleaved=False)")
         if rotary_cos is None or rotary_sin is None:
             raise RuntimeError("rotary_cos and rotary_sin must be given together")
         key = (rotary_cos.data_ptr(), rotary_sin.data_ptr(), tuple(rotary_cos.shape))

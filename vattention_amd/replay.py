@@ -71,6 +71,7 @@ class CacheConfig:
     memory_for_gpu: int
     block_size: Optional[int] = None
     num_gpu_blocks: Optional[int] = None
+    vattn_keep_layout: bool = False      # True: never let the cache engine's layout policy replace the configured page size / layout
 
 
 class Sequence:
@@ -140,11 +141,12 @@ class HotPathRunner:
         self.iter_hook = None       # called once per iteration right after engine.step (bench.py: the TP control-plane exchange)
         # Compute runs on a NON-BLOCKING stream: on ROCm 7.2 hipMemMap / hipMemUnmap wait for work queued on
         # the legacy default stream (and every blocking stream) but not for non-blocking streams
-        # (tools/vmm_probe.cpp, profiles/r01_vmm_probe.md), so this is what lets page mapping — on the
+        # (tools/vmm_probe.cpp, profiles/r01_vmm_sync_probe_raw.txt), so this is what lets page mapping — on the
         # mapper thread or in step_async's synchronous part — overlap the forward pass.
         self.stream = torch.cuda.Stream(device=self.device)
         from . import vattention as _va
         self._tpp = _va.layout()["tokens_per_page"]
+        self.page_size = self.engine.page_size       # what the engine actually uses (its layout policy may have replaced the configured one)
 
     def _qkv(self, T: int):
         # synthetic N(0,1) activations, one set per token count (the transformer body is out of scope)
@@ -315,6 +317,8 @@ class HotPathRunner:
             "sync_map_ms": (vm1["sync_ns"] - vm0["sync_ns"]) / 1e6, "async_map_ms": (vm1["async_ns"] - vm0["async_ns"]) / 1e6,
             "join_wait_ms": (vm1["join_wait_ns"] - vm0["join_wait_ns"]) / 1e6,
             "tlb_flushes": vm1["tlb_flushes"] - vm0["tlb_flushes"], "tlb_flush_ms": (vm1["tlb_flush_ns"] - vm0["tlb_flush_ns"]) / 1e6,
+            "handles_created": vm1["handles_created"] - vm0["handles_created"], "create_ms": round((vm1["create_ns"] - vm0["create_ns"]) / 1e6, 1),
+            "fence_waits": vm1["fence_waits"] - vm0["fence_waits"], "quiesce_calls": vm1["quiesce_calls"] - vm0["quiesce_calls"],
         })
         out.pop("util_at_peak")
         return out
