@@ -144,6 +144,12 @@ int vattn_free_batch_idx(vattn_t* m, int slot);
 /* free_batch_idx + a fence on `stream` (a hipStream_t; the stream the iteration that last reads the slot was launched on):
  * a later reclaim of the slot's pages waits for that point only instead of synchronising the whole device. */
 int vattn_free_batch_idx_on_stream(vattn_t* m, int slot, void* stream);
+/* Admission look-ahead (MI355X extension): reserve the slot alloc_new_batch_idx(seqlen) would return and map the pages `seqlen`
+ * tokens need on the MAPPER thread, while the current iteration runs.  Returns the slot (-1: none free).  The slot stays
+ * inactive until its length is passed to vattn_step / vattn_step_async (which then maps nothing for it on the critical
+ * path); alloc_new_batch_idx skips reserved slots; vattn_free_batch_idx / vattn_cancel_premap release the reservation. */
+int vattn_premap(vattn_t* m, uint64_t seqlen);
+int vattn_cancel_premap(vattn_t* m, int slot);
 /* VATTN_FLAG_LAYERED_ASYNC: block until the pages the current step needs are mapped for `layer` (returns at once when no
  * layered batch is pending); VATTN_ERR_* if the mapper failed.  vattn_layers_ready: layers mapped so far (num_layers when
  * nothing is pending).  vattn_set_sync_layers: layers mapped before step_async returns (default 2). */

@@ -30,7 +30,14 @@ int main() {
     std::mt19937 rng(7);
     std::vector<uint64_t> lens(16, 0);
     std::vector<uint64_t> target(16, 0);
+    int pre_slot = -1;
+    uint64_t pre_len = 0;
     for (int it = 0; it < 4000; it++) {
+        if (pre_slot >= 0) {                                     // the request looked ahead for arrives (or is dropped)
+            if (rng() % 8 == 0) vattn_cancel_premap(m, pre_slot);
+            else { lens[pre_slot] = pre_len; target[pre_slot] = pre_len + rng() % 300; }
+            pre_slot = -1;
+        }
         if (rng() % 3 == 0) {
             const uint64_t n = 1 + rng() % 2000;
             const int s = vattn_alloc_new_batch_idx(m, n);
@@ -39,6 +46,10 @@ int main() {
         const int rc = (it % 5 == 4) ? vattn_step(m, lens.data(), 16, 1) : vattn_step_async(m, lens.data(), 16);
         if (rc != 0 && rc != VATTN_ERR_OOM) { printf("step failed %d: %s\n", rc, vattn_last_error(m)); return 3; }
         (void)vattn_num_free_kvblocks(m);
+        if (rng() % 4 == 0) {                                    // admission look-ahead while the mapper still works on the step's batch
+            pre_len = 1 + rng() % 2000;
+            pre_slot = vattn_premap(m, pre_len);
+        }
         for (uint32_t l = 0; l < cfg.num_layers; l++) {          // what the attention wrapper does before each layer
             if (vattn_wait_layer(m, l) != 0) { printf("wait_layer failed\n"); return 5; }
             if (vattn_layers_ready(m) <= l) { printf("layer %u not ready after wait\n", l); return 6; }

@@ -376,3 +376,91 @@ def test_layer_ordered_async_mapping():
     p.step_async(lens); p.pm.wait()
     assert p.pm.stats()["layered_batches"] == 1
     p.pm.cleanup(); p.pm.close()
+
+
+def test_admission_lookahead_premap():
+    """premap(seqlen): the slot the next request will get is reserved and its pages are mapped by the mapper thread; the step that
+    activates the request maps nothing synchronously; alloc_new_batch_idx never hands the reserved slot to anyone else; the end
+    state equals the plain alloc + step path (same pages at the same offsets)."""
+    cfg = dict(num_layers=4, num_kv_heads=2, head_size=128, max_batch_size=4, max_context_length=4096, itemsize=2,
+               page_size=32 << 10, megacache=False)          # 64 tokens per page
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    ref = ProductImpl(cfg, flags=0)
+    ref.reserve_physical_pages(60 * group)
+    a = ref.alloc_new_batch_idx(700)
+    lens = [0] * 4
+    lens[a] = 700
+    ref.step_async(lens); ref.pm.wait()
+    b = ref.alloc_new_batch_idx(1500)
+    lens[b] = 1500
+    ref.step_async(lens); ref.pm.wait()
+    want_state, want_ranges = ref.pm.state(), ref.mapped_ranges()
+    ref.pm.cleanup(); ref.pm.close()
+
+    p = ProductImpl(cfg, flags=0)
+    p.reserve_physical_pages(60 * group)
+    assert p.alloc_new_batch_idx(700) == a
+    lens = [0] * 4
+    lens[a] = 700
+    p.step_async(lens)
+    slot = p.pm.premap(1500)                          # while request `a`'s iteration "runs"
+    assert slot == b
+    other = p.alloc_new_batch_idx(64)                 # a third request arriving meanwhile must not get the reserved slot
+    assert other not in (a, slot)
+    p.free_batch_idx(other)
+    p.pm.wait()
+    st0 = p.pm.stats()
+    assert p.pm.state()["mapped"][slot] == 24 and p.pm.state()["lens"][slot] == 0
+    lens[slot] = 1500                                 # the engine activates the request
+    p.step_async(lens)
+    st1 = p.pm.stats()
+    assert st1["sync_batches"] == st0["sync_batches"], "the activating step mapped on the critical path"
+    p.pm.wait()
+    assert p.pm.state() == want_state and p.mapped_ranges() == want_ranges
+    # a cancelled look-ahead leaves reclaimable pages and frees the slot for the next allocation
+    s3 = p.pm.premap(600)
+    assert s3 not in (a, slot) and s3 >= 0
+    p.pm.wait()
+    assert p.pm.state()["mapped"][s3] == 10
+    p.pm.cancel_premap(s3)
+    assert p.alloc_new_batch_idx(600) == s3           # reused, pages already in place
+    # no free slot -> -1, nothing reserved
+    lens[s3] = 600
+    p.step_async(lens); p.pm.wait()
+    s4 = p.pm.premap(100)
+    assert s4 >= 0
+    assert p.pm.premap(100) == -1
+    # a look-ahead never reclaims: with the pool exhausted it only reserves
+    p.pm.cancel_premap(s4)
+    assert fake_counters()["violations"] == 0 and fake_counters()["stale_vas"] == 0
+    p.pm.cleanup(); p.pm.close()
+
+
+def test_premapped_pages_are_the_last_to_be_reclaimed():
+    cfg = dict(num_layers=2, num_kv_heads=2, head_size=128, max_batch_size=4, max_context_length=4096, itemsize=2,
+               page_size=32 << 10, megacache=False)
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    p = ProductImpl(cfg, flags=0)
+    p.reserve_physical_pages(30 * group)
+    a = p.alloc_new_batch_idx(640)                    # 10 groups
+    lens = [0] * 4
+    lens[a] = 640
+    p.step_async(lens); p.pm.wait()
+    p.free_batch_idx(a)                               # deferred reclamation: 10 cached groups on an inactive slot
+    lens[a] = 0
+    r = p.pm.premap(640)                              # takes the cached slot (smallest sufficient): no new maps
+    assert r == a
+    o = p.alloc_new_batch_idx(1280)                   # 20 groups: exactly what is left in the pool
+    assert o != r
+    lens[o] = 1280
+    p.step_async(lens); p.pm.wait()
+    # the pool is dry now; the step's own look-ahead (one more page) could only come from the reserved slot, and takes exactly
+    # what it needs (the reference's reclaim would strip the whole inactive slot, vattention.cu:420-438)
+    m0 = p.pm.state()["mapped"]
+    assert m0[o] + m0[r] == 30 and m0[r] >= 8
+    lens[o] = 1400
+    p.step_async(lens); p.pm.wait()
+    st = p.pm.state()
+    assert st["mapped"][o] >= 22 and 0 < st["mapped"][r] < 10 and st["mapped"][o] + st["mapped"][r] == 30
+    assert fake_counters()["violations"] == 0
+    p.pm.cleanup(); p.pm.close()

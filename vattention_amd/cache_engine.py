@@ -123,6 +123,17 @@ class vATTNCacheEngine:
         self.curr_batch_idx = allidx[:len(both)]
         get_attention_wrapper().set_batch_idx(self.curr_batch_idx, allidx[len(both):], both)
 
+    def prefetch_request(self, seq_id: int, seq_len: int) -> int:
+        """MI355X extension: call once the scheduler knows which request it admits NEXT (before or while the current iteration runs):
+        its slot is reserved and its pages are mapped by the mapper thread under the current forward pass, so that the iteration
+        that starts the request maps nothing synchronously.  Returns the slot (-1: none free / already placed)."""
+        if seq_id in self.seq_to_batch_idx:
+            return -1
+        slot = vattention.premap(seq_len)
+        if slot >= 0:
+            self.seq_to_batch_idx[seq_id] = slot
+        return slot
+
     def on_step_completion(self, seq_metadata_list) -> None:
         for md in seq_metadata_list:
             if md.seq.is_finished():

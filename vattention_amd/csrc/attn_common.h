@@ -86,6 +86,7 @@ template <typename P> __device__ __forceinline__ const P* uniform_ptr(const P* p
 // Arithmetic of /root/reference/sarathi-lean/csrc/pos_encoding_kernels.cu:32-35 in `scalar_t`: x' = x*cos - y*sin, y' = y*cos + x*sin
 // with every product and the sum rounded to the I/O dtype (restated by oracle/attn.py rotary_embedding_ref; bit-exact).
 template <typename T> __device__ __forceinline__ void rope8(typename Tr<T>::v8& x, typename Tr<T>::v8& y, typename Tr<T>::v8 c, typename Tr<T>::v8 s) {
+#pragma clang fp contract(off)      // x*c - y*s must NOT become an fma: the reference rounds both products first (bit-exact K rows)
     using X = Tr<T>;
 #pragma unroll
     for (int j = 0; j < 8; j++) {

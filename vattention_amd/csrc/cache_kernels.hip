@@ -76,6 +76,7 @@ template <typename T, bool NEOX>
 __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions, T* __restrict__ query, T* __restrict__ key,
                                         const T* __restrict__ cos_sin, int64_t cs_stride, int rot_dim, int64_t query_stride,
                                         int64_t key_stride, int num_heads, int num_kv_heads, int hs, int64_t num_tokens) {
+#pragma clang fp contract(off)      // every product is rounded to the I/O dtype before the sum, as scalar_t arithmetic does in the reference
     using X = Tr<T>;
     const int e = rot_dim / 2;
     const int64_t per_tok = (int64_t)(num_heads + num_kv_heads) * e;

@@ -66,6 +66,8 @@ int vattn_wait(vattn_t* m) { return m->pm->wait(); }
 int vattn_alloc_new_batch_idx(vattn_t* m, uint64_t seqlen) { return m->pm->alloc_new_batch_idx(seqlen); }
 int vattn_free_batch_idx(vattn_t* m, int slot) { return m->pm->free_batch_idx(slot); }
 int vattn_free_batch_idx_on_stream(vattn_t* m, int slot, void* stream) { return m->pm->free_batch_idx(slot, stream, true); }
+int vattn_premap(vattn_t* m, uint64_t seqlen) { return m->pm->premap(seqlen); }
+int vattn_cancel_premap(vattn_t* m, int slot) { return m->pm->cancel_premap(slot); }
 int vattn_wait_layer(vattn_t* m, uint32_t layer) { return m->pm->wait_layer(layer); }
 uint32_t vattn_layers_ready(vattn_t* m) { return m->pm->layers_ready(); }
 int vattn_set_sync_layers(vattn_t* m, uint32_t n) { return m->pm->set_sync_layers(n); }

@@ -72,6 +72,7 @@ int PageManager::init() {
 
     mapped_pages_.assign(cfg_.max_batch_size, 0);
     lens_.assign(cfg_.max_batch_size, 0);
+    reserved_.assign(cfg_.max_batch_size, 0);
 
     const int nt = cfg_.megacache ? 2 : 2 * (int)cfg_.num_layers;
     const uint64_t align = std::max<uint64_t>(cfg_.page_size, rec_gran);
@@ -222,13 +223,18 @@ int PageManager::grow(int r, uint64_t nblocks, bool sync) {   // vattention.cu:2
 }
 
 void PageManager::reclaim_on_demand(uint64_t nblocks) {   // vattention.cu:420-438
-    for (int r = (int)cfg_.max_batch_size - 1; r >= 0; r--) {
-        if (kvblocks_available(nblocks)) break;
-        const uint64_t mapped = mapped_pages_[r];
-        const uint64_t required = tokens_to_pages(lens_[r]);
-        if (mapped <= required) continue;
-        release_some(r, required);
-    }
+    // (slots pre-mapped for the NEXT request — premap(), an extension — are only touched if nothing else can be reclaimed)
+    for (int pass = 0; pass < 2; pass++)
+        for (int r = (int)cfg_.max_batch_size - 1; r >= 0; r--) {
+            if (kvblocks_available(nblocks)) return;
+            if (pass == 0 && reserved_[r]) continue;
+            if (pass == 1 && !reserved_[r]) continue;
+            const uint64_t mapped = mapped_pages_[r];
+            const uint64_t required = tokens_to_pages(lens_[r]);
+            if (mapped <= required) continue;
+            if (pass == 0) { release_some(r, required); continue; }
+            while (mapped_pages_[r] > required && !kvblocks_available(nblocks)) unmap_req_page_one(r);   // only what is missing
+        }
 }
 
 void PageManager::do_reclaim_pages() {   // vattention.cu:444-469
@@ -350,7 +356,8 @@ int PageManager::step(const uint64_t* lens, uint32_t n, bool eager_reclaim) {   
     int err = VATTN_OK;
     for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
         lens_[r] = lens[r];
-        if (eager_reclaim && lens[r] == 0 && mapped_pages_[r] != 0) {
+        if (lens[r] != 0) reserved_[r] = 0;
+        if (eager_reclaim && lens[r] == 0 && mapped_pages_[r] != 0 && !reserved_[r]) {
             release_some(r, 0);
             continue;
         }
@@ -367,6 +374,8 @@ int PageManager::step_async(const uint64_t* lens, uint32_t n) {   // vattention.
     if (n != cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "seq_lens must have max_batch_size entries");
     if (fatal_.load()) return fail(fatal_.load(), last_error_);
     lens_.assign(lens, lens + n);                       // utils.h:155-158
+    for (uint32_t r = 0; r < n; r++)
+        if (lens[r] != 0) reserved_[r] = 0;             // a pre-mapped slot has been claimed
     int rc = wait_locked_free();                        // wait_kvcache_manager_sync
     if (rc) return rc;
     int err = VATTN_OK;
@@ -461,7 +470,7 @@ int PageManager::alloc_new_batch_idx(uint64_t seqlen) {   // vattention.cu:564-5
     int new_id = -1;
     const uint64_t required = tokens_to_pages(seqlen);
     for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
-        if (active(r)) continue;
+        if (active(r) || reserved_[r]) continue;
         if (new_id == -1) { new_id = r; continue; }
         if (mapped_pages_[r] >= required && mapped_pages_[r] < mapped_pages_[new_id]) new_id = r;
     }
@@ -469,10 +478,46 @@ int PageManager::alloc_new_batch_idx(uint64_t seqlen) {   // vattention.cu:564-5
     return new_id;
 }
 
+// Admission look-ahead (MI355X extension; the reference's background thread only looks ahead on ACTIVE requests' growth,
+// vattention.cu:486-536): picks the slot alloc_new_batch_idx(seqlen) would pick, reserves it for the caller and lets the MAPPER
+// thread map the pages `seqlen` tokens need while the current iteration runs; the slot stays inactive (length 0) until the engine
+// passes its length to step()/step_async(), which then finds the pages in place and maps nothing on the critical path.  The
+// bookkeeping states it produces are ordinary ones (an inactive slot with mapped pages, as deferred reclamation leaves them).
+int PageManager::premap(uint64_t seqlen) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (!inited_ || cleaned_ || fatal_.load()) return -1;
+    int slot = -1;
+    const uint64_t required = tokens_to_pages(seqlen);
+    for (int r = 0; r < (int)cfg_.max_batch_size; r++) {
+        if (active(r) || reserved_[r]) continue;
+        if (slot == -1) { slot = r; continue; }
+        if (mapped_pages_[r] >= required && mapped_pages_[r] < mapped_pages_[slot]) slot = r;
+    }
+    if (slot < 0) return -1;
+    reserved_[slot] = 1;
+    if (be_.fence_record) be_.fence_record(be_.ctx, (uint32_t)slot, nullptr);      // a new occupant: the previous one's fence is void
+    if (required > mapped_pages_[slot] && required <= max_pages_per_req_) {
+        const uint64_t need = required - mapped_pages_[slot];
+        if (kvblocks_available(need)) {                 // never reclaims for a look-ahead: a later step() does that if it must
+            grow(slot, need, false);
+            flush_async();
+        }
+    }
+    return slot;
+}
+
+int PageManager::cancel_premap(int slot) {
+    std::lock_guard<std::mutex> l(state_mu_);
+    if (slot < 0 || slot >= (int)cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "slot out of range");
+    reserved_[slot] = 0;                                // the pages stay mapped: reclaimable like any finished slot's
+    return VATTN_OK;
+}
+
 int PageManager::free_batch_idx(int slot, void* stream, bool with_fence) {   // vattention.cu:591-594
     std::lock_guard<std::mutex> l(state_mu_);
     if (slot < 0 || slot >= (int)cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "slot out of range");
     lens_[slot] = 0;
+    reserved_[slot] = 0;
     // the point in the engine's stream after the last kernel that can read this slot's pages (plain free: no fence, a later
     // reclaim of the slot then synchronises the whole device)
     if (be_.fence_record && be_.fence_record(be_.ctx, (uint32_t)slot, with_fence ? (stream ? stream : (void*)-1) : nullptr) != 0)

@@ -49,6 +49,8 @@ public:
     int wait();
     int alloc_new_batch_idx(uint64_t seqlen);
     int free_batch_idx(int slot, void* stream = nullptr, bool with_fence = false);
+    int premap(uint64_t seqlen);
+    int cancel_premap(int slot);
     int wait_layer(uint32_t layer);
     uint32_t layers_ready();
     int set_sync_layers(uint32_t n);
@@ -89,6 +91,7 @@ private:
     std::vector<uint32_t> refcnt_;
     struct SharedGroup { std::vector<std::pair<uint32_t, uint64_t>> holders; };   // (slot, page position inside the slot)
     std::vector<SharedGroup> shared_;
+    std::vector<uint8_t> reserved_;                               // slots handed out by premap() and not yet activated / freed
     std::atomic<int> fatal_{0};                                   // sticky: a failed unmap / set-access / TLB invalidation
     std::mutex state_mu_;
     std::vector<PhysOp> plan_;

@@ -799,6 +799,20 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     // short chunks on long prefixes) split the key range over 8-wave workgroups; if even 8 splits leave most CUs idle, take
     // the 4-wave tiling.  Measured (tools/kbench.py --pf-splits, profiles/r01_kbench.txt): Llama-70B/TP8 2k chunk @ 30k
     // 393 -> 901 TFLOP/s, 512 chunk @ 16k 105 -> 568, Yi-34B/TP2 1k chunk @ 64k 653 -> 850.
+    // d = 128: prefill64_kernel (4 waves x 64 rows, one 256-row workgroup per CU, LDS-DMA ring, in-wave software pipeline; +15-20 % on
+    // every shape that gives its workgroups enough key tiles to amortise the longer prologue) whenever its grid — after the same
+    // KV split as the 8-wave tiling — fills at least 3/4 of the CUs and every workgroup gets >= 24 key tiles.  Measured
+    // (tools/kbench.py, profiles/r02_kbench.txt): Yi-6B 32 k prompt 968 -> 1165 TFLOP/s, 16 k chunk @ 112 k 1012 -> 1190,
+    // Llama-70B/TP8 2 k chunk @ 30 k 918 -> 1052; short whole prompts (2 k tokens: 16 tiles per workgroup) and grids that stay
+    // under 192 workgroups keep the tilings below.
+    if (p->d == 128) {
+        const int ns7 = wg8 >= 256 ? 1 : pick(wg8, 256);
+        if (wg8 * ns7 >= 192 && tiles / ns7 >= 24) {
+            pl.tiling = 7;
+            pl.nsplit = ns7;
+            return pl;
+        }
+    }
     if (wg8 > 256) return pl;
     if (wg8 == 256) { pl.tiling = 4; return pl; }
     const int ns8 = pick(wg8, 256);

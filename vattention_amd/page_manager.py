@@ -86,6 +86,12 @@ class PageManager:
         else:
             self._check(self._lib.vattn_free_batch_idx_on_stream(self._h, int(slot), C.c_void_p(stream)))
 
+    def premap(self, seqlen: int) -> int:
+        return self._lib.vattn_premap(self._h, int(seqlen))
+
+    def cancel_premap(self, slot: int) -> None:
+        self._check(self._lib.vattn_cancel_premap(self._h, int(slot)))
+
     def wait_layer(self, layer: int) -> None:
         self._check(self._lib.vattn_wait_layer(self._h, int(layer)))
 

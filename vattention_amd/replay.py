@@ -139,6 +139,8 @@ class HotPathRunner:
         self.stats = ReplayStats()
         self.sample_kv_util = True
         self.iter_hook = None       # called once per iteration right after engine.step (bench.py: the TP control-plane exchange)
+        self.next_request = None    # (seq_id, context length) the scheduler will admit next: pre-mapped under this iteration's forward
+        self.admission_lookahead = True
         # Compute runs on a NON-BLOCKING stream: on ROCm 7.2 hipMemMap / hipMemUnmap wait for work queued on
         # the legacy default stream (and every blocking stream) but not for non-blocking streams
         # (tools/vmm_probe.cpp, profiles/r01_vmm_sync_probe_raw.txt), so this is what lets page mapping — on the
@@ -169,6 +171,9 @@ class HotPathRunner:
             self.engine.step(mds)
             if self.iter_hook is not None:
                 self.iter_hook(self)
+            if self.next_request is not None and self.admission_lookahead:
+                self.engine.prefetch_request(*self.next_request)       # queued behind this step's own look-ahead batch
+                self.next_request = None
             self.wrapper.begin_forward(mds)
             out = None
             for layer in range(self.L):
@@ -225,6 +230,8 @@ class HotPathRunner:
                 s = waiting.pop(0)
                 running.append(s)
                 prefilling = [s]
+            if waiting and len(running) < B:
+                self.next_request = (waiting[0].seq_id, min(chunk, waiting[0].prompt_len))
             if prefilling:
                 mds = [SequenceMetadata(prefilling[0], chunk, True)]
                 if chunk_size:                       # Sarathi: piggy-back the running decodes on the prefill chunk
@@ -292,6 +299,8 @@ class HotPathRunner:
                 mds = [SequenceMetadata(s, s.prompt_len, True) for s in admitted]
             else:
                 mds = [SequenceMetadata(s, 0, False) for s in running]
+            if waiting and len(running) < B:
+                self.next_request = (waiting[0].seq_id, waiting[0].prompt_len)      # the head of the queue is what gets admitted next
             self.run_iteration(mds)
             out["iters"] += 1
             running = [s for s in running if not s.is_finished()]

@@ -151,6 +151,16 @@ def enable_layered_async(on: bool = True) -> None:
     _default_flags = (_default_flags | L.FLAG_LAYERED_ASYNC) if on else (_default_flags & ~L.FLAG_LAYERED_ASYNC)
 
 
+def premap(seqlen: int) -> int:
+    """Admission look-ahead (include/vattn.h, vattn_premap): reserve the slot the NEXT request will get and map its pages on the
+    mapper thread while the current iteration runs.  Returns the slot, -1 if none is free."""
+    return _require().premap(seqlen)
+
+
+def cancel_premap(slot: int) -> None:
+    _require().cancel_premap(slot)
+
+
 def wait_layer(layer_id: int) -> None:
     """Block until the pages the current step needs are mapped for `layer_id` (no-op unless a layered batch is pending)."""
     global _layered_pending
