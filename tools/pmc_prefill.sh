@@ -17,7 +17,7 @@ for i in (1, 2, 3):
     if not f:
         print("pass %d: no database" % i); continue
     db = sqlite3.connect(f[0])
-    for r in db.execute("select substr(kernel_name,1,60), counter_name, count(*), avg(value) from counters_collection where kernel_name like '%prefill_kernel%' group by kernel_name, counter_name order by counter_name"):
+    for r in db.execute("select substr(kernel_name,1,60), counter_name, count(*), avg(value) from counters_collection where kernel_name like '%prefill%' group by kernel_name, counter_name order by counter_name"):
         print("%-60s %-30s n=%d per-dispatch %.4g" % r)
 PY
 rm -rf gpurun_out/pmcp_1 gpurun_out/pmcp_2 gpurun_out/pmcp_3

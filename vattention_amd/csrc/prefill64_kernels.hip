@@ -20,6 +20,7 @@
 // (bottom-right causal), softmax.h:69-157 (fp32 max/sum via exp2, P rounded to the I/O dtype before PV),
 // flash_fwd_kernel.h:57-499 (the operator's non-split kernel), :1116-1297 (split combine, here combine_rows_kernel).
 // Every K/V access is bounded by a buffer descriptor that ends at the sequence's visible length.
+#include <cstdlib>
 #include "attn_common.h"
 
 namespace vattn_k {
@@ -84,9 +85,21 @@ template <typename T> struct Mfma;
         static __device__ __forceinline__ void pv_nop(f32x16& o, V8 a, V8 b) {                                                     \
             asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                         \
         }                                                                                                                          \
+        /* l += p.lo + p.hi for a packed pair of probabilities (f32 accumulate) */                                                 \
+        static __device__ __forceinline__ void dot2_ones(float& l, unsigned packed) {                                              \
+            asm("v_dot2c_f32_" SUFFIX " %0, %1, %2" : "+v"(l) : "s"(ONES), "v"(packed));                                           \
+        }                                                                                                                          \
     };
+#define SUFFIX "f16"
+#define ONES 0x3c003c00u
 VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16")
+#undef SUFFIX
+#undef ONES
+#define SUFFIX "bf16"
+#define ONES 0x3f803f80u
 VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16")
+#undef SUFFIX
+#undef ONES
 #undef VATTN_MFMA_STRUCT
 // one scalar f32 add that the SLP vectoriser cannot pack into v_pk_add_f32 (packed f32 VALU beside MFMAs costs more than two
 // plain adds, MI355X_MICROARCH "price of one filler")
@@ -301,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     auto raise_max = [&](int qc, float delta) {
         const float alpha = fast_exp2(-delta);
         nmsub[qc] -= delta;
+        if (ABL & 64) asm volatile("s_nop 3" ::: "memory");      // v_dot2c result -> a different VALU opcode: 3 wait states, not interlocked
 #pragma unroll
         for (int i = 0; i < DB; i++)
 #pragma unroll
@@ -313,6 +327,13 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         V8 r;
 #pragma unroll
         for (int j = 0; j < 8; j++) r[j] = X::cvt(pt[ks >> 1][qc][8 * (ks & 1) + j]);
+        if (ABL & 64) {
+            // row sums from the PACKED probabilities: one v_dot2c (p.lo * 1 + p.hi * 1 + l, f32 accumulate) per two scores
+            // instead of two v_add — the sum then is over exactly the values the P.V product uses
+            const u32x4 w = __builtin_bit_cast(u32x4, r);
+#pragma unroll
+            for (int j = 0; j < 4; j++) M::dot2_ones(l_acc[qc][j & 1], w[j]);
+        }
         return r;
     };
 
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             if (GE(e) - 1 == G)
                 asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale), "v"(nmsub[qc]));
             if (GE(e) == G) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
-            if (GE(e) + 1 == G)      // (v_pk_add_f32 was tried: forming the register pairs costs more moves than the adds it saves)
+            if (GE(e) + 1 == G && !(ABL & 64))      // (v_pk_add_f32 was tried: forming the register pairs costs more moves than the adds it saves)
                 asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][0]), "+v"(l_acc[qc][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
         }
     };
@@ -581,16 +602,16 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
 // variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1-3, 10-12 = schedule variants; 4-9 = timing
 // ablations (wrong results)
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
-    const int sel = (p->variant >> 8) & 15;
+    static const int env_sel = [] { const char* e = getenv("VATTN_PREFILL64_BUILD"); return e ? atoi(e) & 15 : 0; }();   // measurement hook
+    const int sel = ((p->variant >> 8) & 15) ? ((p->variant >> 8) & 15) : env_sel;
     if (p->dtype == VATTN_DTYPE_BF16) {
-        launch64_t<__bf16, 0, 24, 4>(p, st, nsplit);
+        if (sel == 1) launch64_t<__bf16, 64, 24, 4>(p, st, nsplit);
+        else launch64_t<__bf16, 0, 24, 4>(p, st, nsplit);
         return;
     }
     switch (sel) {
-        case 1: launch64_t<_Float16, 0, 20, 4>(p, st, nsplit); break;
-        case 2: launch64_t<_Float16, 0, 16, 4>(p, st, nsplit); break;
+        case 1: launch64_t<_Float16, 64, 24, 4>(p, st, nsplit); break;         // row sums by v_dot2c over the packed P
         case 3: launch64_t<_Float16, 0, 24, 3>(p, st, nsplit); break;
-        case 11: launch64_t<_Float16, 0, 20, 3>(p, st, nsplit); break;
         case 4: launch64_t<_Float16, 1, 24, 4>(p, st, nsplit); break;          // no LDS-DMA in the steady state
         case 5: launch64_t<_Float16, 2, 24, 4>(p, st, nsplit); break;          // no fma / exp2 / row sums
         case 6: launch64_t<_Float16, 8, 24, 4>(p, st, nsplit); break;          // no per-tile wait + barrier
