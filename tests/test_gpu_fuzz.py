@@ -41,7 +41,7 @@ def test_fuzz_prefill(seed):
         causal = rng.random() < 0.8
         cls = [rng.choice([0, 1, 30, 64, 333, 600]) + (n if rng.random() < 0.85 else rng.randrange(1, n + 1)) for _ in range(B)]
         slots = rng.sample(range(B + 2), B)
-        variant = rng.choice([0, 0, 1, 2, 8, 9, 32, 64, 12 if D == 128 else 0, 4 if D == 128 else 0, 14 if D == 128 else 0, 14 if D == 128 else 2])
+        variant = rng.choice([0, 0, 1, 2, 8, 9, 32, 64, 12 if D == 128 else 0, 4 if D == 128 else 0, 14 if D == 128 else 0, 2574 if D == 128 else 2, 270 if D == 128 else 0, 526 if D == 128 else 8])
         splits = rng.choice([0, 0, 0, 1, 2, 3, 7])
         q = torch.randn(B, n, Hq, D).to(dtype)
         kc = torch.randn(B + 2, ctx, Hkv, D).to(dtype)
@@ -80,7 +80,7 @@ def test_fuzz_batched_chunks(seed):
         slots = rng.sample(range(B + 1), B)
         i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
         out = flash_attn_varlen_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), i32(starts), i32(lens), max(lens), i32(cls), i32(slots),
-                                             causal=True, num_splits=rng.choice([0, 0, 2, 5]), _variant=rng.choice([0, 2, 8, 64, 14]),
+                                             causal=True, num_splits=rng.choice([0, 0, 2, 5]), _variant=rng.choice([0, 2, 8, 64, 14, 2574]),
                                              _max_seqlen_k=max(cls))
         torch.cuda.synchronize()
         for i in range(B):

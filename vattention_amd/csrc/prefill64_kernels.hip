@@ -127,6 +127,15 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     constexpr int KK = HD / 16;        // k-steps of the S^T MFMA chain
     constexpr int DB = HD / 32;        // 32-wide d blocks of O^T
     extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring [2][16 KiB], then V ring [3][16 KiB]; LDS address 0
+    // ABL bit 7 (a layout, not an ablation): the K image in LDS is stored as 16 pieces of 4 rows, each piece 1088 bytes apart (64
+    // bytes of padding), inside a piece chunk c of row r3 at byte 64*c + 16*r3.  ds_read_b128's lane groups ({0-3,12-15,20-27}, ...)
+    // then hit 16 distinct 16-byte slots of the 256-byte bank row WITHOUT an XOR swizzle, so the address of fragment (kk, kb) is
+    // one lane-dependent register + the immediate 8704*kb + 128*kk (+ the slot, static because slots go by (t - tb) & 1 and the
+    // loop is unrolled twice): no per-fragment address arithmetic in the hot loop.
+    constexpr bool KP = (ABL & 128) != 0;
+    constexpr int KPIECE = KP ? 1088 : 1024;
+    constexpr int KSLOT = KP ? 16 * 1088 : S::kTileBytes;
+    constexpr int VBASE = KP ? 36864 : 2 * S::kTileBytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -168,14 +177,15 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     unsigned koff[4], voff[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int row = 4 * (4 * wave + j) + (lane >> 4);
-        koff[j] = (unsigned)row * k_rs_bytes + (unsigned)(((lane & 15) ^ (row & 15)) << 4);
+        const int row = 4 * (4 * wave + j) + (KP ? (lane & 3) : (lane >> 4));
+        koff[j] = (unsigned)row * k_rs_bytes + (unsigned)((KP ? (lane >> 2) : ((lane & 15) ^ (row & 15))) << 4);
         const int key = 16 * j + (lane >> 2);
         voff[j] = (unsigned)key * v_rs_bytes + (unsigned)((4 * wave + (lane & 3)) << 4);
     }
     using M = Mfma<T>;
-    const unsigned k_lds_wave = (unsigned)(wave * 4096);                       // this wave's four K pieces inside a K slot
-    const unsigned v_lds_wave = (unsigned)(2 * S::kTileBytes + wave * 4096);   // ... and V pieces inside a V slot
+    const unsigned k_lds_wave = (unsigned)(wave * 4 * KPIECE);                 // this wave's four K pieces inside a K slot
+    const unsigned v_lds_wave = (unsigned)(VBASE + wave * 4096);               // ... and V pieces inside a V slot
+    auto kslot = [&](int t) { return KP ? ((t - tb) & 1) : (t & 1); };         // K(t)'s slot of the ring
     auto k_rsrc = [&](int t) -> u32x4 {
         int rem = Lk - t * PF_BN;
         rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
@@ -188,11 +198,11 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     };
     auto dma_k_all = [&](int t) {      // K(t) -> K slot t & 1, this wave's four pieces
         const u32x4 r = k_rsrc(t);
-        const unsigned l0 = k_lds_wave + (unsigned)((t & 1) * S::kTileBytes);
+        const unsigned l0 = k_lds_wave + (unsigned)(kslot(t) * KSLOT);
         dma_piece_first(l0, r, koff[0]);
-        dma_piece(l0 + 1024, r, koff[1]);
-        dma_piece(l0 + 2048, r, koff[2]);
-        dma_piece(l0 + 3072, r, koff[3]);
+        dma_piece(l0 + KPIECE, r, koff[1]);
+        dma_piece(l0 + 2 * KPIECE, r, koff[2]);
+        dma_piece(l0 + 3 * KPIECE, r, koff[3]);
     };
     auto dma_v_all = [&](int t) {
         const u32x4 r = v_rsrc(t);
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < (3 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + 2 * S::kTileBytes + (i * 256 + tid) * 16) = z;
+        for (int i = 0; i < (3 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + VBASE + (i * 256 + tid) * 16) = z;
     }
     __syncthreads();
     dma_k_all(tb);
@@ -268,10 +278,11 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     }
 
     // LDS fragment addressing: one lane-dependent base per tensor + immediate offsets
-    const unsigned kfrag_lane = (unsigned)(l31 * S::kRowBytes);
+    const unsigned kfrag_lane = KP ? (unsigned)((l31 >> 2) * KPIECE + (l31 & 3) * 16 + g * 64) : (unsigned)(l31 * S::kRowBytes);
     const unsigned kswz = (unsigned)(l31 & 15);
     auto kfrag = [&](const char* ksm, int f) -> V8 {                  // f = 2*kk + kb: K rows 32*kb + l31, d = 16*kk + 8*g ..
         const int kk = f >> 1, kb = f & 1;
+        if (KP) return *(const V8*)(ksm + kb * 8 * KPIECE + kk * 128 + kfrag_lane);
         return *(const V8*)(ksm + kb * 32 * S::kRowBytes + kfrag_lane + (((unsigned)(2 * kk + g) ^ kswz) << 4));
     };
     const int i16 = lane & 15, dh = (lane >> 4) & 1;
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     f32x16 sc[2][2];      // S(t): raw scores of the current tile; becomes P(t) in place
     f32x16 sd[2][2];
     {
-        const char* ksm = smem + (tb & 1) * S::kTileBytes;
+        const char* ksm = smem + kslot(tb) * KSLOT;
 #pragma unroll
         for (int f = 0; f < 2 * KK; f++) {
             const V8 a = kfrag(ksm, f);
@@ -394,10 +405,12 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // in flight.  The barrier of this step sits in phase B after group 23: by then every wave has finished reading K(t+1)
     // (phase A) and V(t-1) (step t-1), so K(t+3) -> slot of K(t+1) and V(t+2) -> slot of V(t-1) are issued right behind it, one
     // piece per group in the eight groups that carry no softmax work.
-    auto step = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2) {
-        const char* ksm = smem + ((t + 1) & 1) * S::kTileBytes;
-        const char* ksm_next = smem + (t & 1) * S::kTileBytes;                  // K(t+2)
-        const char* vsm = smem + 2 * S::kTileBytes + (t % 3) * S::kTileBytes;
+    auto step = [&](int t, const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2) {
+        // par = (t - tb) & 1, a literal at both call sites: with the padded K layout every K fragment address folds to lane + immediate
+        const int s_cur = KP ? par : (t & 1);                                   // slot of K(t), K(t+2)
+        const char* ksm = smem + (s_cur ^ 1) * KSLOT;                           // K(t+1)
+        const char* ksm_next = smem + s_cur * KSLOT;                            // K(t+2)
+        const char* vsm = smem + VBASE + (t % 3) * S::kTileBytes;
         // descriptors of K(t+3) and V(t+2): running base pointers and remaining-row counts, advanced one tile per step with a handful
         // of SALU instructions (past the last tile the row count clamps to 0: nothing is fetched)
         const u32x4 rk = running_rsrc(k_next_ptr, k_next_rem, k_rs_bytes);
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         v_next_ptr += v_tile_bytes;
         k_next_rem -= PF_BN;
         v_next_rem -= PF_BN;
-        const unsigned lk0 = k_lds_wave + (unsigned)(((t + 1) & 1) * S::kTileBytes);
+        const unsigned lk0 = k_lds_wave + (unsigned)((s_cur ^ 1) * KSLOT);      // K(t+3) -> the slot K(t+1) leaves
         const unsigned lv0 = v_lds_wave + (unsigned)(((t + 2) % 3) * S::kTileBytes);
         // Every wave runs the SAME straight-line body for every tile of the workgroup (the barrier makes the waves wait for each other
         // anyway): a tile that lies wholly beyond a wave's causal limit is masked to -inf, contributes P = 0, and leaves the running
@@ -463,9 +476,9 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             }
             if (!(ABL & 1)) {
                 if (j == 24) dma_piece_first(lk0, rk, koff[0]);
-                if (j == 25) dma_piece(lk0 + 1024, rk, koff[1]);
-                if (j == 26) dma_piece(lk0 + 2048, rk, koff[2]);
-                if (j == 27) dma_piece(lk0 + 3072, rk, koff[3]);
+                if (j == 25) dma_piece(lk0 + KPIECE, rk, koff[1]);
+                if (j == 26) dma_piece(lk0 + 2 * KPIECE, rk, koff[2]);
+                if (j == 27) dma_piece(lk0 + 3 * KPIECE, rk, koff[3]);
                 if (j == 28) dma_piece_first(lv0, rv, voff[0]);
                 if (j == 29) dma_piece(lv0 + 1024, rv, voff[1]);
                 if (j == 30) dma_piece(lv0 + 2048, rv, voff[2]);
@@ -499,11 +512,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     __builtin_amdgcn_s_barrier();                    // also: every wave is done with K(tb) (the prologue's S')
     dma_k_all(tb + 2);
     dma_v_all(tb + 1);
-    V8 kfa = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 0), kfb = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 1),
-       kfc = kfrag(smem + ((tb + 1) & 1) * S::kTileBytes, 2);
+    V8 kfa = kfrag(smem + kslot(tb + 1) * KSLOT, 0), kfb = kfrag(smem + kslot(tb + 1) * KSLOT, 1), kfc = kfrag(smem + kslot(tb + 1) * KSLOT, 2);
     for (int t = tb; t < nt; t += 2) {
-        step(t, sc, sd, kfa, kfb, kfc);
-        if (t + 1 < nt) step(t + 1, sd, sc, kfa, kfb, kfc);
+        step(t, 0, sc, sd, kfa, kfb, kfc);
+        if (t + 1 < nt) step(t + 1, 1, sd, sc, kfa, kfb, kfc);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // trailing DMA retired (nothing may land in LDS of
     SCHED_FENCE();                                                                // a later workgroup); last PV results readable
@@ -579,6 +591,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 // host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
+constexpr int kSmem64 = 36864 + 3 * PfSmem<128>::kTileBytes;      // K ring (padded layout: 2 x 17 408, rounded up) + V ring
 template <typename T, int ABL, int NA, int RING> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
@@ -592,11 +605,11 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * PfSmem<128>::kTileBytes);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), 5 * PfSmem<128>::kTileBytes, st, *p, order, nqb, nsplit);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), kSmem64, st, *p, order, nqb, nsplit);
 }
 
 // variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1-3, 10-12 = schedule variants; 4-9 = timing
@@ -606,11 +619,14 @@ void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     const int sel = ((p->variant >> 8) & 15) ? ((p->variant >> 8) & 15) : env_sel;
     if (p->dtype == VATTN_DTYPE_BF16) {
         if (sel == 1) launch64_t<__bf16, 64, 24, 4>(p, st, nsplit);
+        else if (sel == 10) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit);
         else launch64_t<__bf16, 0, 24, 4>(p, st, nsplit);
         return;
     }
     switch (sel) {
         case 1: launch64_t<_Float16, 64, 24, 4>(p, st, nsplit); break;         // row sums by v_dot2c over the packed P
+        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit); break;        // padded K image, immediate fragment addresses
+        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit); break;  // both
         case 3: launch64_t<_Float16, 0, 24, 3>(p, st, nsplit); break;
         case 4: launch64_t<_Float16, 1, 24, 4>(p, st, nsplit); break;          // no LDS-DMA in the steady state
         case 5: launch64_t<_Float16, 2, 24, 4>(p, st, nsplit); break;          // no fma / exp2 / row sums
