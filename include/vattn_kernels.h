@@ -89,6 +89,19 @@ size_t vattn_attn_workspace_bytes(const vattn_attn_params* p);
  * causal chunk against the growing cache) and decode form (seqlen_q == 1, split-KV + combine). */
 int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream);
 
+/* Fused prefill || decode for a hybrid batch (replaces the reference's POD-Attention entry point
+ * /root/reference/pod_attn/pod_attn/flash_attn_interface.py true_fused_attn_with_kvcache, call site
+ * /root/reference/sarathi-lean/sarathi/model_executor/attention/vattention_flashattention_pod_wrapper.py:121-203): ONE launch of
+ * persistent workgroups, two per CU, typed prefill / decode by a per-CU arrival counter, fed from two device-side work queues;
+ * the decode part's split-KV merge happens in the same launch.  `prefill` is a prefill-form parameter block (seqlen_q > 1 or the
+ * batched-chunk form, k_new == NULL: append with vattn_cache_flat first), `decode` a decode-form block (seqlen_q == 1, optional
+ * one-row append); both d == 128 and the same dtype; their `workspace` fields are ignored.  `workspace` is
+ * vattn_hybrid_workspace_bytes() bytes of device memory that must be ZERO before the first launch; the launch leaves its control
+ * words zero, so it can be reused by the next launch on the same stream without a memset.  Results are those of the two
+ * stand-alone launches (same device functions). */
+size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode);
+int vattn_hybrid_attn(const vattn_attn_params* prefill, const vattn_attn_params* decode, void* workspace, void* stream);
+
 /* cache_flat: k_cache[t*k_cache_stride + i] = key[t*key_stride + i], same for value,
  * t < num_tokens, i < num_heads*head_size (cache_kernels.cu:483-520). */
 int vattn_cache_flat(const void* key, const void* value, void* k_cache, void* v_cache,

@@ -106,12 +106,24 @@ def test_hybrid_batches_two_streams_match_serial():
         return outs, k0, v0
 
     a, ka, va = run("fa_vattn")
-    for backend in ("fa_streams", "fa_pod"):
-        b, kb, vb = run(backend)
-        assert len(a) == len(b)
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
-        assert torch.equal(ka, kb) and torch.equal(va, vb)
+    b, kb, vb = run("fa_streams")
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(ka, kb) and torch.equal(va, vb)
+    # fa_pod: the hybrid iterations go through the fused launch (other tilings / split counts than the serial plan: same values up to
+    # fp rounding; its parity proper — against the oracle — is tests/test_gpu_hybrid_fused.py); cache contents are bit-identical
+    from vattention_amd.attention.vattention_flashattention_pod_wrapper import VAttentionFlashAttentionPodWrapper as Pod
+    prev = Pod.FUSE_MIN_SHARE
+    Pod.FUSE_MIN_SHARE = 0.0              # fuse every hybrid iteration, however lopsided
+    try:
+        b, kb, vb = run("fa_pod")
+    finally:
+        Pod.FUSE_MIN_SHARE = prev
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() < 2e-3
+    assert torch.equal(ka, kb) and torch.equal(va, vb)
 
 
 def test_pool_pressure_reclaim_and_remap_keep_kv_intact():

@@ -73,9 +73,10 @@ def test_backend_registry_resolves_native_and_hybrid_backends():
             A.set_attention_backend(name)
             assert type(A.get_attention_wrapper()).__name__ == "VAttentionFlashAttentionWrapper"
             assert A.is_vattention_backend() and not A.is_vLLM_backend()
-        for name in ("fa_streams", "fa_pod", "fa_pod_megacache"):
+        for name, cls in (("fa_streams", "VAttentionFlashAttentionStreamsWrapper"), ("fa_pod", "VAttentionFlashAttentionPodWrapper"),
+                          ("fa_pod_megacache", "VAttentionFlashAttentionPodWrapper")):
             A.set_attention_backend(name)
-            assert type(A.get_attention_wrapper()).__name__ == "VAttentionFlashAttentionStreamsWrapper"
+            assert type(A.get_attention_wrapper()).__name__ == cls
             assert A.is_vattention_backend()
         for name in ("fi_vattn", "fa3_vattn", "fa_paged"):
             A.set_attention_backend(name)

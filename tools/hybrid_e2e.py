@@ -44,8 +44,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     print("model %s ctx %d chunk %d batch %d P:D %g layers %d" % (a.model, a.ctx, a.chunk, a.batch, a.pd, a.layers))
     res = {}
-    for backend in ("fa_vattn", "fa_streams", "fa_vattn", "fa_streams"):
+    for backend in ("fa_vattn", "fa_streams", "fa_pod", "fa_vattn", "fa_streams", "fa_pod"):
         tps, dt, it = run(a, backend)
         res.setdefault(backend, []).append(tps)
         print("  %-11s %9.0f tokens/s  (%.2f s, %d iterations)" % (backend, tps, dt, it))
-    print("  two streams / serial = %.3f" % (max(res["fa_streams"]) / max(res["fa_vattn"])))
+    print("  two streams / serial = %.3f   fused launch (fa_pod) / serial = %.3f" % (max(res["fa_streams"]) / max(res["fa_vattn"]), max(res["fa_pod"]) / max(res["fa_vattn"])))

@@ -43,7 +43,9 @@ def main():
              ("llama8b chunk512@8k + B128@8k", 32, 8, 512, 7680, 128, 8192),
              ("llama8b chunk2k@30k + B32@32k", 32, 8, 2048, 30720, 32, 32768),
              ("yi6b chunk4k@28k + B16@32k", 32, 4, 4096, 28672, 16, 32768),
-             ("llama70b/tp8 chunk2k@30k + B64@32k", 8, 1, 2048, 30720, 64, 32768)]
+             ("llama70b/tp8 chunk2k@30k + B64@32k", 8, 1, 2048, 30720, 64, 32768),
+             ("llama8b chunk512@4k + B64@4k", 32, 8, 512, 3584, 64, 4096),
+             ("llama8b chunk256@8k + B32@8k", 32, 8, 256, 7936, 32, 8192)]
     for name, Hq, Hkv, n, c, B, ctx in cases:
         torch.manual_seed(0)
         q = torch.randn(1, n, Hq, 128, device=DEV, dtype=torch.float16)
@@ -78,8 +80,24 @@ def main():
 
         t_par_u = timeit(both(pu))
         t_par_a = timeit(both(pa))
+        # the fused launch (vattn_hybrid_attn): by-arrival roles (product), and with every workgroup preferring one queue (A/B)
+        lib = K.klib()
+        need = lib.vattn_hybrid_workspace_bytes(C.byref(pu), C.byref(pd))
+        ws = torch.zeros(need // 4 + 64, dtype=torch.float32, device=DEV)
+
+        def fused(mode):
+            def f():
+                pu.variant = (pu.variant & ~(3 << 12)) | (mode << 12)
+                rc = lib.vattn_hybrid_attn(C.byref(pu), C.byref(pd), C.c_void_p(ws.data_ptr()), C.c_void_p(s_main.cuda_stream))
+                if rc != 0:
+                    raise RuntimeError(K.last_error())
+            return f
+
+        t_f0, t_f1, t_f2 = timeit(fused(0)), timeit(fused(1)), timeit(fused(2))
+        pu.variant &= ~(3 << 12)
         print("  prefill %.3f ms (single pass %.3f)  decode %.3f ms | serial, default plan %.3f ms | two streams: single-pass prefill %.3f ms, "
-              "default-plan prefill %.3f ms | best/serial %.2fx" % (t_pa, t_pu, t_d, t_ser, t_par_u, t_par_a, t_ser / min(t_par_u, t_par_a, t_ser)))
+              "default-plan prefill %.3f ms | FUSED launch %.3f ms (prefill-first roles %.3f, decode-first roles %.3f) | streams/serial %.2fx  fused/serial %.2fx"
+              % (t_pa, t_pu, t_d, t_ser, t_par_u, t_par_a, t_f0, t_f1, t_f2, t_ser / min(t_par_u, t_par_a, t_ser), t_ser / t_f0))
         del keepa, keepu
         del keepd, kd, vd
 

@@ -12,6 +12,7 @@ from typing import Union
 
 from .base_attention_wrapper import BaseAttentionWrapper  # noqa: F401
 from .no_op_attention_wrapper import NoOpAttentionWrapper
+from .vattention_flashattention_pod_wrapper import VAttentionFlashAttentionPodWrapper
 from .vattention_flashattention_streams_wrapper import VAttentionFlashAttentionStreamsWrapper
 from .vattention_flashattention_wrapper import VAttentionFlashAttentionWrapper
 
@@ -63,9 +64,9 @@ _VLLM = {"FA_PAGED", "FI_PAGED", "FI_UNPAGED", "FI_SERIAL_PAGED"}
 _NATIVE = {AttentionBackend.FA_VATTN, AttentionBackend.FA_VATTN_SYNC, AttentionBackend.FA_VATTN_MEGACACHE,
            AttentionBackend.FA_VATTN_MEGACACHE_SYNC}
 
-# hybrid-batch backends: prefill || decode on two HIP streams (the reference's FA_STREAMS; its fused-kernel FA_POD maps here too)
-_NATIVE_HYBRID = {AttentionBackend.FA_STREAMS, AttentionBackend.FA_POD, AttentionBackend.FA_STREAMS_MEGACACHE,
-                  AttentionBackend.FA_POD_MEGACACHE}
+# hybrid-batch backends: prefill || decode on two HIP streams (the reference's FA_STREAMS) and as one fused launch (FA_POD)
+_NATIVE_HYBRID = {AttentionBackend.FA_STREAMS, AttentionBackend.FA_STREAMS_MEGACACHE}
+_NATIVE_POD = {AttentionBackend.FA_POD, AttentionBackend.FA_POD_MEGACACHE}
 
 ATTENTION_BACKEND = AttentionBackend.NO_OP
 
@@ -93,6 +94,8 @@ def get_attention_wrapper():
         return VAttentionFlashAttentionWrapper.get_instance()
     if ATTENTION_BACKEND in _NATIVE_HYBRID:
         return VAttentionFlashAttentionStreamsWrapper.get_instance()
+    if ATTENTION_BACKEND in _NATIVE_POD:
+        return VAttentionFlashAttentionPodWrapper.get_instance()
     raise NotImplementedError(
         f"attention backend {ATTENTION_BACKEND.value} wraps a CUDA-only library in the reference and has no "
         "MI355X-native counterpart here; use FA_VATTN / FA_VATTN_SYNC / FA_VATTN_MEGACACHE[_SYNC] / FA_STREAMS / FA_POD[_MEGACACHE]")

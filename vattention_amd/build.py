@@ -17,7 +17,7 @@ PKG = os.path.join(ROOT, "vattention_amd")
 CSRC = os.path.join(PKG, "csrc")
 ARCH = "gfx950"
 LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "vmm_selfcheck.hip", "attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "decode_kernels.hip",
-               "cache_kernels.hip")
+               "cache_kernels.hip", "hybrid_kernels.hip")
 
 
 def _newer(target, sources):
@@ -35,7 +35,8 @@ def _run(cmd):
 def build_lib(force=False):
     out = os.path.join(PKG, "libvattn_amd.so")
     srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "page_manager.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(ROOT, "include", "vattn.h"),
+    deps = srcs + [os.path.join(CSRC, "page_manager.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
+                   os.path.join(ROOT, "include", "vattn.h"),
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

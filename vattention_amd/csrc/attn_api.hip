@@ -228,6 +228,19 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
     return p->seqlen_q == 1 ? launch_decode_form(p, st) : launch_prefill_form(p, st);
 }
 
+size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode) {
+    if (!prefill || !decode || decode->h_k <= 0 || decode->h <= 0 || decode->b <= 0) return 0;
+    return hybrid_workspace_bytes(prefill, decode);
+}
+
+int vattn_hybrid_attn(const vattn_attn_params* prefill, const vattn_attn_params* decode, void* workspace, void* stream) {
+    int rc = validate(prefill);
+    if (rc) return rc;
+    rc = validate(decode);
+    if (rc) return rc;
+    return launch_hybrid(prefill, decode, workspace, (hipStream_t)stream);
+}
+
 int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
     hipStream_t st = (hipStream_t)stream;
     int* d = nullptr;

@@ -164,5 +164,7 @@ size_t prefill_workspace_bytes(const vattn_attn_params* p);
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit);   // prefill64_kernels.hip (d = 128)
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
 size_t decode_workspace_bytes(const vattn_attn_params* p);
+int launch_hybrid(const vattn_attn_params* prefill, const vattn_attn_params* decode, void* ws, hipStream_t st);   // hybrid_kernels.hip
+size_t hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode);
 
 }  // namespace vattn_k

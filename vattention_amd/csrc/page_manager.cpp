@@ -339,6 +339,7 @@ int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInt
         {
             std::lock_guard<std::mutex> q(q_mu_);
             frontier_.store(num_pages_);
+            precreate_window_.store(num_pages_ <= kPrecreateWholePoolBelow ? num_pages_ : kPrecreateAheadPages);
             precreate_left_.store(num_pages_);
         }
         q_cv_.notify_all();

@@ -132,9 +132,14 @@ private:
     std::atomic<uint64_t> frontier_{0};          // lowest page id ever handed out by the pool (ids below it were never used)
     uint64_t precreate_floor() const {           // ids below this are not created ahead of demand (yet): sliding window
         const uint64_t f = frontier_.load(std::memory_order_relaxed);
-        return f > kPrecreateAheadPages ? f - kPrecreateAheadPages : 0;
+        const uint64_t w = precreate_window_.load(std::memory_order_relaxed);
+        return f > w ? f - w : 0;
     }
+    // pages created ahead of demand by the idle mapper: the whole pool when it has few enough handles that creating them all
+    // costs seconds (hipMemCreate is O(live handles): 31 k handles of 8 MiB = 6 s in the background), a sliding window otherwise
     static constexpr uint64_t kPrecreateAheadPages = 4096;
+    static constexpr uint64_t kPrecreateWholePoolBelow = 40000;
+    std::atomic<uint64_t> precreate_window_{kPrecreateAheadPages};
     std::mutex exec_mu_;                         // serialises driver calls
     std::mutex q_mu_;
     std::condition_variable q_cv_, done_cv_;

@@ -72,8 +72,49 @@ def _set_cache(p, k_cache, v_cache):
     p.v_batch_stride, p.v_row_stride, p.v_head_stride = v_cache.stride(0), v_cache.stride(1), v_cache.stride(2)
 
 
-def _launch(p, dev):
+_capture = None      # a list while hybrid_attn() records the two parameter blocks of a fused prefill || decode launch
+_hybrid_ws = {}      # (device, stream) -> zero-initialised workspace of the fused launch (the kernel leaves its control words zero)
+
+
+def hybrid_attn(prefill_call, decode_call, device, _role_mode: int = 0) -> None:
+    """Fused prefill || decode for a hybrid batch (include/vattn_kernels.h, vattn_hybrid_attn; the reference's POD entry point
+    pod_attn/flash_attn_interface.py true_fused_attn_with_kvcache): `prefill_call` and `decode_call` are callables that each issue
+    exactly ONE attention call of this module (flash_attn_with_kvcache / flash_attn_varlen_with_kvcache, results via out=); the
+    two calls are recorded instead of launched and go to the GPU as one launch on the current stream."""
+    global _capture
+    if _capture is not None:
+        raise RuntimeError("hybrid_attn does not nest")
+    _capture = []
+    try:
+        prefill_call()
+        n_pre = len(_capture)
+        decode_call()
+        cap = _capture
+    finally:
+        _capture = None
+    if n_pre != 1 or len(cap) != 2:
+        raise RuntimeError("hybrid_attn: each part must issue exactly one attention call (got %d + %d)" % (n_pre, len(cap) - n_pre))
+    (pp, keep_p), (pd, keep_d) = cap
+    if _role_mode:
+        pp.variant = (pp.variant & ~(3 << 12)) | ((_role_mode & 3) << 12)
+    lib = K.klib()
+    need = lib.vattn_hybrid_workspace_bytes(C.byref(pp), C.byref(pd))
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _hybrid_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.zeros((max(need, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)      # zero ONCE: see the header
+        _hybrid_ws[key] = ws
+    rc = lib.vattn_hybrid_attn(C.byref(pp), C.byref(pd), ws.data_ptr(), K.current_stream_ptr(device))
+    if rc != 0:
+        raise RuntimeError(K.last_error())
+    del keep_p, keep_d
+
+
+def _launch(p, dev, keep=()):
     """Attach the split-KV workspace the call needs (one buffer per device and stream) and launch on the current stream."""
+    if _capture is not None:
+        _capture.append((p, keep))
+        return
     lib = K.klib()
     need = lib.vattn_attn_workspace_bytes(C.byref(p))
     if need:
@@ -172,7 +213,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
     if rot is not None:
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
-    _launch(p, dev)
+    _launch(p, dev, keep=(q, k, v, k_cache, v_cache, cache_seqlens, cache_batch_idx, out, lse, rot))
     return (out, lse) if return_softmax_lse else out
 
 
@@ -240,5 +281,5 @@ def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q
     if _rotary_cos_sin is not None:      # q rows of entry i are rotated at positions (cache_seqlens[i] - q_lens[i]) + row
         rot = _rotary_table(None, None, _rotary_cos_sin, False, q)
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
-    _launch(p, dev)
+    _launch(p, dev, keep=(q, k_cache, v_cache, q_start, q_lens, cache_seqlens, cache_batch_idx, out, _rotary_cos_sin))
     return out

@@ -41,6 +41,10 @@ def klib():
         lib.vattn_attn_workspace_bytes.argtypes = [C.POINTER(AttnParams)]
         lib.vattn_flash_attn_with_kvcache.restype = i32
         lib.vattn_flash_attn_with_kvcache.argtypes = [C.POINTER(AttnParams), vp]
+        lib.vattn_hybrid_workspace_bytes.restype = C.c_size_t
+        lib.vattn_hybrid_workspace_bytes.argtypes = [C.POINTER(AttnParams), C.POINTER(AttnParams)]
+        lib.vattn_hybrid_attn.restype = i32
+        lib.vattn_hybrid_attn.argtypes = [C.POINTER(AttnParams), C.POINTER(AttnParams), vp, vp]
         lib.vattn_cache_flat.restype = i32
         lib.vattn_cache_flat.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp]
         lib.vattn_cache_flat_rope.restype = i32

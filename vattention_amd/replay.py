@@ -139,7 +139,7 @@ class HotPathRunner:
         self.stats = ReplayStats()
         self.sample_kv_util = True
         self.iter_hook = None       # called once per iteration right after engine.step (bench.py: the TP control-plane exchange)
-        self.next_request = None    # (seq_id, context length) the scheduler will admit next: pre-mapped under this iteration's forward
+        self.next_request = None    # (seq_id, context length) — or a list of them — the scheduler will admit next: pre-mapped under this iteration's forward
         self.admission_lookahead = True
         # Compute runs on a NON-BLOCKING stream: on ROCm 7.2 hipMemMap / hipMemUnmap wait for work queued on
         # the legacy default stream (and every blocking stream) but not for non-blocking streams
@@ -172,7 +172,9 @@ class HotPathRunner:
             if self.iter_hook is not None:
                 self.iter_hook(self)
             if self.next_request is not None and self.admission_lookahead:
-                self.engine.prefetch_request(*self.next_request)       # queued behind this step's own look-ahead batch
+                nxt = self.next_request if isinstance(self.next_request, list) else [self.next_request]
+                for sid, n in nxt:
+                    self.engine.prefetch_request(sid, n)               # queued behind this step's own look-ahead batch
                 self.next_request = None
             self.wrapper.begin_forward(mds)
             out = None
@@ -299,8 +301,15 @@ class HotPathRunner:
                 mds = [SequenceMetadata(s, s.prompt_len, True) for s in admitted]
             else:
                 mds = [SequenceMetadata(s, 0, False) for s in running]
-            if waiting and len(running) < B:
-                self.next_request = (waiting[0].seq_id, waiting[0].prompt_len)      # the head of the queue is what gets admitted next
+            # what the NEXT iteration will admit (same token budget and batch rule, free-block rule left to the real admission): the
+            # mapper thread maps these prompts' pages while this iteration computes
+            nxt, bud = [], max_tokens
+            for s in waiting:
+                if len(running) + len(nxt) >= B or s.prompt_len > bud:
+                    break
+                nxt.append((s.seq_id, s.prompt_len))
+                bud -= s.prompt_len
+            self.next_request = nxt or None
             self.run_iteration(mds)
             out["iters"] += 1
             running = [s for s in running if not s.is_finished()]
