@@ -114,12 +114,12 @@ def test_hybrid_batches_two_streams_match_serial():
     # fa_pod: the hybrid iterations go through the fused launch (other tilings / split counts than the serial plan: same values up to
     # fp rounding; its parity proper — against the oracle — is tests/test_gpu_hybrid_fused.py); cache contents are bit-identical
     from vattention_amd.attention.vattention_flashattention_pod_wrapper import VAttentionFlashAttentionPodWrapper as Pod
-    prev = Pod.FUSE_MIN_SHARE
-    Pod.FUSE_MIN_SHARE = 0.0              # fuse every hybrid iteration, however lopsided
+    prev = Pod.FUSE_MIN_SHARE, Pod.FUSED_ENABLED
+    Pod.FUSE_MIN_SHARE, Pod.FUSED_ENABLED = 0.0, True      # fuse every hybrid iteration, however lopsided
     try:
         b, kb, vb = run("fa_pod")
     finally:
-        Pod.FUSE_MIN_SHARE = prev
+        Pod.FUSE_MIN_SHARE, Pod.FUSED_ENABLED = prev
     assert len(a) == len(b)
     for x, y in zip(a, b):
         assert (x - y).abs().max().item() < 2e-3

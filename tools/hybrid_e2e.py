@@ -34,6 +34,7 @@ def run(a, backend):
 
 
 if __name__ == "__main__":
+    os.environ["VATTN_POD_FUSED"] = "1"      # fa_pod = the fused launch here (off by default in the product: see the wrapper)
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--ctx", type=int, default=16384)

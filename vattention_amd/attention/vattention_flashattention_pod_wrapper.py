@@ -8,10 +8,13 @@ cache prefix; the decode part appends its one row per sequence in-kernel).  The 
 output without the `[prefill_cache_len:]` offset its non-fused sibling applies (:154-158); here both parts write straight into
 their rows of `output`, as in the base wrapper.
 
-The fused launch co-locates one matrix-bound and one HBM-bound workgroup on every CU; it pays when neither part dwarfs the
-other.  begin_forward() estimates both parts' stand-alone times on the host (lengths are known there) and takes the fused launch
-when the smaller part is at least FUSE_MIN_SHARE of the larger one; otherwise the iteration runs as in the streams wrapper
-(prefill64 / KV-split prefill followed by — or beside — decode)."""
+The fused launch co-locates one matrix-bound and one HBM-bound workgroup on every CU.  MEASURED on MI355X
+(profiles/r02_hybrid_probe.txt, r02_hybrid_e2e.txt) it LOSES to the serial order and to two streams on every Sarathi-shaped batch
+(0.26-0.64x): the stand-alone kernels already saturate what each is bound by (HBM for decode at 12 waves per CU, board power for
+prefill), and inside one kernel both bodies share one register allocation (256 per lane), which leaves decode a third of its
+waves.  So the fused launch is built, parity-checked against the oracle (tests/test_gpu_hybrid_fused.py) and OFF by default:
+`fa_pod` follows the streams wrapper's per-iteration policy unless FUSED_ENABLED is set (env VATTN_POD_FUSED=1), in which case
+begin_forward() takes the fused launch when the smaller part's estimated time is at least FUSE_MIN_SHARE of the larger one's."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
@@ -25,15 +28,20 @@ from .vattention_flashattention_streams_wrapper import VAttentionFlashAttentionS
 
 class VAttentionFlashAttentionPodWrapper(VAttentionFlashAttentionStreamsWrapper):
     _inst = None
+    FUSED_ENABLED = None          # None: read VATTN_POD_FUSED from the environment
     FUSE_MIN_SHARE = 0.15
     # stand-alone rates of the two bodies inside the fused launch [measured, profiles/r02_hybrid_probe.txt]
-    FUSED_PREFILL_FLOPS = 6.0e14
+    FUSED_PREFILL_FLOPS = 4.5e14
 
     def begin_forward(self, seq_metadata_list) -> None:
         super().begin_forward(seq_metadata_list)
         self._fused = self._plan_fused()
 
     def _plan_fused(self) -> bool:
+        import os
+        enabled = self.FUSED_ENABLED if self.FUSED_ENABLED is not None else os.environ.get("VATTN_POD_FUSED", "0") == "1"
+        if not enabled:
+            return False
         if not self.prefill_query_lens or not self.decode_batch_size or self.head_dim != 128:
             return False
         if len(self.prefill_query_lens) >= 2 and max(self.prefill_query_lens) < 2:

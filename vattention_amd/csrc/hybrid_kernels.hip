@@ -112,13 +112,18 @@ __global__ __launch_bounds__(256, 2) void hybrid_kernel(vattn_attn_params pp, va
             const int hk = t % pd.h_k, b = t / pd.h_k;
             decode_body<T, 128, true>(pd, dsplits, gblocks, fused_append, split, hk, gb, b, smem);
             if (dsplits > 1) {
-                __threadfence();                      // this workgroup's partial is visible device-wide before its ticket is
+                // release: the barrier retires every wave's partial stores (they sit in this XCD's L2), then ONE wave writes the L2
+                // back before the group's ticket is taken — an agent-scope fence per wave costs 4x that on this multi-XCD part
                 __syncthreads();
                 const int grp = (b * pd.h_k + hk) * gblocks + gb;
-                if (tid == 0) s_it[0] = atomicAdd(&done[grp], 1);
+                if (tid < 64) {
+                    __threadfence();
+                    if (tid == 0) s_it[0] = atomicAdd(&done[grp], 1);
+                }
                 __syncthreads();
                 if (s_it[0] == dsplits - 1) {         // the last split of the group: merge (every other partial was released before)
-                    __threadfence();
+                    if (tid < 64) __threadfence();    // acquire: one invalidate serves the CU
+                    __syncthreads();
                     hybrid_combine<T>(pd, dsplits, hk, gb, b);
                     if (tid == 0) done[grp] = 0;
                 }

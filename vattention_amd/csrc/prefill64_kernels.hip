@@ -617,24 +617,26 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     static const int env_sel = [] { const char* e = getenv("VATTN_PREFILL64_BUILD"); return e ? atoi(e) & 15 : 0; }();   // measurement hook
     const int sel = ((p->variant >> 8) & 15) ? ((p->variant >> 8) & 15) : env_sel;
+    // product build: padded K image (ABL bit 7; +0.6 % over the XOR-swizzled image, 28 fewer VALU instructions per tile)
     if (p->dtype == VATTN_DTYPE_BF16) {
-        if (sel == 1) launch64_t<__bf16, 64, 24, 4>(p, st, nsplit);
-        else if (sel == 10) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit);
-        else launch64_t<__bf16, 0, 24, 4>(p, st, nsplit);
+        if (sel == 1) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit);
+        else if (sel == 3) launch64_t<__bf16, 0, 24, 4>(p, st, nsplit);
+        else launch64_t<__bf16, 128, 24, 4>(p, st, nsplit);
         return;
     }
     switch (sel) {
-        case 1: launch64_t<_Float16, 64, 24, 4>(p, st, nsplit); break;         // row sums by v_dot2c over the packed P
-        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit); break;        // padded K image, immediate fragment addresses
-        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit); break;  // both
-        case 3: launch64_t<_Float16, 0, 24, 3>(p, st, nsplit); break;
-        case 4: launch64_t<_Float16, 1, 24, 4>(p, st, nsplit); break;          // no LDS-DMA in the steady state
-        case 5: launch64_t<_Float16, 2, 24, 4>(p, st, nsplit); break;          // no fma / exp2 / row sums
-        case 6: launch64_t<_Float16, 8, 24, 4>(p, st, nsplit); break;          // no per-tile wait + barrier
-        case 7: launch64_t<_Float16, 16, 24, 4>(p, st, nsplit); break;         // no LDS fragment reads
-        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32, 24, 4>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
-        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32, 24, 4>(p, st, nsplit); break;   // MFMAs only
-        default: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit); break;
+        case 1: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit); break;   // row sums by v_dot2c over the packed P (no gain: the
+                                                                               // dot instructions serialise with the MFMA pipe, profiles/r02_issue_probe.txt)
+        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit); break;        // = product
+        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit); break;  // = build 1
+        case 3: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit); break;          // XOR-swizzled K image (the round's first layout)
+        case 4: launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit); break;          // no LDS-DMA in the steady state
+        case 5: launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit); break;          // no fma / exp2 / row sums
+        case 6: launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit); break;          // no per-tile wait + barrier
+        case 7: launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit); break;         // no LDS fragment reads
+        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
+        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit); break;   // MFMAs only
+        default: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit); break;
     }
 }
 
