@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         // maximum alone; past the last tile S'(t+1) is computed from a zero-filled K slot and never used.
         // ---------------- 64 groups of { MFMA ; fragment read ahead ; a slice of softmax VALU } ----------------
         // phase A: S'(t+1) = K(t+1).Q^T - m   (32 MFMAs: k-step kk = i>>2, key block (i>>1)&1, query block i&1)
+        V8 pf[2][2];         // P(t) fragments of the key slice being multiplied and of the next one
         V8 kf[RING];         // RING - 1 fragments (twice as many MFMAs) ahead of their use
         kf[0] = kf0;
         kf[1] = kf1;
@@ -438,16 +439,23 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             else M::qk_acc(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
             if ((i & 1) == 0 && f + RING - 1 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + RING - 1) % RING] = kfrag(ksm, f + RING - 1);
             softmax_stages(i, cur);
+            // key slice 0 of P(t) (pairs 0-7: exponentiated by group GE(7) <= 12 for NA >= 16) is packed HERE, so the first P.V MFMA
+            // of phase B does not wait for eight conversions issued right in front of it
+            if (NA >= 16) {
+                if (i == 13) pf[0][0] = pack_p(cur, 0, 0);
+                if (i == 15) pf[0][1] = pack_p(cur, 0, 1);
+            }
             SCHED_FENCE();
         }
         // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
         V8 vf[RING];
-        V8 pf[2][2];
         vf[0] = vfrag(vsm, 0);
         vf[1] = vfrag(vsm, 1);
         if (RING > 3) vf[2] = vfrag(vsm, 2);
-        pf[0][0] = pack_p(cur, 0, 0);
-        pf[0][1] = pack_p(cur, 0, 1);
+        if (NA < 16) {
+            pf[0][0] = pack_p(cur, 0, 0);
+            pf[0][1] = pack_p(cur, 0, 1);
+        }
         float mx0 = -INFINITY, mx1 = -INFINITY;
         SCHED_FENCE();
 #pragma unroll
