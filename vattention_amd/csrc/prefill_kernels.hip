@@ -428,7 +428,11 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     // (tools/kbench.py, profiles/r02_kbench.txt): Yi-6B 32 k prompt 968 -> 1165 TFLOP/s, 16 k chunk @ 112 k 1012 -> 1190,
     // Llama-70B/TP8 2 k chunk @ 30 k 918 -> 1052; short whole prompts (2 k tokens: 16 tiles per workgroup) and grids that stay
     // under 192 workgroups keep the tilings below.
-    if (p->d == 128) {
+    // Exception (profiles/r02_kbench_split_sweep.txt): a causal WHOLE prompt whose grid is at most one workgroup per CU (Llama-70B/TP8
+    // 8 k prompt: 256 workgroups of 4 ... 128 key tiles) is bound by its longest workgroup's key walk; two key-range shares per
+    // query block on the 8-wave tiling (two rounds, heaviest first) measure 0.192 ms against 0.239 (prefill64 unsplit), 0.226 (4-wave
+    // tiling unsplit) and 0.201 (prefill64, two shares).
+    if (p->d == 128 && (uniform || wg8 > 256)) {
         const int ns7 = wg8 >= 256 ? 1 : pick(wg8, 256);
         if (wg8 * ns7 >= 192 && tiles / ns7 >= 24) {
             pl.tiling = 7;
@@ -437,7 +441,12 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
         }
     }
     if (wg8 > 256) return pl;
-    if (wg8 == 256) { pl.tiling = 4; return pl; }
+    if (wg8 == 256) {
+        const int ns = uniform ? 1 : cap_by_tiles(2);
+        if (ns > 1) pl.nsplit = ns;
+        else pl.tiling = 4;
+        return pl;
+    }
     const int ns8 = pick(wg8, 256);
     if (ns8 == 1) { pl.tiling = 4; return pl; }                      // cannot split (short prefix): more, smaller workgroups
     if (wg8 * ns8 >= 192) { pl.nsplit = ns8; return pl; }
