@@ -26,8 +26,8 @@ Extra objects on the JSON line (N = 1): `roofline` (dominant kernel: causal pref
 launch / mean launch duration from HIP events on the launch stream inside the timed region), `roofline_decode` (HBM-bound split-KV
 decode, same method), `cold_wave` (the first wave on a fresh pool: handle creation, synchronous vs mapper-thread mapping),
 `dynamic` (256-request arxiv replay, all 32 layers of Llama-3-8B: peak concurrency, fragmentation, mapping cost), `cpu_baseline`
-(the CPU oracle — kind "port" — timed on the real shapes of this workload: one layer of a batch-16 decode step at 32k and the last
-2 048 query rows of the 32 702-token prefill, scaled by the stated law).
+(the CPU oracle — kind "port" — timed on the real shapes of this workload: one layer of a decode step at 32k and the last
+512 query rows of the 32 702-token prefill, scaled by the stated law).
 """
 from __future__ import annotations
 
