@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--no-dynamic", action="store_true", help="skip the dynamic-trace and full-trace legs (N = 1)")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; makes the number INVALID)")
     ap.add_argument("--ctx", type=int, default=0, help="override context length (debug only; makes the number INVALID)")
+    ap.add_argument("--rank-of", type=int, default=0, help="debug: run ONE rank's share of the --gpus N workload of this value on a single GPU, "
+                    "without the collectives (checks the tensor-parallel workloads where only one GPU is visible; NOT a bench line)")
     return ap.parse_args()
 
 
@@ -156,11 +158,13 @@ def main():
     from vattention_amd.attention.timers import drain_op_timers, enable_op_timers
     from vattention_amd.replay import CacheConfig, HotPathRunner, ModelConfig, ParallelConfig
 
-    w = dict(WORKLOADS[world])
+    if a.rank_of and (world != 1 or a.rank_of not in WORKLOADS):
+        raise SystemExit("--rank-of needs --gpus 1 and one of %s" % sorted(WORKLOADS))
+    w = dict(WORKLOADS[a.rank_of or world])
     if a.ctx:
         w["ctx"] = a.ctx
     dtype = torch.float16                                    # benchmark_runner.py:81
-    valid = not (a.layers or a.ctx)
+    valid = not (a.layers or a.ctx or a.rank_of)
 
     def make_runner(model_name, tp, ctx, page, batch, backend_name, mem_bytes, layers=0):
         model = ModelConfig.named(model_name, dtype=dtype, max_model_len=ctx, attention_backend=backend_name)

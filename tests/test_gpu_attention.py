@@ -63,6 +63,50 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
         assert torch.equal(kgi.cpu(), kc1) and torch.equal(vgi.cpu(), vc1)     # in-place append, bit-exact, nothing else touched
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("B,G,Hkv,D,lens", [
+    (1, 8, 4, 128, [32700]),              # B1 @ 32k: 48 splits, the shape the single-launch merge exists for
+    (3, 8, 2, 128, [5000, 17, 900]),      # ragged: some splits of the short sequences are empty
+    (2, 40, 1, 128, [3000, 777]),         # G = 40: two workgroups of two 16-head blocks each (the second half empty in the last)
+    (2, 32, 2, 128, [4096, 100]),         # G = 32: ONE pass over K/V for all 32 heads
+    (2, 71, 1, 64, [2500, 300]),          # Falcon-7B shape (d = 64, G = 71)
+    (4, 17, 2, 64, [1000, 1, 64, 333]),
+], ids=["b1_32k", "ragged", "g40", "g32", "falcon_g71_d64", "g17_d64"])
+def test_decode_single_launch_merge_and_head_block_groups(B, G, Hkv, D, lens, dtype):
+    """Round 2 decode forms against the oracle: (a) the split-KV merge inside the decode launch (variant bit 9 forces it, bit 8
+    forbids it, default = by grid size), incl. repeated calls on one stream (the group counters reset themselves); (b) two 16-head
+    blocks per workgroup for G > 16 (variant bit 7 = one block per workgroup, the round-1 form)."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(B * 131 + G)
+    Hq, ctx, slots = G * Hkv, max(lens) + 40, B + 2
+    kc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    vc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    q = torch.randn(B, 1, Hq, D).to(dtype)
+    kn = torch.randn(B, 1, Hkv, D).to(dtype)
+    vn = torch.randn(B, 1, Hkv, D).to(dtype)
+    idx = torch.randperm(slots)[:B].to(torch.int32)
+    cl = torch.tensor(lens, dtype=torch.int32)
+    ml = max(lens) + 1
+    kc1, vc1 = kc.clone(), vc.clone()
+    ref64 = flash_attn_with_kvcache_ref(q, kc1[:, :ml], vc1[:, :ml], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+    kc2, vc2 = kc.clone(), vc.clone()
+    ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :ml], vc2[:, :ml], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
+    outs = {}
+    for variant in (0, 256, 512, 128, 128 | 512):
+        for splits in (0, 5):
+            kg, vg = kc.to(DEV), vc.to(DEV)
+            for rep in range(3 if variant & 512 else 1):
+                out = flash_attn_with_kvcache(q.to(DEV), kg[:, :ml], vg[:, :ml], kn.to(DEV), vn.to(DEV), cache_seqlens=cl.to(DEV),
+                                              cache_batch_idx=idx.to(DEV), causal=True, num_splits=splits, _variant=variant)
+                torch.cuda.synchronize()
+                _check(out, ref64, ref32, dtype, "decode variant %d splits %d call %d" % (variant, splits, rep))
+            assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)
+            outs[(variant, splits)] = out.float().cpu()
+    # the merge arithmetic is the same in both forms: same values up to the order of one multiply-add
+    for splits in (0, 5):
+        assert (outs[(256, splits)] - outs[(512, splits)]).abs().max().item() <= (1e-3 if dtype == torch.float16 else 8e-3)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12, 14, 270, 526, 2574], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved", "w4q2_dma_pipelined", "w4q2_dma_dot2_rowsum", "w4q2_dma_kpad", "w4q2_dma_dot2_kpad"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("n,c,Hq,Hkv", [
@@ -184,11 +228,16 @@ def test_prefill_kv_split(causal, variant):
     ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=causal, math="f32")
     base = None
     for splits in (1, 2, 3, 5, 16):
-        out, lse = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
-                                           causal=causal, num_splits=splits, return_softmax_lse=True, _variant=variant)
-        torch.cuda.synchronize()
-        _check(out, ref64, ref32, torch.float16, "kv-split prefill splits=%d" % splits)
-        assert torch.allclose(lse.double().cpu(), lse64.double(), atol=2e-3, rtol=1e-3), "lse splits=%d" % splits
+        got = {}
+        for two_launch in (0, 16384):      # the shares merged inside the launch (default), and by combine_rows_kernel in a second launch
+            for rep in range(2):           # twice on one stream: the merge counters reset themselves
+                out, lse = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
+                                                   causal=causal, num_splits=splits, return_softmax_lse=True, _variant=variant | two_launch)
+                torch.cuda.synchronize()
+                _check(out, ref64, ref32, torch.float16, "kv-split prefill splits=%d two_launch=%d" % (splits, two_launch))
+                assert torch.allclose(lse.double().cpu(), lse64.double(), atol=2e-3, rtol=1e-3), "lse splits=%d" % splits
+            got[two_launch] = out.float().cpu()
+        assert torch.equal(got[0], got[16384]), "the two merge forms run the same arithmetic on the same partials"
         if base is None:
             base = out.float().cpu()
         else:      # splitting only regroups the fp32 accumulation

@@ -8,6 +8,9 @@
 //   I/O dtype before PV), flash_fwd_kernel.h:1116-1297 (split combine).
 // Every K/V access is predicated on the sequence's visible length: rows at or beyond it may sit
 // on unmapped virtual pages (SURVEY §7 "never touch unmapped VA").
+#include <map>
+#include <mutex>
+#include <utility>
 #include "attn_common.h"
 
 namespace vattn_k {
@@ -166,6 +169,31 @@ __global__ void selftest_dma_high_kernel(int* res, const unsigned* gsrc) {
         res[7] = found;
     }
 }
+
+// Counters of the single-launch merges (split-KV decode, KV-split prefill) for launches on stream `st`: created (and zeroed, stream-ordered) on first use, never while
+// the stream is being captured into a graph (then the caller takes the two-launch form; a warm-up call before capture creates it).
+int* merge_counters(hipStream_t st, size_t n_ints) {
+    struct Buf { int* p; size_t n; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    Buf& b = bufs[std::make_pair(dev, st)];
+    if (b.p && b.n >= n_ints) return b.p;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    const size_t n = n_ints < 16384 ? 16384 : n_ints;
+    int* np = nullptr;
+    if (hipMalloc((void**)&np, n * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemsetAsync(np, 0, n * sizeof(int), st) != hipSuccess) { (void)hipFree(np); return nullptr; }
+    // an older, smaller buffer may still be in use by launches queued on the stream: it is leaked on purpose (a few KiB, at most
+    // once per growth step)
+    b.p = np;
+    b.n = n;
+    return np;
+}
+
 
 thread_local std::string g_err;
 int fail(int code, const char* msg) {

@@ -156,12 +156,69 @@ __device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order
 }
 
 
+// ---- single-launch merge of KV-split prefill partials (round 2) ----
+// Called by every workgroup of a KV-split prefill launch after it has written its partial (normalised fp32 rows + log2-domain LSE,
+// layout of combine_rows_kernel): release (barrier, then ONE wave's agent-scope fence), ticket from the query block's counter, and
+// the holder of the last ticket merges the nsplit partials of the block's rows [q0, q_end) of head h — the arithmetic of
+// combine_rows_kernel (one wave per row, lanes over column pairs), without the second launch and with the partials still in L2 /
+// MALL.  `counter` is zero between launches (the merger resets it).
+template <typename T, int HD>
+__device__ __forceinline__ void prefill_release_and_merge(const vattn_attn_params& p, const int nsplit, const int b, const int h, const int q0,
+                                                          const int q_end, const int64_t q_first, int* counter, int* s_ticket) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    __syncthreads();
+    if (tid < 64) {
+        __threadfence();
+        if (tid == 0) *s_ticket = atomicAdd(counter, 1);
+    }
+    __syncthreads();
+    if (*s_ticket != nsplit - 1) return;
+    if (tid < 64) __threadfence();
+    __syncthreads();
+    const int sq = p.seqlen_q;
+    const float* oacc = (const float*)p.workspace;
+    const int64_t sstride = (int64_t)p.b * sq * p.h;
+    const float* lacc = oacc + (int64_t)nsplit * sstride * HD;
+    for (int q = q0 + wave; q < q_end; q += nwaves) {
+        const int64_t row = ((int64_t)b * sq + q) * p.h + h;
+        const float my = (lane < nsplit) ? lacc[(int64_t)lane * sstride + row] : -INFINITY;
+        float mx = my;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));      // splits <= 16 live in lanes 0..15
+        mx = __shfl(mx, 0, 64);
+        const float mxs = (mx == -INFINITY) ? 0.f : mx;
+        const float w = (lane < nsplit) ? fast_exp2(my - mxs) : 0.f;
+        float wsum = w;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) wsum += xor_shuffle(wsum, o);
+        wsum = __shfl(wsum, 0, 64);
+        const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+        if (2 * lane < HD) {
+            const float* src = oacc + row * HD + 2 * lane;
+            float a0 = 0.f, a1 = 0.f;
+            for (int s = 0; s < nsplit; s++) {
+                const float ws = __shfl(w, s, 64);
+                const float2 v = *(const float2*)(src + (int64_t)s * sstride * HD);
+                a0 += ws * v.x;
+                a1 += ws * v.y;
+            }
+            T* dst = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + q) * p.o_row_stride + (int64_t)h * p.o_head_stride + 2 * lane;
+            dst[0] = Tr<T>::cvt(a0 * inv);
+            dst[1] = Tr<T>::cvt(a1 * inv);
+        }
+        if (p.softmax_lse && lane == 0)
+            p.softmax_lse[((int64_t)b * p.h + h) * sq + q] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+    }
+    if (tid == 0) *counter = 0;
+}
+
 // ---- host-side pieces shared by the translation units ----
 int fail(int code, const char* msg);                                    // attn_api.hip: records the message for vattn_kernels_last_error
 void launch_append(const vattn_attn_params* p, hipStream_t st);         // cache_kernels.hip
 int launch_prefill_form(const vattn_attn_params* p, hipStream_t st);    // prefill_kernels.hip (seqlen_q > 1)
 size_t prefill_workspace_bytes(const vattn_attn_params* p);
-void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit);   // prefill64_kernels.hip (d = 128)
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done);   // prefill64_kernels.hip (d = 128); done: counters of the single-launch merge or NULL
+int* merge_counters(hipStream_t st, size_t n_ints);                      // attn_api.hip: zeroed per-(device, stream) counters, NULL while capturing
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
 size_t decode_workspace_bytes(const vattn_attn_params* p);
 int launch_hybrid(const vattn_attn_params* prefill, const vattn_attn_params* decode, void* ws, hipStream_t st);   // hybrid_kernels.hip

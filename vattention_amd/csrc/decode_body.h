@@ -9,9 +9,12 @@ constexpr int DC_WAVES = 4;
 constexpr int DC_BN = 32;     // keys per wave tile
 
 // workspace layout: float o_accum[splits][b][h][d]; float lse_accum[splits][b][h]  (log2 domain, scaled)
-// The work of ONE workgroup — split `split` of kv head hk, head block gb, sequence b — as a device function: decode_kernel below
+// The work of ONE workgroup — split `split` of kv head hk, head-block GROUP gb, sequence b — as a device function: decode_kernel below
 // maps blockIdx to it; hybrid_kernel (hybrid_kernels.hip) calls it from a persistent loop.
-template <typename T, int HD, bool USE_TR>
+// NB: 16-head blocks per workgroup (round 2).  With G > 16 query heads per kv head the blocks gb*NB .. gb*NB + NB-1 share ONE pass
+// over the K/V rows: the K fragments (registers) and the V^T staging (LDS) of a tile feed NB score / output MFMA chains.  NB = 2
+// keeps the kernel inside the 168-register budget of three workgroups per CU; wider groups run as ceil(G/32) such workgroups.
+template <typename T, int HD, bool USE_TR, int NB = 1>
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
                                             const int split, const int hk, const int gb, const int b, char* smem) {
     using X = Tr<T>;
@@ -47,20 +50,21 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     const int new_key = fused_append ? Lk - 1 : -1;
     const int new_tile = fused_append ? new_key / DC_BN : -1;
 
-    const int row_head = gb * 16 + l15;                 // query head within the group handled by this lane's column
-    const bool row_valid = row_head < G;
-    const int h = hk * G + row_head;
-    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
     const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
     const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
 
     // Q^T fragments (B operand, n = query head): slot (g4, j) <-> d = 32*kk + 8*g4 + j
-    V8 qf[KK];
+    V8 qf[NB][KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row_valid) v = *(const uint4*)(qptr + 32 * kk + 8 * g4);
-        qf[kk] = as_v8<V8>(v);
+    for (int nb = 0; nb < NB; nb++) {
+        const int row_head = (gb * NB + nb) * 16 + l15;     // query head within the group handled by this lane's column
+        const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)(hk * G + row_head) * p.q_head_stride;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row_head < G) v = *(const uint4*)(qptr + 32 * kk + 8 * g4);
+            qf[nb][kk] = as_v8<V8>(v);
+        }
     }
     // fused RoPE (include/vattn_kernels.h): the query token sits at position Lk - 1; slot (g4, j) of k-step kk is element
     // d = 32*kk + 8*g4 + j, so element d and its partner d + HD/2 live in the SAME lane (k-steps kk and kk + KK/2)
@@ -70,14 +74,20 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
         for (int kk = 0; kk < KK / 2; kk++) {
             V8 c, s;
             rope_load<T>(p, (int64_t)(Lk - 1), 32 * kk + 8 * g4, c, s);
-            rope8<T>(qf[kk], qf[kk + KK / 2], c, s);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) rope8<T>(qf[nb][kk], qf[nb][kk + KK / 2], c, s);
         }
     }
 
-    f32x4 o[DB];
+    f32x4 o[NB][DB];
+    float m_run[NB], l_run[NB];
 #pragma unroll
-    for (int i = 0; i < DB; i++) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+        for (int i = 0; i < DB; i++) o[nb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_run[nb] = -INFINITY;
+        l_run[nb] = 0.f;
+    }
     const float sc = p.softmax_scale * kLog2e;
     char* vsm = smem + wave * V_WAVE_BYTES;
 
@@ -155,55 +165,60 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             const int row = idx / CPR, c = idx % CPR;
             *(uint4*)(vsm + (c >> 1) * VSUB + row * 32 + ((c & 1) << 4)) = vreg[ps];
         }
-        // ---- S^T = K.Q^T on the register-resident K fragments ----
-        f32x4 s[2];
+        // ---- S^T = K.Q^T on the register-resident K fragments (every head block of the group uses the same fragments) ----
+        f32x4 s[NB][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-            s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-            for (int kk = 0; kk < KK; kk++) s[kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qf[kk], s[kb]);
-        }
+            for (int kb = 0; kb < 2; kb++) {
+                s[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) s[nb][kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qf[nb][kk], s[nb][kb]);
+            }
         // prefetch the wave's next tile while this one is being consumed (out of range past the split's end)
         load_tile(tile + DC_WAVES < tile_end ? tile + DC_WAVES : ntiles_total);
 
-        // s[kb][r] = S^T[key = k0 + 16*kb + 4*g4 + r][head row l15]
-        if (k0 + DC_BN > Lk) {
+        // s[nb][kb][r] = S^T[key = k0 + 16*kb + 4*g4 + r][head row l15 of block nb]
+        V8 pf[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            if (k0 + DC_BN > Lk) {
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (k0 + 16 * kb + 4 * g4 + r >= Lk) s[nb][kb][r] = -INFINITY;
+            }
+            float mloc = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (k0 + 16 * kb + 4 * g4 + r >= Lk) s[kb][r] = -INFINITY;
+                for (int r = 0; r < 4; r++) mloc = fmaxf(mloc, s[nb][kb][r]);
+            mloc = fmaxf(mloc, xor_shuffle(mloc, 16));
+            mloc = fmaxf(mloc, xor_shuffle(mloc, 32));
+            const float m_new = fmaxf(m_run[nb], mloc);
+            const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
+            const float alpha = fast_exp2(m_run[nb] * sc - msub);
+            m_run[nb] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float e = fast_exp2(__builtin_fmaf(s[nb][kb][r], sc, -msub));
+                    psum += e;
+                    pf[nb][4 * kb + r] = X::cvt(e);
+                }
+            l_run[nb] = l_run[nb] * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < DB; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[nb][i][r] *= alpha;
         }
-        float mloc = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) mloc = fmaxf(mloc, s[kb][r]);
-        mloc = fmaxf(mloc, xor_shuffle(mloc, 16));
-        mloc = fmaxf(mloc, xor_shuffle(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
-        const float alpha = fast_exp2(m_run * sc - msub);
-        m_run = m_new;
-        float psum = 0.f;
-        V8 pf;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float e = fast_exp2(__builtin_fmaf(s[kb][r], sc, -msub));
-                psum += e;
-                pf[4 * kb + r] = X::cvt(e);
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DB; i++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[i][r] *= alpha;
 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- O^T += V^T.P^T : A slot (g4, j) <-> key k0 + (j<4 ? 4*g4 + j : 16 + 4*g4 + j-4) ----
+        // ---- O^T += V^T.P^T : A slot (g4, j) <-> key k0 + (j<4 ? 4*g4 + j : 16 + 4*g4 + j-4); one V^T fragment read per d block ----
 #pragma unroll
         for (int db = 0; db < DB; db++) {
             V8 a;
@@ -220,65 +235,139 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
                     a[j] = vs[key * 16 + l15];
                 }
             }
-            o[db] = X::mfma16(a, pf, o[db]);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) o[nb][db] = X::mfma16(a, pf[nb], o[nb][db]);
         }
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- merge the 4 waves (each holds a partial softmax over its own tiles) ----
-    l_run += xor_shuffle(l_run, 16);
-    l_run += xor_shuffle(l_run, 32);
-    __syncthreads();                                    // all waves are done with their V staging area
-    // o[db][r] = O^T[d = 16*db + 4*g4 + r][head row l15]
+    // ---- merge the 4 waves (each holds a partial softmax over its own tiles), one head block after the other ----
     float* osm = (float*)smem;                          // [wave][16 rows][HD]
     float* msm = (float*)(smem + DC_WAVES * 16 * HD * 4);   // [wave][16] m, then [wave][16] l
     float* lsm = msm + DC_WAVES * 16;
 #pragma unroll
-    for (int db = 0; db < DB; db++)
+    for (int nb = 0; nb < NB; nb++) {
+        float lr = l_run[nb];
+        lr += xor_shuffle(lr, 16);
+        lr += xor_shuffle(lr, 32);
+        __syncthreads();                                // all waves are done with their V staging area / the previous block's merge
+        // o[nb][db][r] = O^T[d = 16*db + 4*g4 + r][head row l15]
 #pragma unroll
-        for (int r = 0; r < 4; r++) osm[(wave * 16 + l15) * HD + 16 * db + 4 * g4 + r] = o[db][r];
-    if (g4 == 0) {
-        msm[wave * 16 + l15] = m_run;
-        lsm[wave * 16 + l15] = l_run;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 16 * HD; idx += 64 * DC_WAVES) {
-        const int row = idx / HD, d = idx % HD;
-        const int rh = gb * 16 + row;
-        if (rh >= G) continue;
-        float mx = -INFINITY;
+        for (int db = 0; db < DB; db++)
 #pragma unroll
-        for (int w = 0; w < DC_WAVES; w++) mx = fmaxf(mx, msm[w * 16 + row]);
-        float acc = 0.f, lsum = 0.f;
-        const float mxs = (mx == -INFINITY) ? 0.f : mx * sc;
-#pragma unroll
-        for (int w = 0; w < DC_WAVES; w++) {
-            const float f = fast_exp2(msm[w * 16 + row] * sc - mxs);
-            acc += f * osm[(w * 16 + row) * HD + d];
-            lsum += f * lsm[w * 16 + row];
+            for (int r = 0; r < 4; r++) osm[(wave * 16 + l15) * HD + 16 * db + 4 * g4 + r] = o[nb][db][r];
+        if (g4 == 0) {
+            msm[wave * 16 + l15] = m_run[nb];
+            lsm[wave * 16 + l15] = lr;
         }
-        const int hh = hk * G + rh;
-        const float inv = (lsum == 0.f || lsum != lsum) ? 1.f : 1.f / lsum;
-        if (num_splits == 1) {
-            ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d] = X::cvt(acc * inv);
-            if (p.softmax_lse && d == 0)
-                p.softmax_lse[(int64_t)b * p.h + hh] = (lsum == 0.f) ? INFINITY : (mx * p.softmax_scale + __logf(lsum));
-        } else {
-            float* oacc = (float*)p.workspace;
-            float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
-            const int64_t row_idx = ((int64_t)split * p.b + b) * p.h + hh;
-            oacc[row_idx * HD + d] = acc * inv;
-            if (d == 0) lacc[row_idx] = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
+        __syncthreads();
+        for (int idx = tid; idx < 16 * HD; idx += 64 * DC_WAVES) {
+            const int row = idx / HD, d = idx % HD;
+            const int rh = (gb * NB + nb) * 16 + row;
+            if (rh >= G) continue;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < DC_WAVES; w++) mx = fmaxf(mx, msm[w * 16 + row]);
+            float acc = 0.f, lsum = 0.f;
+            const float mxs = (mx == -INFINITY) ? 0.f : mx * sc;
+#pragma unroll
+            for (int w = 0; w < DC_WAVES; w++) {
+                const float f = fast_exp2(msm[w * 16 + row] * sc - mxs);
+                acc += f * osm[(w * 16 + row) * HD + d];
+                lsum += f * lsm[w * 16 + row];
+            }
+            const int hh = hk * G + rh;
+            const float inv = (lsum == 0.f || lsum != lsum) ? 1.f : 1.f / lsum;
+            if (num_splits == 1) {
+                ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d] = X::cvt(acc * inv);
+                if (p.softmax_lse && d == 0)
+                    p.softmax_lse[(int64_t)b * p.h + hh] = (lsum == 0.f) ? INFINITY : (mx * p.softmax_scale + __logf(lsum));
+            } else {
+                float* oacc = (float*)p.workspace;
+                float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
+                const int64_t row_idx = ((int64_t)split * p.b + b) * p.h + hh;
+                oacc[row_idx * HD + d] = acc * inv;
+                if (d == 0) lacc[row_idx] = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
+            }
         }
     }
 }
 
-template <typename T, int HD, bool USE_TR>
-__global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append) {
+// LSE-weighted merge of the num_splits partials of head blocks gb*NB .. gb*NB + NB-1 of (b, hk) by ONE workgroup (256 threads: 16
+// threads per head, 8 output columns each) — the in-launch form of combine_kernel, used by the fused hybrid launch and by
+// decode_kernel's single-launch merge (the workgroup that completes a group's last split calls it).
+template <typename T, int HD, int NB>
+__device__ __forceinline__ void decode_group_combine(const vattn_attn_params& p, const int num_splits, const int hk, const int gb, const int b) {
+    const int tid = threadIdx.x;
+    const int G = p.h / p.h_k;
+    constexpr int CPT = HD / 16;                        // columns per thread
+    const float* oacc = (const float*)p.workspace;
+    const int64_t sstride = (int64_t)p.b * p.h;
+    const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        const int rh = (gb * NB + nb) * 16 + (tid >> 4);
+        if (rh >= G) continue;
+        const int hh = hk * G + rh;
+        const int d0 = (tid & 15) * CPT;
+        const int64_t row = (int64_t)b * p.h + hh;
+        float mx = -INFINITY;
+        for (int s = 0; s < num_splits; s++) mx = fmaxf(mx, lacc[(int64_t)s * sstride + row]);
+        const float mxs = (mx == -INFINITY) ? 0.f : mx;
+        float acc[CPT];
+#pragma unroll
+        for (int e = 0; e < CPT; e++) acc[e] = 0.f;
+        float wsum = 0.f;
+        for (int s = 0; s < num_splits; s++) {
+            const float w = fast_exp2(lacc[(int64_t)s * sstride + row] - mxs);
+            const float* src = oacc + ((int64_t)s * sstride + row) * HD + d0;
+            wsum += w;
+#pragma unroll
+            for (int e = 0; e < CPT; e += 4) {
+                const f32x4 a = *(const f32x4*)(src + e);
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[e + u] += w * a[u];
+            }
+        }
+        const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+        T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d0;
+#pragma unroll
+        for (int e = 0; e < CPT; e++) optr[e] = Tr<T>::cvt(acc[e] * inv);
+        if (p.softmax_lse && (tid & 15) == 0)
+            p.softmax_lse[(int64_t)b * p.h + hh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+    }
+}
+
+// Single-launch merge: after its partial is written, a workgroup releases it (the barrier retires every wave's stores into this
+// XCD's L2; ONE wave's agent-scope fence writes them back), takes a ticket from the group's counter, and the holder of the last
+// ticket acquires and merges.  `done` counters are zero between launches (the merger resets its group's).
+template <typename T, int HD, int NB>
+__device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params& p, const int num_splits, const int hk, const int gb, const int b,
+                                                         int* done_counter, int* s_ticket) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid < 64) {
+        __threadfence();
+        if (tid == 0) *s_ticket = atomicAdd(done_counter, 1);
+    }
+    __syncthreads();
+    if (*s_ticket == num_splits - 1) {
+        if (tid < 64) __threadfence();
+        __syncthreads();
+        decode_group_combine<T, HD, NB>(p, num_splits, hk, gb, b);
+        if (tid == 0) *done_counter = 0;
+    }
+}
+
+// gblocks = head-block GROUPS per kv head (ceil(ceil(G/16) / NB)).  `done`: NULL = partials are merged by combine_kernel in a second
+// launch; else one zero-initialised int per (sequence, kv head, group): single-launch merge.
+template <typename T, int HD, bool USE_TR, int NB>
+__global__ __launch_bounds__(64 * DC_WAVES, (HD > 128 || (HD == 128 && NB > 1)) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_ticket;
     int split, hk, gb, b;
     if (gridDim.y == 1 && gridDim.z == 1 && gblocks > 1) {
-        // G > 16 query heads per kv head (MQA models): the ceil(G/16) head blocks of one (split, kv head, sequence) read the
+        // G > 32 query heads per kv head (MQA models): the head-block groups of one (split, kv head, sequence) read the
         // SAME K/V rows.  1-D grid laid out so that those sibling workgroups get consecutive slots on ONE XCD (ids 8 apart):
         // the first reader pulls the rows from HBM, the others hit that XCD's L2
         const int L = blockIdx.x;
@@ -296,7 +385,9 @@ __global__ __launch_bounds__(64 * DC_WAVES, HD > 128 ? 2 : 3) void decode_kernel
         gb = blockIdx.y % gblocks;
         b = blockIdx.z;
     }
-    decode_body<T, HD, USE_TR>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem);
+    decode_body<T, HD, USE_TR, NB>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem);
+    if (done != nullptr && num_splits > 1)
+        decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket);
 }
 
 }  // namespace vattn_k

@@ -63,10 +63,9 @@ __global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int n
 // Split count for the decode form.  The kernel is built for 3 workgroups per CU (<= 168 VGPRs, 33 KiB LDS), i.e.
 // 768 resident workgroups on 256 CUs; like the reference's heuristic (flash_api.cpp:258-323) pick the smallest
 // split count whose last "round" of workgroups is nearly full, but against THIS chip's residency.
-int pick_splits(const vattn_attn_params* p, int gblocks) {
+int pick_splits(const vattn_attn_params* p, int gblocks, long slots = 768) {
     if (p->num_splits > 0) return p->num_splits > 128 ? 128 : p->num_splits;
     const long wg = (long)p->b * p->h_k * gblocks;
-    const long slots = 768;
     const int max_len = p->seqlen_k + p->seqlen_knew;
     const int tiles = (max_len + DC_BN - 1) / DC_BN;
     long cap = tiles / 4;                       // at least one 32-key tile per wave and split
@@ -87,28 +86,51 @@ int pick_splits(const vattn_attn_params* p, int gblocks) {
     return (int)pick;
 }
 
-template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hipStream_t st) {
+// Head blocks per workgroup: two when the kv head serves more than 16 query heads (one pass over K/V for 32 heads).
+static inline int decode_nb(const vattn_attn_params* p) { return (p->h / p->h_k > 16 && !(p->variant & 128)) ? 2 : 1; }
+static inline int decode_groups(const vattn_attn_params* p) {
+    const int blocks = (p->h / p->h_k + 15) / 16;
+    const int nb = decode_nb(p);
+    return (blocks + nb - 1) / nb;
+}
+// Single-launch merge (the last workgroup of a group merges its partials) instead of a second launch of combine_kernel: taken when
+// the whole grid is resident at once (<= 768 workgroups) — there the second launch is a visible share of the call (B1 @ 32 k: 24 us
+// of which ~7 us are the combine launch); variant bit 8: never, bit 9: always (A/B).  The group counters live in a small library-owned
+// device buffer per (device, stream), zeroed when it is created; the kernel leaves them zero.
+static inline long decode_slots(const vattn_attn_params* p) { return (p->d == 128 && decode_nb(p) == 2) ? 512 : 768; }   // resident workgroups
+static inline bool decode_inline_merge(const vattn_attn_params* p, int splits, int groups) {
+    if (splits <= 1 || (p->variant & 256)) return false;
+    if (p->variant & 512) return true;
+    return (long)splits * p->h_k * groups * p->b <= decode_slots(p);
+}
+template <typename T, int HD, int NB> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
     const bool use_tr = (p->variant & 1) == 0;
-    const int G = p->h / p->h_k;
-    const int gblocks = (G + 15) / 16;
-    const int splits = pick_splits(p, gblocks);
+    const int groups = decode_groups(p);
+    const int splits = pick_splits(p, groups, decode_slots(p));
     if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
-    dim3 grid(splits, p->h_k * gblocks, p->b), block(64 * DC_WAVES);
-    if (gblocks > 1 && !(p->variant & 64)) {           // sibling head blocks share an XCD (variant bit 6: plain 3-D grid, for A/B)
+    dim3 grid(splits, p->h_k * groups, p->b), block(64 * DC_WAVES);
+    if (groups > 1 && !(p->variant & 64)) {            // sibling groups share an XCD (variant bit 6: plain 3-D grid, for A/B)
         const long w = (long)splits * p->h_k * p->b;
-        grid = dim3((unsigned)(((w + 7) / 8) * 8 * gblocks));
+        grid = dim3((unsigned)(((w + 7) / 8) * 8 * groups));
     }
     const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
+    const vattn_attn_params& q = *p;
+    int* done = decode_inline_merge(p, splits, groups) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
+    const bool inline_merge = done != nullptr;
     if (use_tr)
-        hipLaunchKernelGGL((decode_kernel<T, HD, true>), grid, block, smem, st, *p, splits, gblocks, fused_append);
+        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, splits, groups, fused_append, done);
     else
-        hipLaunchKernelGGL((decode_kernel<T, HD, false>), grid, block, smem, st, *p, splits, gblocks, fused_append);
-    if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, *p, splits, 1);
+        hipLaunchKernelGGL((decode_kernel<T, HD, false, NB>), grid, block, smem, st, q, splits, groups, fused_append, done);
+    if (splits > 1 && !inline_merge) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, splits, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;
+}
+
+template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hipStream_t st) {
+    return decode_nb(p) == 2 ? launch_decode_nb<T, HD, 2>(p, st) : launch_decode_nb<T, HD, 1>(p, st);
 }
 
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st) {
@@ -118,9 +140,8 @@ int launch_decode_form(const vattn_attn_params* p, hipStream_t st) {
 }
 
 size_t decode_workspace_bytes(const vattn_attn_params* p) {
-    const int G = p->h / p->h_k;
-    const int gblocks = (G + 15) / 16;
-    const int splits = pick_splits(p, gblocks);
+    const int groups = decode_groups(p);
+    const int splits = pick_splits(p, groups, decode_slots(p));
     if (splits <= 1) return 0;
     return (size_t)splits * p->b * p->h * (p->d + 1) * sizeof(float);
 }

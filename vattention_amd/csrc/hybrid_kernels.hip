@@ -24,47 +24,6 @@ namespace vattn_k {
 constexpr int HY_CU_SLOTS = 2048;                    // (xcc, se, sh, cu) keys
 constexpr int HY_CTL_INTS = 4 + HY_CU_SLOTS;         // next[2], exited, pad, arrivals[HY_CU_SLOTS]; then done[groups]
 
-// LSE-weighted merge of the dsplits partials of the 16-head block (b, hk, gb): 16 threads per head, 8 output columns each
-template <typename T>
-__device__ __forceinline__ void hybrid_combine(const vattn_attn_params& p, const int dsplits, const int hk, const int gb, const int b) {
-    constexpr int HD = 128;
-    const int tid = threadIdx.x;
-    const int G = p.h / p.h_k;
-    const int rh = gb * 16 + (tid >> 4);
-    if (rh >= G) return;
-    const int hh = hk * G + rh;
-    const int d0 = (tid & 15) * 8;
-    const float* oacc = (const float*)p.workspace;
-    const int64_t sstride = (int64_t)p.b * p.h;
-    const float* lacc = oacc + (int64_t)dsplits * sstride * HD;
-    const int64_t row = (int64_t)b * p.h + hh;
-    float mx = -INFINITY;
-    for (int s = 0; s < dsplits; s++) mx = fmaxf(mx, lacc[(int64_t)s * sstride + row]);
-    const float mxs = (mx == -INFINITY) ? 0.f : mx;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float wsum = 0.f;
-    for (int s = 0; s < dsplits; s++) {
-        const float w = fast_exp2(lacc[(int64_t)s * sstride + row] - mxs);
-        const float* src = oacc + ((int64_t)s * sstride + row) * HD + d0;
-        const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
-        wsum += w;
-#pragma unroll
-        for (int e = 0; e < 4; e++) { acc[e] += w * a[e]; acc[4 + e] += w * c[e]; }
-    }
-    const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
-    T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d0;
-    typename Tr<T>::v8 o8;
-#pragma unroll
-    for (int e = 0; e < 8; e++) o8[e] = Tr<T>::cvt(acc[e] * inv);
-    if ((p.o_head_stride & 7) == 0 && (p.o_batch_stride & 7) == 0) *(typename Tr<T>::v8*)optr = o8;
-    else {
-#pragma unroll
-        for (int e = 0; e < 8; e++) optr[e] = o8[e];
-    }
-    if (p.softmax_lse && (tid & 15) == 0)
-        p.softmax_lse[(int64_t)b * p.h + hh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256, 2) void hybrid_kernel(vattn_attn_params pp, vattn_attn_params pd, int* ctl, int n_pre, int n_dec, int nqb,
                                                         int dsplits, int gblocks, int fused_append, int role_mode) {
@@ -110,24 +69,10 @@ __global__ __launch_bounds__(256, 2) void hybrid_kernel(vattn_attn_params pp, va
             const int gb = t % gblocks;
             t /= gblocks;
             const int hk = t % pd.h_k, b = t / pd.h_k;
-            decode_body<T, 128, true>(pd, dsplits, gblocks, fused_append, split, hk, gb, b, smem);
-            if (dsplits > 1) {
-                // release: the barrier retires every wave's partial stores (they sit in this XCD's L2), then ONE wave writes the L2
-                // back before the group's ticket is taken — an agent-scope fence per wave costs 4x that on this multi-XCD part
-                __syncthreads();
-                const int grp = (b * pd.h_k + hk) * gblocks + gb;
-                if (tid < 64) {
-                    __threadfence();
-                    if (tid == 0) s_it[0] = atomicAdd(&done[grp], 1);
-                }
-                __syncthreads();
-                if (s_it[0] == dsplits - 1) {         // the last split of the group: merge (every other partial was released before)
-                    if (tid < 64) __threadfence();    // acquire: one invalidate serves the CU
-                    __syncthreads();
-                    hybrid_combine<T>(pd, dsplits, hk, gb, b);
-                    if (tid == 0) done[grp] = 0;
-                }
-            }
+            decode_body<T, 128, true, 1>(pd, dsplits, gblocks, fused_append, split, hk, gb, b, smem);
+            // release the partial, take the group's ticket, the last one merges (decode_body.h: one agent-scope fence per WORKGROUP —
+            // a fence per wave costs 4x that on this multi-XCD part)
+            if (dsplits > 1) decode_release_and_merge<T, 128, 1>(pd, dsplits, hk, gb, b, &done[(b * pd.h_k + hk) * gblocks + gb], &s_it[0]);
         }
     }
     // leave the control words zero for the next launch

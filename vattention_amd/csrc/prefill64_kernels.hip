@@ -118,7 +118,7 @@ __device__ __forceinline__ float add1(float a, float b) {
 // NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
 // (RING - 1 fragments ahead of their MFMA).
 template <typename T, int ABL, int NA, int RING>
-__global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
+__global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int HD = 128;
@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     constexpr int KK = HD / 16;        // k-steps of the S^T MFMA chain
     constexpr int DB = HD / 32;        // 32-wide d blocks of O^T
     extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring [2][16 KiB], then V ring [3][16 KiB]; LDS address 0
+    // (no static __shared__ in this kernel: the LDS-DMA destinations are ABSOLUTE LDS addresses that assume smem starts at 0; the
+    // merge ticket lives in the 16 bytes behind the V ring)
     // ABL bit 7 (a layout, not an ablation): the K image in LDS is stored as 16 pieces of 4 rows, each piece 1088 bytes apart (64
     // bytes of padding), inside a piece chunk c of row r3 at byte 64*c + 16*r3.  ds_read_b128's lane groups ({0-3,12-15,20-27}, ...)
     // then hit 16 distinct 16-byte slots of the 256-byte bank row WITHOUT an XOR swizzle, so the address of fragment (kk, kb) is
@@ -594,13 +596,16 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         }
     }
     (void)sc_ln;
+    // single-launch merge of the key-range shares (attn_common.h)
+    if (nsplit > 1 && done != nullptr)
+        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, done + ((int64_t)b * p.h + h) * nqb + qb, (int*)(smem + VBASE + 3 * S::kTileBytes));
 }
 
 // host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
 constexpr int kSmem64 = 36864 + 3 * PfSmem<128>::kTileBytes;      // K ring (padded layout: 2 x 17 408, rounded up) + V ring
-template <typename T, int ABL, int NA, int RING> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+template <typename T, int ABL, int NA, int RING> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -613,38 +618,38 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64 + 16);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), kSmem64, st, *p, order, nqb, nsplit);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit, done);
 }
 
 // variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1-3, 10-12 = schedule variants; 4-9 = timing
 // ablations (wrong results)
-void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done) {
     static const int env_sel = [] { const char* e = getenv("VATTN_PREFILL64_BUILD"); return e ? atoi(e) & 15 : 0; }();   // measurement hook
     const int sel = ((p->variant >> 8) & 15) ? ((p->variant >> 8) & 15) : env_sel;
     // product build: padded K image (ABL bit 7; +0.6 % over the XOR-swizzled image, 28 fewer VALU instructions per tile)
     if (p->dtype == VATTN_DTYPE_BF16) {
-        if (sel == 1) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit);
-        else if (sel == 3) launch64_t<__bf16, 0, 24, 4>(p, st, nsplit);
-        else launch64_t<__bf16, 128, 24, 4>(p, st, nsplit);
+        if (sel == 1) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit, done);
+        else if (sel == 3) launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done);
+        else launch64_t<__bf16, 128, 24, 4>(p, st, nsplit, done);
         return;
     }
     switch (sel) {
-        case 1: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit); break;   // row sums by v_dot2c over the packed P (no gain: the
+        case 1: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done); break;   // row sums by v_dot2c over the packed P (no gain: the
                                                                                // dot instructions serialise with the MFMA pipe, profiles/r02_issue_probe.txt)
-        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit); break;        // = product
-        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit); break;  // = build 1
-        case 3: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit); break;          // XOR-swizzled K image (the round's first layout)
-        case 4: launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit); break;          // no LDS-DMA in the steady state
-        case 5: launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit); break;          // no fma / exp2 / row sums
-        case 6: launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit); break;          // no per-tile wait + barrier
-        case 7: launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit); break;         // no LDS fragment reads
-        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit); break;       // MFMAs + fragment reads + barrier
-        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit); break;   // MFMAs only
-        default: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit); break;
+        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done); break;        // = product
+        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done); break;  // = build 1
+        case 3: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done); break;          // XOR-swizzled K image (the round's first layout)
+        case 4: launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done); break;          // no LDS-DMA in the steady state
+        case 5: launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done); break;          // no fma / exp2 / row sums
+        case 6: launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done); break;          // no per-tile wait + barrier
+        case 7: launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit, done); break;         // no LDS fragment reads
+        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit, done); break;       // MFMAs + fragment reads + barrier
+        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit, done); break;   // MFMAs only
+        default: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done); break;
     }
 }
 

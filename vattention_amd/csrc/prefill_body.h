@@ -24,7 +24,8 @@ namespace vattn_k {
 // The work of ONE workgroup — query block qb of head h of batch entry b, key-range share `split` of nsplit — as a device function:
 // prefill_kernel below maps blockIdx to it; hybrid_kernel (hybrid_kernels.hip) calls it from a persistent loop.
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const int b, const int h, const int qb, const int split, const int nsplit, char* smem) {
+__device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const int b, const int h, const int qb, const int split, const int nsplit, char* smem,
+                                             int* merge_counter = nullptr, int* s_ticket = nullptr) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     using S = PfSmem<HD>;
@@ -383,14 +384,20 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
             }
         }
     }
+    // single-launch merge of the key-range shares (attn_common.h): the workgroup that completes the block's last share merges them
+    if (nsplit > 1 && merge_counter != nullptr)
+        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, merge_counter, s_ticket);
 }
 
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
+__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_ticket;
     int b, h, qb, split;
     if (!wg_to_work(p, order, nqb, nsplit, b, h, qb, split)) return;
-    prefill_body<T, HD, USE_TR, WAVES, QC, MSUM>(p, b, h, qb, split, nsplit, smem);
+    // done: one zeroed counter per (sequence, head, query block) = single-launch merge of the key-range shares; NULL = combine_rows_kernel
+    prefill_body<T, HD, USE_TR, WAVES, QC, MSUM>(p, b, h, qb, split, nsplit, smem,
+                                                 done ? done + ((int64_t)b * p.h + h) * nqb + qb : nullptr, &s_ticket);
 }
 
 }  // namespace vattn_k

@@ -455,6 +455,13 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     return pl;
 }
 
+// Counters of the single-launch merge of a KV-split prefill (one per (sequence, head, query block)), or NULL: two-launch form
+// (variant bit 14 forces it; also while the stream is being captured before a warm-up call created the buffer).
+static int* prefill_merge_counters(const vattn_attn_params* p, hipStream_t st, int nsplit, int nqb) {
+    if (nsplit <= 1 || (p->variant & 16384)) return nullptr;
+    return merge_counters(st, (size_t)p->b * p->h * nqb);
+}
+
 template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr, int nsplit) {
     constexpr int BM = 32 * QC * WAVES;
     const int nqb = (p->seqlen_q + BM - 1) / BM;
@@ -476,11 +483,12 @@ template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(
         return true;
     }();
     (void)attr_once;
+    int* done = prefill_merge_counters(p, st, nsplit, nqb);
     if (use_tr)
-        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit);
+        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done);
     else
-        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit);
-    if (nsplit > 1) {
+        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done);
+    if (nsplit > 1 && !done) {
         const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
         hipLaunchKernelGGL((combine_rows_kernel<T, HD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, nsplit, p->seqlen_q, rows);
     }
@@ -494,8 +502,9 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     bool launched = false;
     if constexpr (HD == 128) {
         if (pl.tiling == 7) {
-            launch_prefill64(p, st, pl.nsplit);
-            if (pl.nsplit > 1) {
+            int* done = prefill_merge_counters(p, st, pl.nsplit, (p->seqlen_q + 255) / 256);
+            launch_prefill64(p, st, pl.nsplit, done);
+            if (pl.nsplit > 1 && !done) {
                 const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
                 hipLaunchKernelGGL((combine_rows_kernel<T, 128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, pl.nsplit, p->seqlen_q, rows);
             }
