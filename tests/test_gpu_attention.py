@@ -75,7 +75,8 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
 def test_decode_single_launch_merge_and_head_block_groups(B, G, Hkv, D, lens, dtype):
     """Round 2 decode forms against the oracle: (a) the split-KV merge inside the decode launch (variant bit 9 forces it, bit 8
     forbids it, default = by grid size), incl. repeated calls on one stream (the group counters reset themselves); (b) two 16-head
-    blocks per workgroup for G > 16 (variant bit 7 = one block per workgroup, the round-1 form)."""
+    blocks per workgroup for G > 16 (variant bit 7 = one block per workgroup, the round-1 form).  The in-launch merge is opt-in
+    (measured slower: agent-scope fences flush the L2); default and bit 8 are the two-launch form."""
     from vattention_amd.flash_attn import flash_attn_with_kvcache
     torch.manual_seed(B * 131 + G)
     Hq, ctx, slots = G * Hkv, max(lens) + 40, B + 2
@@ -92,10 +93,10 @@ def test_decode_single_launch_merge_and_head_block_groups(B, G, Hkv, D, lens, dt
     kc2, vc2 = kc.clone(), vc.clone()
     ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :ml], vc2[:, :ml], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     outs = {}
-    for variant in (0, 256, 512, 128, 128 | 512):
+    for variant in (0, 256, 512, 1024, 128, 128 | 512, 128 | 1024):      # bit 9: merge ordered by fences, bit 10: device-scope accesses
         for splits in (0, 5):
             kg, vg = kc.to(DEV), vc.to(DEV)
-            for rep in range(3 if variant & 512 else 1):
+            for rep in range(3 if variant & (512 | 1024) else 1):
                 out = flash_attn_with_kvcache(q.to(DEV), kg[:, :ml], vg[:, :ml], kn.to(DEV), vn.to(DEV), cache_seqlens=cl.to(DEV),
                                               cache_batch_idx=idx.to(DEV), causal=True, num_splits=splits, _variant=variant)
                 torch.cuda.synchronize()
@@ -105,6 +106,7 @@ def test_decode_single_launch_merge_and_head_block_groups(B, G, Hkv, D, lens, dt
     # the merge arithmetic is the same in both forms: same values up to the order of one multiply-add
     for splits in (0, 5):
         assert (outs[(256, splits)] - outs[(512, splits)]).abs().max().item() <= (1e-3 if dtype == torch.float16 else 8e-3)
+        assert torch.equal(outs[(512, splits)], outs[(1024, splits)]), "the two in-launch merge protocols differ only in how the partials travel"
 
 
 @pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12, 14, 270, 526, 2574], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved", "w4q2_dma_pipelined", "w4q2_dma_dot2_rowsum", "w4q2_dma_kpad", "w4q2_dma_dot2_kpad"])
@@ -229,7 +231,7 @@ def test_prefill_kv_split(causal, variant):
     base = None
     for splits in (1, 2, 3, 5, 16):
         got = {}
-        for two_launch in (0, 16384):      # the shares merged inside the launch (default), and by combine_rows_kernel in a second launch
+        for two_launch in (16384, 32768, 0):      # merged inside the launch (opt-in: fence protocol, device-scope protocol), and by combine_rows_kernel (default)
             for rep in range(2):           # twice on one stream: the merge counters reset themselves
                 out, lse = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
                                                    causal=causal, num_splits=splits, return_softmax_lse=True, _variant=variant | two_launch)
@@ -237,7 +239,7 @@ def test_prefill_kv_split(causal, variant):
                 _check(out, ref64, ref32, torch.float16, "kv-split prefill splits=%d two_launch=%d" % (splits, two_launch))
                 assert torch.allclose(lse.double().cpu(), lse64.double(), atol=2e-3, rtol=1e-3), "lse splits=%d" % splits
             got[two_launch] = out.float().cpu()
-        assert torch.equal(got[0], got[16384]), "the two merge forms run the same arithmetic on the same partials"
+        assert torch.equal(got[0], got[16384]) and torch.equal(got[0], got[32768]), "the merge forms run the same arithmetic on the same partials"
         if base is None:
             base = out.float().cpu()
         else:      # splitting only regroups the fp32 accumulation

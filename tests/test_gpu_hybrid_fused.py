@@ -59,7 +59,7 @@ def test_fused_hybrid_launch_matches_the_oracle(Hq, Hkv, chunks, dec_lens, dtype
     ref64, kc_ref, vc_ref = _oracle(c, chunks, dec_lens, dtype, {})
     ref32, _, _ = _oracle(c, chunks, dec_lens, dtype, {"math": "f32"})
     P, Bd, T, D = c["P"], c["Bd"], c["T"], c["D"]
-    for role_mode, rounds in ((0, 3), (1, 1), (2, 1)):
+    for role_mode, rounds, dvar in ((0, 3, 0), (1, 1, 0), (2, 1, 0), (0, 3, 1024)):      # dvar 1024: split merge through device-scope accesses
         kg, vg = c["kc"].to(DEV), c["vc"].to(DEV)
         q = c["q"].to(DEV)
         for _ in range(rounds):           # the same launch again: idempotent (the append rewrites the same rows), control words self-reset
@@ -78,7 +78,7 @@ def test_fused_hybrid_launch_matches_the_oracle(Hq, Hkv, chunks, dec_lens, dtype
             ml = max(dec_lens) + 1
             dec = lambda: flash_attn_with_kvcache(q[T:].unsqueeze(1), kg[:, :ml], vg[:, :ml], c["kn"].to(DEV), c["vn"].to(DEV),
                                                   cache_seqlens=torch.tensor(dec_lens, dtype=torch.int32, device=DEV),
-                                                  cache_batch_idx=c["d_slots"].to(DEV), causal=True, out=out[T:].unsqueeze(1))
+                                                  cache_batch_idx=c["d_slots"].to(DEV), causal=True, out=out[T:].unsqueeze(1), _variant=dvar)
             hybrid_attn(pre, dec, torch.device(DEV), _role_mode=role_mode)
             torch.cuda.synchronize()
             assert not torch.isnan(out.float()).any(), "rows left unwritten (role mode %d)" % role_mode

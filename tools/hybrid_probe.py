@@ -94,10 +94,13 @@ def main():
             return f
 
         t_f0, t_f1, t_f2 = timeit(fused(0)), timeit(fused(1)), timeit(fused(2))
+        pd.variant |= 1024                    # split merge through device-scope accesses instead of fences
+        t_f3 = timeit(fused(0))
+        pd.variant &= ~1024
         pu.variant &= ~(3 << 12)
         print("  prefill %.3f ms (single pass %.3f)  decode %.3f ms | serial, default plan %.3f ms | two streams: single-pass prefill %.3f ms, "
-              "default-plan prefill %.3f ms | FUSED launch %.3f ms (prefill-first roles %.3f, decode-first roles %.3f) | streams/serial %.2fx  fused/serial %.2fx"
-              % (t_pa, t_pu, t_d, t_ser, t_par_u, t_par_a, t_f0, t_f1, t_f2, t_ser / min(t_par_u, t_par_a, t_ser), t_ser / t_f0))
+              "default-plan prefill %.3f ms | FUSED launch %.3f ms (prefill-first roles %.3f, decode-first roles %.3f; fence-free merge %.3f) | streams/serial %.2fx  fused/serial %.2fx"
+              % (t_pa, t_pu, t_d, t_ser, t_par_u, t_par_a, t_f0, t_f1, t_f2, t_f3, t_ser / min(t_par_u, t_par_a, t_ser), t_ser / min(t_f0, t_f3)))
         del keepa, keepu
         del keepd, kd, vd
 

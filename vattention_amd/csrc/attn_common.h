@@ -156,32 +156,42 @@ __device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order
 }
 
 
+// ---- device-scope (cache-bypassing) accesses for data handed from one workgroup to another inside a launch ----
+// Relaxed atomics at agent scope compile to global_store/load ... sc1: the store is written through to the device's coherence
+// point and the load does not hit a stale line of this XCD's L2 — no fence (= no L2 write-back + invalidate) needed around them.
+__device__ __forceinline__ void store_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- single-launch merge of KV-split prefill partials (round 2) ----
 // Called by every workgroup of a KV-split prefill launch after it has written its partial (normalised fp32 rows + log2-domain LSE,
 // layout of combine_rows_kernel): release (barrier, then ONE wave's agent-scope fence), ticket from the query block's counter, and
 // the holder of the last ticket merges the nsplit partials of the block's rows [q0, q_end) of head h — the arithmetic of
 // combine_rows_kernel (one wave per row, lanes over column pairs), without the second launch and with the partials still in L2 /
 // MALL.  `counter` is zero between launches (the merger resets it).
+// mode 1: partials written with ordinary stores, ordered by agent-scope fences (each writes back and invalidates the XCD's L2);
+// mode 2: partials written and read with device-scope accesses (store_dev / load_dev), ordered by the barrier's vmcnt(0) alone.
 template <typename T, int HD>
 __device__ __forceinline__ void prefill_release_and_merge(const vattn_attn_params& p, const int nsplit, const int b, const int h, const int q0,
-                                                          const int q_end, const int64_t q_first, int* counter, int* s_ticket) {
+                                                          const int q_end, const int64_t q_first, int* counter, int* s_ticket, const int mode) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    __syncthreads();
+    __syncthreads();                                   // every wave's partial stores have completed (s_waitcnt vmcnt(0) + barrier)
     if (tid < 64) {
-        __threadfence();
+        if (mode == 1) __threadfence();
         if (tid == 0) *s_ticket = atomicAdd(counter, 1);
     }
     __syncthreads();
     if (*s_ticket != nsplit - 1) return;
-    if (tid < 64) __threadfence();
+    if (mode == 1 && tid < 64) __threadfence();
     __syncthreads();
+    const bool dev = mode == 2;
     const int sq = p.seqlen_q;
     const float* oacc = (const float*)p.workspace;
     const int64_t sstride = (int64_t)p.b * sq * p.h;
     const float* lacc = oacc + (int64_t)nsplit * sstride * HD;
     for (int q = q0 + wave; q < q_end; q += nwaves) {
         const int64_t row = ((int64_t)b * sq + q) * p.h + h;
-        const float my = (lane < nsplit) ? lacc[(int64_t)lane * sstride + row] : -INFINITY;
+        float my = -INFINITY;
+        if (lane < nsplit) my = dev ? load_dev(lacc + (int64_t)lane * sstride + row) : lacc[(int64_t)lane * sstride + row];
         float mx = my;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));      // splits <= 16 live in lanes 0..15
@@ -198,7 +208,10 @@ __device__ __forceinline__ void prefill_release_and_merge(const vattn_attn_param
             float a0 = 0.f, a1 = 0.f;
             for (int s = 0; s < nsplit; s++) {
                 const float ws = __shfl(w, s, 64);
-                const float2 v = *(const float2*)(src + (int64_t)s * sstride * HD);
+                const float* sp = src + (int64_t)s * sstride * HD;
+                float2 v;
+                if (dev) { v.x = load_dev(sp); v.y = load_dev(sp + 1); }
+                else v = *(const float2*)sp;
                 a0 += ws * v.x;
                 a1 += ws * v.y;
             }
@@ -217,7 +230,7 @@ int fail(int code, const char* msg);                                    // attn_
 void launch_append(const vattn_attn_params* p, hipStream_t st);         // cache_kernels.hip
 int launch_prefill_form(const vattn_attn_params* p, hipStream_t st);    // prefill_kernels.hip (seqlen_q > 1)
 size_t prefill_workspace_bytes(const vattn_attn_params* p);
-void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done);   // prefill64_kernels.hip (d = 128); done: counters of the single-launch merge or NULL
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode);   // prefill64_kernels.hip (d = 128); done: counters of the single-launch merge or NULL
 int* merge_counters(hipStream_t st, size_t n_ints);                      // attn_api.hip: zeroed per-(device, stream) counters, NULL while capturing
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
 size_t decode_workspace_bytes(const vattn_attn_params* p);

@@ -16,7 +16,7 @@ constexpr int DC_BN = 32;     // keys per wave tile
 // keeps the kernel inside the 168-register budget of three workgroups per CU; wider groups run as ceil(G/32) such workgroups.
 template <typename T, int HD, bool USE_TR, int NB = 1>
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
-                                            const int split, const int hk, const int gb, const int b, char* smem) {
+                                            const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
@@ -286,8 +286,14 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
                 float* oacc = (float*)p.workspace;
                 float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
                 const int64_t row_idx = ((int64_t)split * p.b + b) * p.h + hh;
-                oacc[row_idx * HD + d] = acc * inv;
-                if (d == 0) lacc[row_idx] = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
+                const float lv = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
+                if (merge_mode == 2) {      // handed to the merging workgroup inside this launch: device-scope stores (attn_common.h)
+                    store_dev(oacc + row_idx * HD + d, acc * inv);
+                    if (d == 0) store_dev(lacc + row_idx, lv);
+                } else {
+                    oacc[row_idx * HD + d] = acc * inv;
+                    if (d == 0) lacc[row_idx] = lv;
+                }
             }
         }
     }
@@ -297,7 +303,8 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
 // threads per head, 8 output columns each) — the in-launch form of combine_kernel, used by the fused hybrid launch and by
 // decode_kernel's single-launch merge (the workgroup that completes a group's last split calls it).
 template <typename T, int HD, int NB>
-__device__ __forceinline__ void decode_group_combine(const vattn_attn_params& p, const int num_splits, const int hk, const int gb, const int b) {
+__device__ __forceinline__ void decode_group_combine(const vattn_attn_params& p, const int num_splits, const int hk, const int gb, const int b,
+                                                     const bool dev = false) {
     const int tid = threadIdx.x;
     const int G = p.h / p.h_k;
     constexpr int CPT = HD / 16;                        // columns per thread
@@ -312,19 +319,25 @@ __device__ __forceinline__ void decode_group_combine(const vattn_attn_params& p,
         const int d0 = (tid & 15) * CPT;
         const int64_t row = (int64_t)b * p.h + hh;
         float mx = -INFINITY;
-        for (int s = 0; s < num_splits; s++) mx = fmaxf(mx, lacc[(int64_t)s * sstride + row]);
+        for (int s = 0; s < num_splits; s++) mx = fmaxf(mx, dev ? load_dev(lacc + (int64_t)s * sstride + row) : lacc[(int64_t)s * sstride + row]);
         const float mxs = (mx == -INFINITY) ? 0.f : mx;
         float acc[CPT];
 #pragma unroll
         for (int e = 0; e < CPT; e++) acc[e] = 0.f;
         float wsum = 0.f;
         for (int s = 0; s < num_splits; s++) {
-            const float w = fast_exp2(lacc[(int64_t)s * sstride + row] - mxs);
+            const float w = fast_exp2((dev ? load_dev(lacc + (int64_t)s * sstride + row) : lacc[(int64_t)s * sstride + row]) - mxs);
             const float* src = oacc + ((int64_t)s * sstride + row) * HD + d0;
             wsum += w;
 #pragma unroll
             for (int e = 0; e < CPT; e += 4) {
-                const f32x4 a = *(const f32x4*)(src + e);
+                f32x4 a;
+                if (dev) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a[u] = load_dev(src + e + u);
+                } else {
+                    a = *(const f32x4*)(src + e);
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) acc[e + u] += w * a[u];
             }
@@ -343,18 +356,20 @@ __device__ __forceinline__ void decode_group_combine(const vattn_attn_params& p,
 // ticket acquires and merges.  `done` counters are zero between launches (the merger resets its group's).
 template <typename T, int HD, int NB>
 __device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params& p, const int num_splits, const int hk, const int gb, const int b,
-                                                         int* done_counter, int* s_ticket) {
+                                                         int* done_counter, int* s_ticket, const int mode = 1) {
+    // mode 1: ordinary partial stores ordered by agent-scope fences; mode 2: device-scope stores / loads, ordered by the barrier's
+    // s_waitcnt vmcnt(0) alone (attn_common.h, prefill_release_and_merge)
     const int tid = threadIdx.x;
     __syncthreads();
     if (tid < 64) {
-        __threadfence();
+        if (mode == 1) __threadfence();
         if (tid == 0) *s_ticket = atomicAdd(done_counter, 1);
     }
     __syncthreads();
     if (*s_ticket == num_splits - 1) {
-        if (tid < 64) __threadfence();
+        if (mode == 1 && tid < 64) __threadfence();
         __syncthreads();
-        decode_group_combine<T, HD, NB>(p, num_splits, hk, gb, b);
+        decode_group_combine<T, HD, NB>(p, num_splits, hk, gb, b, mode == 2);
         if (tid == 0) *done_counter = 0;
     }
 }
@@ -362,7 +377,7 @@ __device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params
 // gblocks = head-block GROUPS per kv head (ceil(ceil(G/16) / NB)).  `done`: NULL = partials are merged by combine_kernel in a second
 // launch; else one zero-initialised int per (sequence, kv head, group): single-launch merge.
 template <typename T, int HD, bool USE_TR, int NB>
-__global__ __launch_bounds__(64 * DC_WAVES, (HD > 128 || (HD == 128 && NB > 1)) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done) {
+__global__ __launch_bounds__(64 * DC_WAVES, (HD > 128 || (HD == 128 && NB > 1)) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done, int merge_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;
     int split, hk, gb, b;
@@ -385,9 +400,9 @@ __global__ __launch_bounds__(64 * DC_WAVES, (HD > 128 || (HD == 128 && NB > 1)) 
         gb = blockIdx.y % gblocks;
         b = blockIdx.z;
     }
-    decode_body<T, HD, USE_TR, NB>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem);
+    decode_body<T, HD, USE_TR, NB>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0);
     if (done != nullptr && num_splits > 1)
-        decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket);
+        decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket, merge_mode);
 }
 
 }  // namespace vattn_k

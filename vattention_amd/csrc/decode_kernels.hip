@@ -93,15 +93,15 @@ static inline int decode_groups(const vattn_attn_params* p) {
     const int nb = decode_nb(p);
     return (blocks + nb - 1) / nb;
 }
-// Single-launch merge (the last workgroup of a group merges its partials) instead of a second launch of combine_kernel: taken when
-// the whole grid is resident at once (<= 768 workgroups) — there the second launch is a visible share of the call (B1 @ 32 k: 24 us
-// of which ~7 us are the combine launch); variant bit 8: never, bit 9: always (A/B).  The group counters live in a small library-owned
-// device buffer per (device, stream), zeroed when it is created; the kernel leaves them zero.
+// Single-launch merge (the last workgroup of a group merges its partials) instead of a second launch of combine_kernel.  MEASURED
+// SLOWER on MI355X and therefore opt-in only (variant bit 9): the release / acquire it needs are agent-scope fences, and on this
+// multi-XCD part each one writes back and invalidates the XCD's L2 — B1 @ 32 k 23.7 -> 41.5 us, B16 @ 32 k 203 -> 243 us
+// (profiles/r02_kbench_decode_merge.txt).  The group counters live in a small library-owned device buffer per (device, stream),
+// zeroed when it is created; the kernel leaves them zero.
 static inline long decode_slots(const vattn_attn_params* p) { return (p->d == 128 && decode_nb(p) == 2) ? 512 : 768; }   // resident workgroups
 static inline bool decode_inline_merge(const vattn_attn_params* p, int splits, int groups) {
-    if (splits <= 1 || (p->variant & 256)) return false;
-    if (p->variant & 512) return true;
-    return (long)splits * p->h_k * groups * p->b <= decode_slots(p);
+    (void)groups;
+    return splits > 1 && (p->variant & (512 | 1024)) != 0;      // bit 9: fence protocol, bit 10: device-scope accesses, no fence
 }
 template <typename T, int HD, int NB> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
     const bool use_tr = (p->variant & 1) == 0;
@@ -119,10 +119,11 @@ template <typename T, int HD, int NB> int launch_decode_nb(const vattn_attn_para
     const vattn_attn_params& q = *p;
     int* done = decode_inline_merge(p, splits, groups) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
     const bool inline_merge = done != nullptr;
+    const int mm = !inline_merge ? 0 : (p->variant & 1024) ? 2 : 1;
     if (use_tr)
-        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, splits, groups, fused_append, done);
+        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
     else
-        hipLaunchKernelGGL((decode_kernel<T, HD, false, NB>), grid, block, smem, st, q, splits, groups, fused_append, done);
+        hipLaunchKernelGGL((decode_kernel<T, HD, false, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
     if (splits > 1 && !inline_merge) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, splits, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));

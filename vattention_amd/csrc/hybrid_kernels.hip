@@ -26,7 +26,7 @@ constexpr int HY_CTL_INTS = 4 + HY_CU_SLOTS;         // next[2], exited, pad, ar
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void hybrid_kernel(vattn_attn_params pp, vattn_attn_params pd, int* ctl, int n_pre, int n_dec, int nqb,
-                                                        int dsplits, int gblocks, int fused_append, int role_mode) {
+                                                        int dsplits, int gblocks, int fused_append, int role_mode, int merge_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_it[2];
     const int tid = threadIdx.x;
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256, 2) void hybrid_kernel(vattn_attn_params pp, va
             const int gb = t % gblocks;
             t /= gblocks;
             const int hk = t % pd.h_k, b = t / pd.h_k;
-            decode_body<T, 128, true, 1>(pd, dsplits, gblocks, fused_append, split, hk, gb, b, smem);
+            decode_body<T, 128, true, 1>(pd, dsplits, gblocks, fused_append, split, hk, gb, b, smem, merge_mode);
             // release the partial, take the group's ticket, the last one merges (decode_body.h: one agent-scope fence per WORKGROUP —
             // a fence per wave costs 4x that on this multi-XCD part)
-            if (dsplits > 1) decode_release_and_merge<T, 128, 1>(pd, dsplits, hk, gb, b, &done[(b * pd.h_k + hk) * gblocks + gb], &s_it[0]);
+            if (dsplits > 1) decode_release_and_merge<T, 128, 1>(pd, dsplits, hk, gb, b, &done[(b * pd.h_k + hk) * gblocks + gb], &s_it[0], merge_mode);
         }
     }
     // leave the control words zero for the next launch
@@ -131,7 +131,7 @@ template <typename T> static int launch_hybrid_t(const vattn_attn_params* pp, co
     const int fused_append = (pd->k_new && pd->seqlen_knew == 1) ? 1 : 0;
     const int role_mode = (pp->variant >> 12) & 3;
     hipLaunchKernelGGL((hybrid_kernel<T>), dim3(2 * cus), dim3(256), smem, st, *pp, d2, (int*)ws, (int)n_pre, (int)n_dec, nqb, ds, gblocks,
-                       fused_append, role_mode);
+                       fused_append, role_mode, (pd->variant & 1024) ? 2 : 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;

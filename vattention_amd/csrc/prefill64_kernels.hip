@@ -118,7 +118,7 @@ __device__ __forceinline__ float add1(float a, float b) {
 // NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
 // (RING - 1 fragments ahead of their MFMA).
 template <typename T, int ABL, int NA, int RING>
-__global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done) {
+__global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done, int merge_mode) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int HD = 128;
@@ -553,9 +553,18 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                     f32x4 w;
 #pragma unroll
                     for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
-                    *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    if (merge_mode == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) store_dev(opart + 32 * db + 8 * tq + 4 * g + e, w[e]);
+                    } else {
+                        *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    }
                 }
-            if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_log2 + __log2f(l_tot));
+            if (g == 0) {
+                const float lv = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_log2 + __log2f(l_tot));
+                if (merge_mode == 2) store_dev(lpart + row, lv);
+                else lpart[row] = lv;
+            }
         } else if (my_q < Sq) {
             T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + my_q) * p.o_row_stride + (int64_t)h * p.o_head_stride;
             if (((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0) {
@@ -598,14 +607,14 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     (void)sc_ln;
     // single-launch merge of the key-range shares (attn_common.h)
     if (nsplit > 1 && done != nullptr)
-        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, done + ((int64_t)b * p.h + h) * nqb + qb, (int*)(smem + VBASE + 3 * S::kTileBytes));
+        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, done + ((int64_t)b * p.h + h) * nqb + qb, (int*)(smem + VBASE + 3 * S::kTileBytes), merge_mode);
 }
 
 // host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
 constexpr int kSmem64 = 36864 + 3 * PfSmem<128>::kTileBytes;      // K ring (padded layout: 2 x 17 408, rounded up) + V ring
-template <typename T, int ABL, int NA, int RING> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done) {
+template <typename T, int ABL, int NA, int RING> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -622,34 +631,34 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit, done);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit, done, merge_mode);
 }
 
 // variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1-3, 10-12 = schedule variants; 4-9 = timing
 // ablations (wrong results)
-void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done) {
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
     static const int env_sel = [] { const char* e = getenv("VATTN_PREFILL64_BUILD"); return e ? atoi(e) & 15 : 0; }();   // measurement hook
     const int sel = ((p->variant >> 8) & 15) ? ((p->variant >> 8) & 15) : env_sel;
     // product build: padded K image (ABL bit 7; +0.6 % over the XOR-swizzled image, 28 fewer VALU instructions per tile)
     if (p->dtype == VATTN_DTYPE_BF16) {
-        if (sel == 1) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit, done);
-        else if (sel == 3) launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done);
-        else launch64_t<__bf16, 128, 24, 4>(p, st, nsplit, done);
+        if (sel == 1) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode);
+        else if (sel == 3) launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done, merge_mode);
+        else launch64_t<__bf16, 128, 24, 4>(p, st, nsplit, done, merge_mode);
         return;
     }
     switch (sel) {
-        case 1: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done); break;   // row sums by v_dot2c over the packed P (no gain: the
+        case 1: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;   // row sums by v_dot2c over the packed P (no gain: the
                                                                                // dot instructions serialise with the MFMA pipe, profiles/r02_issue_probe.txt)
-        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done); break;        // = product
-        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done); break;  // = build 1
-        case 3: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done); break;          // XOR-swizzled K image (the round's first layout)
-        case 4: launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done); break;          // no LDS-DMA in the steady state
-        case 5: launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done); break;          // no fma / exp2 / row sums
-        case 6: launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done); break;          // no per-tile wait + barrier
-        case 7: launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit, done); break;         // no LDS fragment reads
-        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit, done); break;       // MFMAs + fragment reads + barrier
-        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit, done); break;   // MFMAs only
-        default: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done); break;
+        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode); break;        // = product
+        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;  // = build 1
+        case 3: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done, merge_mode); break;          // XOR-swizzled K image (the round's first layout)
+        case 4: launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;          // no LDS-DMA in the steady state
+        case 5: launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;          // no fma / exp2 / row sums
+        case 6: launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;          // no per-tile wait + barrier
+        case 7: launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;         // no LDS fragment reads
+        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;       // MFMAs + fragment reads + barrier
+        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;   // MFMAs only
+        default: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode); break;
     }
 }
 

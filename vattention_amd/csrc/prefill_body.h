@@ -25,7 +25,7 @@ namespace vattn_k {
 // prefill_kernel below maps blockIdx to it; hybrid_kernel (hybrid_kernels.hip) calls it from a persistent loop.
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
 __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const int b, const int h, const int qb, const int split, const int nsplit, char* smem,
-                                             int* merge_counter = nullptr, int* s_ticket = nullptr) {
+                                             int* merge_counter = nullptr, int* s_ticket = nullptr, const int merge_mode = 0) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     using S = PfSmem<HD>;
@@ -340,9 +340,18 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
                     f32x4 w;
 #pragma unroll
                     for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
-                    *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    if (merge_mode == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) store_dev(opart + 32 * db + 8 * tq + 4 * g + e, w[e]);
+                    } else {
+                        *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    }
                 }
-            if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_run[qc] * sc + __log2f(l_tot));
+            if (g == 0) {
+                const float lv = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_run[qc] * sc + __log2f(l_tot));
+                if (merge_mode == 2) store_dev(lpart + row, lv);
+                else lpart[row] = lv;
+            }
         } else if (my_q < Sq) {
             T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + my_q) * p.o_row_stride + (int64_t)h * p.o_head_stride;
             if ((((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0) && !ABL(7)) {
@@ -386,18 +395,18 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
     }
     // single-launch merge of the key-range shares (attn_common.h): the workgroup that completes the block's last share merges them
     if (nsplit > 1 && merge_counter != nullptr)
-        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, merge_counter, s_ticket);
+        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, merge_counter, s_ticket, merge_mode);
 }
 
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done) {
+__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done, int merge_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;
     int b, h, qb, split;
     if (!wg_to_work(p, order, nqb, nsplit, b, h, qb, split)) return;
     // done: one zeroed counter per (sequence, head, query block) = single-launch merge of the key-range shares; NULL = combine_rows_kernel
     prefill_body<T, HD, USE_TR, WAVES, QC, MSUM>(p, b, h, qb, split, nsplit, smem,
-                                                 done ? done + ((int64_t)b * p.h + h) * nqb + qb : nullptr, &s_ticket);
+                                                 done ? done + ((int64_t)b * p.h + h) * nqb + qb : nullptr, &s_ticket, merge_mode);
 }
 
 }  // namespace vattn_k

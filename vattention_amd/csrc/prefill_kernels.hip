@@ -456,9 +456,15 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
 }
 
 // Counters of the single-launch merge of a KV-split prefill (one per (sequence, head, query block)), or NULL: two-launch form
-// (variant bit 14 forces it; also while the stream is being captured before a warm-up call created the buffer).
+// (combine_rows_kernel).  Opt-in only.  Variant bit 14 = mode 1, ordered by agent-scope fences: they flush the XCD's L2, which the
+// query blocks' K/V prefix re-reads live on — TP8 8 k prompt 0.201 -> 0.274 ms, 512-token chunk @ 16 k 0.073 -> 0.151 ms
+// (profiles/r02_kbench_prefill_merge.txt).  Variant bit 15 = mode 2: partials through device-scope stores / loads, no fence.
+static inline int prefill_merge_mode(const vattn_attn_params* p, int nsplit) {
+    if (nsplit <= 1) return 0;
+    return (p->variant & 32768) ? 2 : (p->variant & 16384) ? 1 : 0;
+}
 static int* prefill_merge_counters(const vattn_attn_params* p, hipStream_t st, int nsplit, int nqb) {
-    if (nsplit <= 1 || (p->variant & 16384)) return nullptr;
+    if (!prefill_merge_mode(p, nsplit)) return nullptr;
     return merge_counters(st, (size_t)p->b * p->h * nqb);
 }
 
@@ -484,10 +490,11 @@ template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(
     }();
     (void)attr_once;
     int* done = prefill_merge_counters(p, st, nsplit, nqb);
+    const int mm = done ? prefill_merge_mode(p, nsplit) : 0;
     if (use_tr)
-        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done);
+        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
     else
-        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done);
+        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
     if (nsplit > 1 && !done) {
         const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
         hipLaunchKernelGGL((combine_rows_kernel<T, HD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, nsplit, p->seqlen_q, rows);
@@ -503,7 +510,7 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     if constexpr (HD == 128) {
         if (pl.tiling == 7) {
             int* done = prefill_merge_counters(p, st, pl.nsplit, (p->seqlen_q + 255) / 256);
-            launch_prefill64(p, st, pl.nsplit, done);
+            launch_prefill64(p, st, pl.nsplit, done, done ? prefill_merge_mode(p, pl.nsplit) : 0);
             if (pl.nsplit > 1 && !done) {
                 const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
                 hipLaunchKernelGGL((combine_rows_kernel<T, 128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, pl.nsplit, p->seqlen_q, rows);
