@@ -348,7 +348,8 @@ def main():
                        "handles_created": out.get("handles_created"), "create_ms": out.get("create_ms"),
                        "sync_map_ms": round(out["sync_map_ms"], 1), "mapper_thread_map_ms": round(out["async_map_ms"], 1),
                        "sync_share_of_map_time": round(out["sync_map_ms"] / tot, 4) if tot else None,
-                       "sync_map_share_of_wall": round(out["sync_map_ms"] / 1e3 / out["seconds"], 4)}
+                       "sync_map_share_of_wall": round(out["sync_map_ms"] / 1e3 / out["seconds"], 4),
+                       "sync_breakdown": out.get("sync_breakdown")}
         finally:
             r2.close()
 

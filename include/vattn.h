@@ -117,6 +117,11 @@ typedef struct vattn_stats {
     uint64_t fence_waits, fence_wait_ns;  /* per-slot fences waited on instead of a device-wide quiesce */
     uint64_t layered_batches, layer_wait_ns;   /* VATTN_FLAG_LAYERED_ASYNC: batches split by layer; time vattn_wait_layer blocked */
     uint64_t rollbacks;                   /* batches whose unexecuted maps were rolled back after a driver failure */
+    /* what the synchronous batches' time (sync_ns) was spent on besides map / set-access / unmap calls */
+    uint64_t sync_create_ns, sync_creates;    /* handles that had to be created on the critical path */
+    uint64_t sync_fence_ns;                   /* waiting for slot fences / device quiesce before an unmap */
+    uint64_t sync_tlb_ns;                     /* TLB invalidation after unmaps */
+    uint64_t sync_maps, sync_unmaps;          /* driver calls executed on the critical path */
 } vattn_stats;
 
 typedef struct vattn_handle vattn_t;

@@ -28,7 +28,8 @@ class VattnStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("handles_created", "handles_released", "map_calls", "access_calls",
                                            "unmap_calls", "sync_batches", "async_batches", "sync_ns", "async_ns",
                                            "join_wait_ns", "create_ns", "pages_mapped_now", "tlb_flushes", "tlb_flush_ns", "quiesce_calls", "quiesce_ns",
-                                           "fence_waits", "fence_wait_ns", "layered_batches", "layer_wait_ns", "rollbacks")]
+                                           "fence_waits", "fence_wait_ns", "layered_batches", "layer_wait_ns", "rollbacks",
+                                           "sync_create_ns", "sync_creates", "sync_fence_ns", "sync_tlb_ns", "sync_maps", "sync_unmaps")]
 
 
 VATTN_OK, VATTN_ERR_INVALID, VATTN_ERR_OOM, VATTN_ERR_DRIVER, VATTN_ERR_POOL_EMPTY = 0, -1, -2, -3, -4

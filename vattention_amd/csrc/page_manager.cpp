@@ -760,6 +760,8 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async, size_t* 
     bool map_failed = false;    // a create / map failed: the remaining maps are skipped (and rolled back by the caller),
                                 // the remaining unmaps — whose bookkeeping is already applied — still run
     bool unmapped = false, quiesced = false;
+    const uint64_t c0_ns = st_.create_ns, c0_n = st_.handles_created, f0_ns = st_.fence_wait_ns + st_.quiesce_ns, m0 = st_.map_calls, u0 = st_.unmap_calls;
+    uint64_t tlb_ns = 0;
     std::vector<uint8_t> fenced;    // slots whose fence this batch has already waited on
     for (size_t i = 0; i < ops.size(); i++) {
         const PhysOp& op = ops[i];
@@ -825,7 +827,8 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async, size_t* 
             fatal_ = VATTN_ERR_DRIVER;
         }
         st_.tlb_flushes++;
-        st_.tlb_flush_ns += now_ns() - f0;
+        tlb_ns = now_ns() - f0;
+        st_.tlb_flush_ns += tlb_ns;
     }
     if (layered) {
         if (rc) layered_error_.store(rc);
@@ -837,7 +840,16 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async, size_t* 
         layer_cv_.notify_all();
     }
     const uint64_t dt = now_ns() - t0;
-    if (is_async) { st_.async_batches++; st_.async_ns += dt; } else { st_.sync_batches++; st_.sync_ns += dt; }
+    if (is_async) { st_.async_batches++; st_.async_ns += dt; } else {
+        st_.sync_batches++;
+        st_.sync_ns += dt;
+        st_.sync_create_ns += st_.create_ns - c0_ns;
+        st_.sync_creates += st_.handles_created - c0_n;
+        st_.sync_fence_ns += st_.fence_wait_ns + st_.quiesce_ns - f0_ns;
+        st_.sync_tlb_ns += tlb_ns;
+        st_.sync_maps += st_.map_calls - m0;
+        st_.sync_unmaps += st_.unmap_calls - u0;
+    }
     return rc;
 }
 

@@ -3,10 +3,11 @@
 //     (one wave per SIMD, 512 registers): each K fragment and each V^T fragment read from LDS feeds TWO MFMAs, halving the
 //     LDS fragment traffic per flop of the 8 x 32-row kernel (prefill_kernels.hip);
 //   * K / V tiles (64 keys) travel HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, one 1-KiB piece per wave
-//     instruction), no staging registers: the K image is row-major with the 16-byte chunk index XOR-swizzled by the row (the
-//     swizzle is applied on the GLOBAL side: lane i fetches the chunk that belongs at its LDS position), the V image is
-//     [d/32][key][32 d] sub-tiles for `ds_read_b64_tr_b16`; a 2-deep ring per tensor (K one tile ahead of V), one barrier
-//     per tile, counted `vmcnt` (the DMA is issued by inline asm, the compiler's wait-count pass never sees it);
+//     instruction), no staging registers: the LDS image of a tile is shaped on the GLOBAL side (lane i fetches the 16 bytes that
+//     belong at LDS position M0 + 16*i) — K as 16 padded 4-row pieces whose fragment addresses are lane + immediate (product;
+//     the first version's row-major image with the chunk index XOR-swizzled by the row is build 3), V as [d/32][key][32 d]
+//     sub-tiles for `ds_read_b64_tr_b16`; a K ring of 2 and a V ring of 3 slots (K runs one tile ahead of V), one barrier per
+//     tile, counted `vmcnt` (the DMA is issued by inline asm, the compiler's wait-count pass never sees it);
 //   * software pipeline inside the wave: phase A  S(t+1) = K(t+1).Q^T  ||  P(t) = exp2(S(t)), row sums;
 //                                        phase B  O += V(t)^T.P(t)^T   ||  row max of S(t+1), f16 packing of P(t);
 //     so the softmax VALU work of a tile is issued between the MFMAs of its neighbours by the same wave;
@@ -112,9 +113,10 @@ __device__ __forceinline__ float add1(float a, float b) {
 // second copy of the tile's 64 scores does not fit the architectural half of the register file)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// ABL (timing ablations for tools/kbench.py, results are WRONG when non-zero; the product instantiates 0): bit 0 no LDS-DMA in the
-// steady state, bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the
-// first MFMAs of a phase, bit 5 no f16 packing.
+// ABL bits 0-5: timing ablations for tools/kbench.py (results are WRONG when any is set): bit 0 no LDS-DMA in the steady state,
+// bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the first MFMAs of
+// a phase, bit 5 no f16 packing.  Bits 6-7 select correct alternatives: bit 6 row sums by v_dot2c over the packed P, bit 7 the
+// padded K image (the product instantiates ABL = 128).
 // NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
 // (RING - 1 fragments ahead of their MFMA).
 template <typename T, int ABL, int NA, int RING>

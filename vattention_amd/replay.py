@@ -337,6 +337,11 @@ class HotPathRunner:
             "tlb_flushes": vm1["tlb_flushes"] - vm0["tlb_flushes"], "tlb_flush_ms": (vm1["tlb_flush_ns"] - vm0["tlb_flush_ns"]) / 1e6,
             "handles_created": vm1["handles_created"] - vm0["handles_created"], "create_ms": round((vm1["create_ns"] - vm0["create_ns"]) / 1e6, 1),
             "fence_waits": vm1["fence_waits"] - vm0["fence_waits"], "quiesce_calls": vm1["quiesce_calls"] - vm0["quiesce_calls"],
+            "sync_breakdown": {"batches": vm1["sync_batches"] - vm0["sync_batches"], "maps": vm1["sync_maps"] - vm0["sync_maps"],
+                               "unmaps": vm1["sync_unmaps"] - vm0["sync_unmaps"], "creates": vm1["sync_creates"] - vm0["sync_creates"],
+                               "create_ms": round((vm1["sync_create_ns"] - vm0["sync_create_ns"]) / 1e6, 1),
+                               "fence_ms": round((vm1["sync_fence_ns"] - vm0["sync_fence_ns"]) / 1e6, 1),
+                               "tlb_ms": round((vm1["sync_tlb_ns"] - vm0["sync_tlb_ns"]) / 1e6, 1)},
         })
         out.pop("util_at_peak")
         return out
