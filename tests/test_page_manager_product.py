@@ -464,3 +464,40 @@ def test_premapped_pages_are_the_last_to_be_reclaimed():
     assert st["mapped"][o] >= 22 and 0 < st["mapped"][r] < 10 and st["mapped"][o] + st["mapped"][r] == 30
     assert fake_counters()["violations"] == 0
     p.pm.cleanup(); p.pm.close()
+
+
+def test_premap_reclaims_from_finished_slots_in_the_background():
+    """Pool dry at look-ahead time: premap takes the pages from slots that hold more than they need on the MAPPER thread (the
+    unmaps, and the wait for those slots' fences, run there), so neither the look-ahead nor the step that activates the request
+    executes driver calls on the caller's thread."""
+    cfg = dict(num_layers=2, num_kv_heads=2, head_size=128, max_batch_size=4, max_context_length=4096, itemsize=2,
+               page_size=32 << 10, megacache=False)          # 64 tokens per page
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    p = ProductImpl(cfg, flags=0)
+    p.reserve_physical_pages(19 * group)
+    a = p.alloc_new_batch_idx(576)                    # 9 groups
+    b = p.alloc_new_batch_idx(640)                    # 10 groups
+    lens = [0] * 4
+    lens[a], lens[b] = 576, 640
+    p.step_async(lens); p.pm.wait()
+    p.pm.free_batch_idx(a); p.pm.free_batch_idx(b)    # both finished: their pages stay mapped (deferred reclamation)
+    lens[a] = lens[b] = 0
+    c = p.alloc_new_batch_idx(30)                     # a short request reuses one of them and keeps its surplus pages for now
+    lens[c] = 30
+    p.step_async(lens); p.pm.wait()
+    m0 = p.pm.state()["mapped"]
+    assert sum(m0) == 19 and p.pm.state()["pool"] == 0, "the pool must be dry for this scenario"
+    st0 = p.pm.stats()
+    s = p.pm.premap(1152)                             # 18 groups: 10 are there, the other 8 come out of slot c's surplus
+    assert s >= 0 and s != c
+    p.pm.wait()
+    st1 = p.pm.stats()
+    assert st1["sync_batches"] == st0["sync_batches"], "a look-ahead executed driver calls on the caller's thread"
+    assert st1["unmap_calls"] > st0["unmap_calls"] and p.pm.state()["mapped"][s] == 18
+    lens[s] = 1152                                    # activation: everything is in place
+    p.step_async(lens)
+    assert p.pm.stats()["sync_batches"] == st1["sync_batches"]
+    p.pm.wait()
+    assert p.pm.state()["mapped"][c] >= 1
+    assert fake_counters()["violations"] == 0 and fake_counters()["stale_vas"] == 0
+    p.pm.cleanup(); p.pm.close()

@@ -222,9 +222,10 @@ int PageManager::grow(int r, uint64_t nblocks, bool sync) {   // vattention.cu:2
     return VATTN_OK;
 }
 
-void PageManager::reclaim_on_demand(uint64_t nblocks) {   // vattention.cu:420-438
-    // (slots pre-mapped for the NEXT request — premap(), an extension — are only touched if nothing else can be reclaimed)
-    for (int pass = 0; pass < 2; pass++)
+void PageManager::reclaim_on_demand(uint64_t nblocks, bool allow_reserved) {   // vattention.cu:420-438
+    // (slots pre-mapped for the NEXT request — premap(), an extension — are only touched if nothing else can be reclaimed, and
+    // never on behalf of another look-ahead)
+    for (int pass = 0; pass < (allow_reserved ? 2 : 1); pass++)
         for (int r = (int)cfg_.max_batch_size - 1; r >= 0; r--) {
             if (kvblocks_available(nblocks)) return;
             if (pass == 0 && reserved_[r]) continue;
@@ -499,9 +500,14 @@ int PageManager::premap(uint64_t seqlen) {
     if (be_.fence_record) be_.fence_record(be_.ctx, (uint32_t)slot, nullptr);      // a new occupant: the previous one's fence is void
     if (required > mapped_pages_[slot] && required <= max_pages_per_req_) {
         const uint64_t need = required - mapped_pages_[slot];
-        if (kvblocks_available(need)) {                 // never reclaims for a look-ahead: a later step() does that if it must
+        // pool dry: take the pages from finished, unreserved slots HERE — the unmaps (and the wait for those slots' fences) then
+        // run on the mapper thread under the current iteration, not in the activating step's critical path
+        if (!kvblocks_available(need)) reclaim_on_demand(need, false);
+        if (kvblocks_available(need)) {
             grow(slot, need, false);
             flush_async();
+        } else if (!plan_.empty()) {
+            flush_async();                              // partial reclaim: keep what was freed
         }
     }
     return slot;

@@ -115,7 +115,7 @@ private:
     void unmap_req_page_one(int r);
     void release_some(int r, uint64_t retain);
     int grow(int r, uint64_t nblocks, bool sync);
-    void reclaim_on_demand(uint64_t nblocks);
+    void reclaim_on_demand(uint64_t nblocks, bool allow_reserved = true);
     void do_reclaim_pages();
     int map_pages_for_curr_step(int r, uint64_t seq_len);
     void background_management();
