@@ -433,7 +433,15 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     // query block on the 8-wave tiling (two rounds, heaviest first) measure 0.192 ms against 0.239 (prefill64 unsplit), 0.226 (4-wave
     // tiling unsplit) and 0.201 (prefill64, two shares).
     if (p->d == 128 && (uniform || wg8 > 256)) {
-        const int ns7 = wg8 >= 256 ? 1 : pick(wg8, 256);
+        int ns7 = wg8 >= 256 ? 1 : pick(wg8, 256);
+        if (uniform && wg8 >= 256) {
+            // a few rounds of EQUAL workgroups (a chunk on a long prefix): if the last round is far from full (Yi-34B/TP4: 14 heads x
+            // 64 query blocks = 3.5 rounds, 12.5 % of the chip idle at the end), split the key range so that whole rounds come out
+            auto eff = [](long w) { return (double)w / (double)(((w + 255) / 256) * 256); };
+            double best = eff(wg8);
+            for (int ns = 2; ns <= 4 && best < 0.93; ns++)
+                if (tiles / ns >= 24 && eff(wg8 * ns) > best + 0.04) { best = eff(wg8 * ns); ns7 = ns; }
+        }
         if (wg8 * ns7 >= 192 && tiles / ns7 >= 24) {
             pl.tiling = 7;
             pl.nsplit = ns7;
