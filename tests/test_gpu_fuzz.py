@@ -2,6 +2,7 @@
 group sizes, head dimension 64 / 128, fp16 / bf16, ragged batches through cache_batch_idx, causal and full attention,
 query chunks longer than the visible keys, forced and automatic split counts, every workgroup order / tiling, batched
 variable-length chunks, decode with in-kernel append.  Deterministic (fixed seeds), ~100 cases."""
+import os
 import random
 
 import pytest
@@ -11,6 +12,8 @@ from oracle.attn import flash_attn_with_kvcache_ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# VATTN_FUZZ_SCALE=10 runs ten times as many seeds (the committed default keeps the suite short)
+SCALE = int(os.environ.get("VATTN_FUZZ_SCALE", "1"))
 
 
 def _tol(dtype):
@@ -24,7 +27,7 @@ def _check(out, ref64, dtype, what):
     assert bool((err <= bound).all()), "%s: max err %.3e" % (what, err.max().item())
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * SCALE))
 def test_fuzz_prefill(seed):
     from vattention_amd.flash_attn import flash_attn_with_kvcache
     rng = random.Random(1000 + seed)
@@ -43,6 +46,8 @@ def test_fuzz_prefill(seed):
         slots = rng.sample(range(B + 2), B)
         variant = rng.choice([0, 0, 1, 2, 8, 9, 32, 64, 12 if D == 128 else 0, 4 if D == 128 else 0, 14 if D == 128 else 0, 2574 if D == 128 else 2, 270 if D == 128 else 0, 526 if D == 128 else 8])
         splits = rng.choice([0, 0, 0, 1, 2, 3, 7])
+        if splits > 1:
+            variant |= rng.choice([0, 0, 16384, 32768])      # the key-range shares merged inside the launch (both protocols)
         q = torch.randn(B, n, Hq, D).to(dtype)
         kc = torch.randn(B + 2, ctx, Hkv, D).to(dtype)
         vc = torch.randn(B + 2, ctx, Hkv, D).to(dtype)
@@ -56,7 +61,7 @@ def test_fuzz_prefill(seed):
             seed, case, D, Hq, Hkv, B, n, cls, causal, variant, splits))
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 * SCALE))
 def test_fuzz_batched_chunks(seed):
     from vattention_amd.flash_attn import flash_attn_varlen_with_kvcache
     rng = random.Random(2000 + seed)
@@ -90,7 +95,7 @@ def test_fuzz_batched_chunks(seed):
             _check(out[starts[i]:starts[i] + lens[i]].unsqueeze(0), ref, torch.float16, "varlen seed %d case %d entry %d" % (seed, case, i))
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", range(5 * SCALE))
 def test_fuzz_decode(seed):
     from vattention_amd.flash_attn import flash_attn_with_kvcache
     rng = random.Random(3000 + seed)
@@ -118,7 +123,44 @@ def test_fuzz_decode(seed):
         kg, vg = kc.to(DEV), vc.to(DEV)
         out = flash_attn_with_kvcache(q.to(DEV), kg, vg, kn.to(DEV) if append else None, vn.to(DEV) if append else None,
                                       cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True,
-                                      num_splits=rng.choice([0, 0, 1, 2, 9, 48]), _variant=rng.choice([0, 1, 64]))
+                                      num_splits=rng.choice([0, 0, 1, 2, 9, 48]), _variant=rng.choice([0, 1, 64, 128, 512, 1024, 128 | 1024]))
         torch.cuda.synchronize()
         _check(out, ref, dtype, "decode seed %d case %d (D=%d Hq=%d Hkv=%d B=%d ctx=%d append=%s)" % (seed, case, D, Hq, Hkv, B, ctx, append))
         assert torch.equal(kg.cpu(), kr) and torch.equal(vg.cpu(), vr)
+
+
+@pytest.mark.parametrize("seed", range(4 * SCALE))
+def test_fuzz_prefill64_midsize(seed):
+    """The round-2 prefill kernel (variant 14 = forced, product build; 782 = XOR-swizzled K image; 270 = v_dot2c row sums) on
+    shapes big enough for its pipeline to reach steady state: hundreds to thousands of query rows on prefixes of up to 7 k keys,
+    ragged two-sequence batches, key-range shares (two-launch and in-launch merges), non-causal, odd group sizes."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    rng = random.Random(7000 + seed)
+    torch.manual_seed(700 + seed)
+    for case in range(3):
+        dtype = rng.choice([torch.float16, torch.float16, torch.bfloat16])
+        Hkv = rng.choice([1, 2, 4])
+        G = rng.choice([1, 4, 7, 8])
+        Hq, D = Hkv * G, 128
+        B = rng.choice([1, 1, 2])
+        n = rng.choice([257, 300, 777, 1024, 1500, 2048, 3000])
+        pre = [rng.choice([0, 0, 64, 1000, 3333, 7000]) for _ in range(B)]
+        cls = [p + (n if rng.random() < 0.8 else rng.randrange(1, n + 1)) for p in pre]
+        ctx = max(cls) + 7
+        causal = rng.random() < 0.85
+        variant = rng.choice([14, 14, 14, 782, 270])
+        splits = rng.choice([0, 0, 1, 2, 3])
+        if splits > 1:
+            variant |= rng.choice([0, 16384, 32768])
+        slots = rng.sample(range(B + 1), B)
+        q = torch.randn(B, n, Hq, D).to(dtype)
+        kc = torch.randn(B + 1, ctx, Hkv, D).to(dtype)
+        vc = torch.randn(B + 1, ctx, Hkv, D).to(dtype)
+        cl = torch.tensor(cls, dtype=torch.int32)
+        idx = torch.tensor(slots, dtype=torch.int32)
+        ref = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=causal)
+        out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
+                                      causal=causal, num_splits=splits, _variant=variant, _max_seqlen_k=max(cls))
+        torch.cuda.synchronize()
+        _check(out, ref, dtype, "prefill64 seed %d case %d (Hq=%d Hkv=%d B=%d n=%d cl=%s causal=%s variant=%d splits=%d %s)" % (
+            seed, case, Hq, Hkv, B, n, cls, causal, variant, splits, dtype))
