@@ -126,7 +126,8 @@ class vATTNCacheEngine:
     def prefetch_request(self, seq_id: int, seq_len: int) -> int:
         """MI355X extension: call once the scheduler knows which request it admits NEXT (before or while the current iteration runs):
         its slot is reserved and its pages are mapped by the mapper thread under the current forward pass, so that the iteration
-        that starts the request maps nothing synchronously.  Returns the slot (-1: none free / already placed)."""
+        that starts the request maps nothing synchronously.  Returns the slot (-1: none free / already placed).  A request that is
+        dropped before it starts is released like any other: free_request(seq_id) (its pages stay mapped and reclaimable)."""
         if seq_id in self.seq_to_batch_idx:
             return -1
         slot = vattention.premap(seq_len)
