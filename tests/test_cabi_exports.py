@@ -114,6 +114,7 @@ def test_split_plans_from_the_workspace_query():
     assert pf_splits(4096, 32768, 32, 4, 32768) == 1    # 4k chunk, 32 heads: 512 workgroups
     assert pf_splits(16384, 131072, 14, 2, 131072) == 2 # Yi-34B/TP4 16k chunk @ 112k: 896 equal workgroups = 3.5 rounds -> 7 whole rounds
     assert pf_splits(16384, 131072, 28, 4, 131072) == 1 # Yi-34B/TP2: 1792 workgroups = 7 whole rounds already
+    assert pf_splits(2048, 2048, 32, 4, 2048) == 1      # 2k prompt, 32 heads: also 256 workgroups, too short to split
     assert pf_splits(8192, 8192, 8, 1, 8192) == 2       # TP8 8k prompt: exactly one 8-wave workgroup per CU, causal whole prompt -> two key-range shares
     # tensor-parallel shards / short chunks on long prefixes are split (only when the host knows the lengths)
     assert pf_splits(2048, 32768, 8, 1, 32768) == 4     # 64 workgroups x 4 = one round

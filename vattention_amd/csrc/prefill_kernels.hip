@@ -450,8 +450,10 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     }
     if (wg8 > 256) return pl;
     if (wg8 == 256) {
+        // ... but only when a share still walks >= 24 key tiles: a 2 k prompt with 32 heads is also exactly 256 workgroups, and there
+        // the two-launch split costs more than the imbalance (0.082 ms split vs 0.060 ms on the 4-wave tiling, profiles/r02_kbench.txt)
         const int ns = uniform ? 1 : cap_by_tiles(2);
-        if (ns > 1) pl.nsplit = ns;
+        if (ns > 1 && tiles / ns >= 24) pl.nsplit = ns;
         else pl.tiling = 4;
         return pl;
     }
