@@ -100,6 +100,7 @@ def decode(variant):
                                          ("yi6b B1@8k", 32, 4, 1, 8192, 4), ("yi6b B1@2k", 32, 4, 1, 2048, 4),
                                          ("llama8b B64@8k", 32, 8, 64, 8192, 64), ("llama8b B256@2k", 32, 8, 256, 2048, 256),
                                          ("llama70b/tp8 B64@32k", 8, 1, 64, 32768, 64), ("yi34b/tp2 B8@128k", 28, 4, 8, 131072, 8),
+                                         ("yi34b/tp2 B1@128k", 28, 4, 1, 131072, 2), ("yi34b/tp4 B1@128k", 14, 2, 1, 131072, 2),
                                          ("mqa G32 B16@16k", 32, 1, 16, 16384, 16), ("gqa G32x4 B8@16k", 128, 4, 8, 16384, 8),
                                          ("mqa G64 B16@8k", 64, 1, 16, 8192, 16)]:
         if ONLY and not any(o.strip() in name for o in ONLY.split(",")):

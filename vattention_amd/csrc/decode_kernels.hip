@@ -72,7 +72,11 @@ int pick_splits(const vattn_attn_params* p, int gblocks, long slots = 768) {
     if (cap < 1) cap = 1;
     // a split shorter than ~700 keys costs more in prologue / merge / combine than it returns: B1@32k 20.4 us at 32-48 splits
     // vs 26 us at 128; short contexts still want one tile per wave (B1@2k: 16 splits 11 us vs 24 us unsplit)
-    if (cap > 48) cap = 48;
+    // -> at most 48 splits up to 32 k keys; longer contexts keep the ~700-key floor instead (128 k: up to 128 splits — a single
+    // sequence of Yi-34B/TP2's 4 kv heads is 192 workgroups at 48 splits, 512 at 128)
+    long cap_len = tiles / 21;
+    cap_len = cap_len < 48 ? 48 : (cap_len > 128 ? 128 : cap_len);
+    if (cap > cap_len) cap = cap_len;
     if (wg * 10 >= slots * 6) return 1;      // the batch alone (nearly) fills the chip: splitting only adds combine work
     // otherwise: fill whole rounds of resident workgroups exactly (measured on MI355X, tools/kbench.py --splits:
     // 16 x 4 heads @32k: 12 splits = 768 workgroups 71.4 % of HBM peak vs 63.9-68.8 % for 4/6/8/16/24)
