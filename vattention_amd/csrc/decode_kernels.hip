@@ -72,10 +72,10 @@ int pick_splits(const vattn_attn_params* p, int gblocks, long slots = 768) {
     if (cap < 1) cap = 1;
     // a split shorter than ~700 keys costs more in prologue / merge / combine than it returns: B1@32k 20.4 us at 32-48 splits
     // vs 26 us at 128; short contexts still want one tile per wave (B1@2k: 16 splits 11 us vs 24 us unsplit)
-    // -> at most 48 splits up to 32 k keys; longer contexts keep the ~700-key floor instead (128 k: up to 128 splits — a single
-    // sequence of Yi-34B/TP2's 4 kv heads is 192 workgroups at 48 splits, 512 at 128)
-    long cap_len = tiles / 21;
-    cap_len = cap_len < 48 ? 48 : (cap_len > 128 ? 128 : cap_len);
+    // -> at most 48 splits; 64 when fewer than four (sequence, kv head) groups exist and the context is long enough to keep ~700
+    // keys per split (one 128 k sequence on a TP4 shard, 2 kv heads: 35.4 us at 48 splits, 30.8 at 64, 33.7 at 128; with 4 kv heads
+    // 48 / 64 / 128 splits measure 52.3 / 52.8 / 53.4 us: profiles/r02_kbench_decode_splits.txt)
+    const long cap_len = (wg <= 3 && tiles / 21 >= 64) ? 64 : 48;
     if (cap > cap_len) cap = cap_len;
     if (wg * 10 >= slots * 6) return 1;      // the batch alone (nearly) fills the chip: splitting only adds combine work
     // otherwise: fill whole rounds of resident workgroups exactly (measured on MI355X, tools/kbench.py --splits:
