@@ -24,6 +24,7 @@ import torch
 
 from .. import vattention as _vattention
 from ..cache_ops import cache_flat, cache_flat_rope
+from .. import flash_attn as _FA
 from ..flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
 from .base_attention_wrapper import BaseAttentionWrapper
 from .timers import OperationMetrics
@@ -57,6 +58,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         self.max_cache_len = 0
         self.decode_batch_size = 0
         self._decode_lens_host: List[int] = []
+        self._dec_plan = None       # per-iteration launch plan of the decode call (built by layer 0, replayed by the other layers)
 
     def get_cache_block(self, num_blocks: int, **kwargs):
         return None          # vAttention has no block tables
@@ -64,6 +66,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
     def begin_forward(self, seq_metadata_list) -> None:
         self.is_profiling_iteration = False
         self.is_metadata_initialized = True
+        self._dec_plan = None
         q_lens, c_lens, totals, dec = [], [], [], []
         for md in seq_metadata_list:
             if md.is_prompt:
@@ -168,10 +171,22 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         return tok
 
     def _forward_decodes(self, query, key, value, kv_cache, softmax_scale, layer_id, output, tok: int) -> None:
-        """ONE batched decode call: new K/V appended in-kernel at cache_seqlens of the slots named by cache_batch_idx."""
+        """ONE batched decode call: new K/V appended in-kernel at cache_seqlens of the slots named by cache_batch_idx.
+        The L layers of an iteration issue the SAME call on different tensors: layer 0 builds the parameter block through the normal
+        entry point (all argument checks), the other layers patch the six tensor pointers into it and launch — with small decode
+        batches the launch is tens of microseconds and the Python argument handling would otherwise be the bottleneck."""
         Hq, Hkv, D = self.num_q_heads, self.num_kv_heads, self.head_dim
         k_all, v_all = kv_cache
         nb = self.decode_batch_size
+        plan = self._dec_plan
+        sig = (query.stride(0), key.stride(0), value.stride(0), output.stride(0), k_all.stride(), v_all.stride(), tok, float(softmax_scale),
+               query.dtype, k_all.dtype)
+        if plan is not None and plan["sig"] == sig and not _FA._capture_active():
+            with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id):
+                _FA.relaunch(plan["p"], query.data_ptr() + plan["q_off"], key.data_ptr() + plan["k_off"], value.data_ptr() + plan["v_off"],
+                             output.data_ptr() + plan["o_off"], k_all.data_ptr(), v_all.data_ptr(), self.device)
+            return
+        capture = None if _FA._capture_active() else []
         with self.get_timer(OperationMetrics.ATTN_INPUT_RESHAPE, layer_id):
             dq = query[tok:tok + nb].view(nb, 1, Hq, D)
             dk = key[tok:tok + nb].view(nb, 1, Hkv, D)
@@ -181,4 +196,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                     cache_seqlens=self.decode_cache_lens, block_table=None,
                                     softmax_scale=softmax_scale, causal=True,
                                     cache_batch_idx=self.batch_index_gen,
-                                    out=output[tok:tok + nb].view(nb, 1, Hq, D), _rotary_cos_sin=self._rotary)
+                                    out=output[tok:tok + nb].view(nb, 1, Hq, D), _rotary_cos_sin=self._rotary, _params_out=capture)
+        if capture:
+            es = query.element_size()
+            self._dec_plan = {"sig": sig, "p": capture[0], "q_off": tok * query.stride(0) * es, "k_off": tok * key.stride(0) * es,
+                              "v_off": tok * value.stride(0) * es, "o_off": tok * output.stride(0) * es}

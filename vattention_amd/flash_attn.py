@@ -110,6 +110,20 @@ def hybrid_attn(prefill_call, decode_call, device, _role_mode: int = 0) -> None:
     del keep_p, keep_d
 
 
+def _capture_active() -> bool:
+    return _capture is not None
+
+
+def relaunch(p, q_ptr: int, k_new_ptr: int, v_new_ptr: int, out_ptr: int, k_cache_ptr: int, v_cache_ptr: int, dev) -> None:
+    """Re-issue a call whose parameter block `p` was built by flash_attn_with_kvcache(..., _params_out=[]) with other tensors of the
+    SAME shapes, strides and dtype (the attention wrapper: layers 1..L-1 of an iteration).  Only the six data pointers change; the
+    workspace is looked up again (another call on this stream may have replaced it with a larger one)."""
+    p.q, p.out, p.k_cache, p.v_cache = q_ptr, out_ptr, k_cache_ptr, v_cache_ptr
+    if p.k_new:
+        p.k_new, p.v_new = k_new_ptr, v_new_ptr
+    _launch(p, dev)
+
+
 def _launch(p, dev, keep=()):
     """Attach the split-KV workspace the call needs (one buffer per device and stream) and launch on the current stream."""
     if _capture is not None:
@@ -136,7 +150,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             cache_batch_idx: Optional[torch.Tensor] = None, cache_leftpad=None, block_table=None,
                             softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                             rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
-                            out=None, _variant=0, _max_seqlen_k: int = 0, _rotary_cos_sin=None):
+                            out=None, _variant=0, _max_seqlen_k: int = 0, _rotary_cos_sin=None, _params_out=None):
     rot = _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q)
     if block_table is not None:
         raise NotImplementedError("paged KV (block_table) is what vAttention replaces; not supported")
@@ -214,6 +228,10 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     if rot is not None:
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
     _launch(p, dev, keep=(q, k, v, k_cache, v_cache, cache_seqlens, cache_batch_idx, out, lse, rot))
+    if _params_out is not None and not return_softmax_lse:
+        # the caller may re-issue this call through relaunch(): the block keeps the index / length / rotary tensors it points to alive
+        p._keep = (cache_seqlens, cache_batch_idx, rot)
+        _params_out.append(p)
     return (out, lse) if return_softmax_lse else out
 
 
