@@ -51,7 +51,7 @@ def time_ms(p, warmup=2, iters=5):
 
 
 def prefill(variant):
-    print("== prefill (causal chunk n against c cached), fp16, D=128 ==")
+    print("== prefill (causal chunk n against c cached), %s, D=128 ==" % ("bf16" if DTYPE == torch.bfloat16 else "fp16"))
     for name, Hq, Hkv, n, c in [("yi6b whole", 32, 4, 32702, 0), ("yi6b chunk4k@28k", 32, 4, 4096, 28672), ("yi6b chunk4k@0", 32, 4, 4096, 0),
                                 ("llama8b 16k", 32, 8, 16384, 0), ("yi34b/tp2 chunk16k@112k", 28, 4, 16384, 114688),
                                 ("llama70b/tp8 8k", 8, 1, 8192, 0), ("small 2k", 32, 4, 2048, 0),
@@ -95,7 +95,7 @@ def prefill(variant):
 
 
 def decode(variant):
-    print("== decode (Sq=1, append + split-KV + combine), fp16, D=128 ==")
+    print("== decode (Sq=1, append + split-KV + combine), %s, D=128 ==" % ("bf16" if DTYPE == torch.bfloat16 else "fp16"))
     for name, Hq, Hkv, B, ctx, slots in [("yi6b B16@32k", 32, 4, 16, 32768, 16), ("yi6b B1@32k", 32, 4, 1, 32768, 4), ("yi6b B4@32k", 32, 4, 4, 32768, 4),
                                          ("yi6b B1@8k", 32, 4, 1, 8192, 4), ("yi6b B1@2k", 32, 4, 1, 2048, 4),
                                          ("llama8b B64@8k", 32, 8, 64, 8192, 64), ("llama8b B256@2k", 32, 8, 256, 2048, 256),
