@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # VATTN_FUZZ_SCALE=10 runs ten times as many seeds (the committed default keeps the suite short)
 SCALE = int(os.environ.get("VATTN_FUZZ_SCALE", "1"))
+BASE = int(os.environ.get("VATTN_FUZZ_SEED_BASE", "0"))      # shifts every seed: a different sample of the same space
 
 
 def _tol(dtype):
@@ -27,7 +28,7 @@ def _check(out, ref64, dtype, what):
     assert bool((err <= bound).all()), "%s: max err %.3e" % (what, err.max().item())
 
 
-@pytest.mark.parametrize("seed", range(6 * SCALE))
+@pytest.mark.parametrize("seed", range(BASE, BASE + 6 * SCALE))
 def test_fuzz_prefill(seed):
     from vattention_amd.flash_attn import flash_attn_with_kvcache
     rng = random.Random(1000 + seed)
@@ -61,7 +62,7 @@ def test_fuzz_prefill(seed):
             seed, case, D, Hq, Hkv, B, n, cls, causal, variant, splits))
 
 
-@pytest.mark.parametrize("seed", range(4 * SCALE))
+@pytest.mark.parametrize("seed", range(BASE, BASE + 4 * SCALE))
 def test_fuzz_batched_chunks(seed):
     from vattention_amd.flash_attn import flash_attn_varlen_with_kvcache
     rng = random.Random(2000 + seed)
@@ -95,7 +96,7 @@ def test_fuzz_batched_chunks(seed):
             _check(out[starts[i]:starts[i] + lens[i]].unsqueeze(0), ref, torch.float16, "varlen seed %d case %d entry %d" % (seed, case, i))
 
 
-@pytest.mark.parametrize("seed", range(5 * SCALE))
+@pytest.mark.parametrize("seed", range(BASE, BASE + 5 * SCALE))
 def test_fuzz_decode(seed):
     from vattention_amd.flash_attn import flash_attn_with_kvcache
     rng = random.Random(3000 + seed)
@@ -129,7 +130,7 @@ def test_fuzz_decode(seed):
         assert torch.equal(kg.cpu(), kr) and torch.equal(vg.cpu(), vr)
 
 
-@pytest.mark.parametrize("seed", range(4 * SCALE))
+@pytest.mark.parametrize("seed", range(BASE, BASE + 4 * SCALE))
 def test_fuzz_prefill64_midsize(seed):
     """The round-2 prefill kernel (variant 14 = forced, product build; 782 = XOR-swizzled K image; 270 = v_dot2c row sums) on
     shapes big enough for its pipeline to reach steady state: hundreds to thousands of query rows on prefixes of up to 7 k keys,
