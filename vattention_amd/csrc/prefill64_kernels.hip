@@ -641,7 +641,7 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
     static const int env_sel = [] { const char* e = getenv("VATTN_PREFILL64_BUILD"); return e ? atoi(e) & 15 : 0; }();   // measurement hook
     const int sel = ((p->variant >> 8) & 15) ? ((p->variant >> 8) & 15) : env_sel;
-    // product build: padded K image (ABL bit 7; +0.6 % over the XOR-swizzled image, 28 fewer VALU instructions per tile)
+    // product build: padded K image (ABL bit 7; 28 fewer VALU instructions per tile than the XOR-swizzled image, same time within noise)
     if (p->dtype == VATTN_DTYPE_BF16) {
         if (sel == 1) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode);
         else if (sel == 3) launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done, merge_mode);
