@@ -156,7 +156,9 @@ int vattn_free_batch_idx_on_stream(vattn_t* m, int slot, void* stream);
 int vattn_premap(vattn_t* m, uint64_t seqlen);
 int vattn_cancel_premap(vattn_t* m, int slot);
 /* VATTN_FLAG_LAYERED_ASYNC: block until the pages the current step needs are mapped for `layer` (returns at once when no
- * layered batch is pending); VATTN_ERR_* if the mapper failed.  vattn_layers_ready: layers mapped so far (num_layers when
+ * layered batch is pending); VATTN_ERR_* if the mapper failed (vattn_last_error is NOT updated by this call — it may run
+ * concurrently with the engine thread's calls; the next vattn_step* / vattn_wait reports the driver's message).  A caller that
+ * does not know its layer index waits for num_layers - 1 once per iteration.  vattn_layers_ready: layers mapped so far (num_layers when
  * nothing is pending).  vattn_set_sync_layers: layers mapped before step_async returns (default 2). */
 int vattn_wait_layer(vattn_t* m, uint32_t layer);
 uint32_t vattn_layers_ready(vattn_t* m);

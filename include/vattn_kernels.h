@@ -97,7 +97,8 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream);
  * batched-chunk form, k_new == NULL: append with vattn_cache_flat first), `decode` a decode-form block (seqlen_q == 1, optional
  * one-row append); both d == 128 and the same dtype; their `workspace` fields are ignored.  `workspace` is
  * vattn_hybrid_workspace_bytes() bytes of device memory that must be ZERO before the first launch; the launch leaves its control
- * words zero, so it can be reused by the next launch on the same stream without a memset.  Results are those of the two
+ * words and merge counters zero (they sit in a fixed-size region ahead of the split partials, whatever the batch), so it can be
+ * reused by the next launch on the same stream — of any batch size it is large enough for — without a memset.  Results are those of the two
  * stand-alone launches (same device functions). */
 size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode);
 int vattn_hybrid_attn(const vattn_attn_params* prefill, const vattn_attn_params* decode, void* workspace, void* stream);

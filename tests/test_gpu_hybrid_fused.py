@@ -86,6 +86,38 @@ def test_fused_hybrid_launch_matches_the_oracle(Hq, Hkv, chunks, dec_lens, dtype
         assert torch.equal(kg.cpu(), kc_ref) and torch.equal(vg.cpu(), vc_ref), "appended rows differ"
 
 
+def test_fused_hybrid_workspace_survives_a_growing_decode_batch():
+    """Back-to-back launches on ONE stream reuse one workspace.  A first launch with a few decode groups leaves fp32 split partials
+    in it; a later launch with MORE groups (b * h_k going from 8 to 96 here) must not find its merge counters on top of those bytes
+    — they live in a fixed-capacity region ahead of the partials (csrc/hybrid_kernels.hip, HY_DONE_CAP).  With the old
+    batch-dependent offset the larger launch's counters started non-zero, the merge never ran, and decode rows stayed unwritten."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache, hybrid_attn
+    dtype, Hq, Hkv = torch.float16, 8, 2
+    # largest batch first (sizes the workspace once), then a small one (leaves partials right behind ITS counters), then a larger one
+    for dec_lens in ([300 + 11 * i for i in range(130)], [900, 1800, 2500, 700], [600 + 37 * i for i in range(48)], [1500] * 3,
+                     [400 + 5 * i for i in range(100)]):
+        chunks = [(512, 256)]
+        c = _case(dtype, Hq, Hkv, chunks, dec_lens, 23 + len(dec_lens))
+        ref64, kc_ref, vc_ref = _oracle(c, chunks, dec_lens, dtype, {})
+        ref32, _, _ = _oracle(c, chunks, dec_lens, dtype, {"math": "f32"})
+        T, Bd, D = c["T"], c["Bd"], c["D"]
+        kg, vg, q = c["kc"].to(DEV), c["vc"].to(DEV), c["q"].to(DEV)
+        out = torch.full((T + Bd, Hq, D), float("nan"), dtype=dtype, device=DEV)
+        s = int(c["p_slots"][0])
+        totals = torch.tensor([chunks[0][0] + chunks[0][1]], dtype=torch.int32, device=DEV)
+        ml = max(dec_lens) + 1
+        hybrid_attn(lambda: flash_attn_with_kvcache(q[:T].unsqueeze(0), kg[s:s + 1], vg[s:s + 1], cache_seqlens=totals, causal=True,
+                                                    out=out[:T].unsqueeze(0), _max_seqlen_k=768),
+                    lambda: flash_attn_with_kvcache(q[T:].unsqueeze(1), kg[:, :ml], vg[:, :ml], c["kn"].to(DEV), c["vn"].to(DEV),
+                                                    cache_seqlens=torch.tensor(dec_lens, dtype=torch.int32, device=DEV),
+                                                    cache_batch_idx=c["d_slots"].to(DEV), causal=True, out=out[T:].unsqueeze(1)),
+                    torch.device(DEV))
+        torch.cuda.synchronize()
+        assert not torch.isnan(out.float()).any(), "decode rows left unwritten with %d sequences" % Bd
+        _check(out, ref64, ref32, dtype, "fused hybrid launch, %d decode sequences after a smaller batch" % Bd)
+        assert torch.equal(kg.cpu(), kc_ref) and torch.equal(vg.cpu(), vc_ref)
+
+
 def test_fused_hybrid_argument_rules():
     from vattention_amd.flash_attn import flash_attn_with_kvcache, hybrid_attn
     dt = torch.float16

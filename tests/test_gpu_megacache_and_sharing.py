@@ -57,7 +57,7 @@ def test_attention_over_megacache_views_matches_oracle():
         assert torch.equal(kg[:, :, l, :, :].cpu()[:, 1400:], kmega[:, 1400:, l])
 
 
-def _runner_vs_oracle(backend, num_layers, page, prompts, decode_steps, max_len=4096, pool_groups=64, max_batch=4, chunk=None):
+def _runner_vs_oracle(backend, num_layers, page, prompts, decode_steps, max_len=4096, pool_groups=64, max_batch=4, chunk=None, pass_layer_id=True):
     """Drives engine + wrapper + page manager (HotPathRunner) and checks EVERY layer's output of every iteration with the oracle
     (per-layer activations differ: layer l sees q/k/v scaled by (1 + l/8))."""
     from vattention_amd import vattention
@@ -79,7 +79,8 @@ def _runner_vs_oracle(backend, num_layers, page, prompts, decode_steps, max_len=
                 r.wrapper.begin_forward(mds)
                 for l in range(num_layers):
                     s = 1.0 + l / 8.0
-                    outs.append(r.wrapper.forward((q * s).half(), (k * s).half(), (v * s).half(), r.engine.gpu_cache[l], r.scale, l))
+                    outs.append(r.wrapper.forward((q * s).half(), (k * s).half(), (v * s).half(), r.engine.gpu_cache[l], r.scale,
+                                                  l if pass_layer_id else None))
                 r.wrapper.end_forward()
             torch.cuda.synchronize()
             qh, kh, vh = q.float().cpu(), k.float().cpu(), v.float().cpu()
@@ -131,6 +132,18 @@ def test_layer_ordered_mapping_end_to_end_matches_oracle():
     st = _runner_vs_oracle("fa_vattn", num_layers=6, page=64 << 10, prompts=[3000, 900], decode_steps=3, pool_groups=80)
     assert st["layered_batches"] >= 2
     assert st["async_ns"] > 0
+
+
+def test_layer_ordered_mapping_with_models_that_pass_no_layer_id():
+    """The reference's yi / mistral / qwen / falcon / internlm models call wrapper.forward(...) WITHOUT layer_id (only llama.py:179-186
+    passes it).  Under the default flags (layer-ordered mapping on) the wrapper must then wait for EVERY layer before the first
+    kernel of the iteration: layers >= sync_layers of a new prompt would otherwise run over pages the mapper thread has not mapped
+    yet (a GPU memory fault).  Many layers and many small pages so that the mapper is still busy when forward() is entered."""
+    from vattention_amd import vattention
+    st = _runner_vs_oracle("fa_vattn", num_layers=12, page=64 << 10, prompts=[3900, 2500], decode_steps=2, pool_groups=100,
+                           pass_layer_id=False)
+    assert st["layered_batches"] >= 2
+    assert vattention._layered_pending is False
 
 
 def test_two_slots_attend_over_one_shared_prefix():

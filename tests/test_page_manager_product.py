@@ -332,6 +332,89 @@ def test_slot_fences_replace_the_device_wide_quiesce():
     p.pm.cleanup(); p.pm.close()
 
 
+def test_inherited_pages_of_a_reactivated_slot_are_unmapped_behind_the_fence():
+    """A slot freed right after LAUNCHING its last iteration (free_batch_idx_on_stream) can be handed to a new, shorter request by
+    the next step; the pages it inherits beyond the new request's need may still be read by the previous occupant's kernel.  An
+    on-demand reclaim that shrinks the now ACTIVE slot must wait for the slot's fence before unmapping them (it used to unmap at
+    once: the active-slot shortcut), while pages mapped for the current occupant still go without any wait."""
+    from tests.impls import fake
+    f = fake()
+    cfg = SHARE_CFG                                     # 64 tokens per page-group
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    p = ProductImpl(cfg, flags=4)
+    p.reserve_physical_pages(8 * group)
+    a = p.alloc_new_batch_idx(500)                      # 8 groups: the whole pool
+    lens = [0] * 4
+    lens[a] = 500
+    p.step(lens, False)
+    p.pm.free_batch_idx(a, stream=0x1234)               # freed behind the launch of its last iteration
+    lens[a] = 0
+    a2 = p.alloc_new_batch_idx(100)                     # best fit: the same slot, 8 groups inherited, 2 needed
+    assert a2 == a
+    lens[a2] = 100
+    b = p.alloc_new_batch_idx(200)                      # 4 groups, pool empty: reclaim from the active slot a2
+    lens[b] = 200
+    q0, w0 = f.vattn_fake_quiesce_count(), f.vattn_fake_fence_wait_count()
+    p.step(lens, False)
+    st = p.pm.state()
+    assert st["mapped"][a2] == 2 and st["mapped"][b] == 4      # (reclaim shrinks a victim to what it needs, vattention.cu:420-438)
+    assert f.vattn_fake_fence_wait_count() == w0 + 1 and f.vattn_fake_quiesce_count() == q0
+    # the slot grows again (pages of the CURRENT occupant), is then cut back by a restart: those pages go without a wait,
+    # the remaining inherited ones (positions 0, 1) still wait
+    p.pm.free_batch_idx(b, stream=0x1234); lens[b] = 0
+    p.step(lens, True)                                  # eager reclaim returns b's 4 groups (fence wait for slot b)
+    lens[a2] = 450                                      # 8 groups: positions 2..7 are new
+    p.step(lens, False)
+    lens[a2] = 260                                      # 5 needed
+    c_ = p.alloc_new_batch_idx(190)
+    lens[c_] = 190                                      # 3 groups, pool empty: a2 gives up positions 7, 6, 5 — all its own
+    q1, w1 = f.vattn_fake_quiesce_count(), f.vattn_fake_fence_wait_count()
+    p.step(lens, False)
+    assert p.pm.state()["mapped"][a2] == 5 and p.pm.state()["mapped"][c_] == 3
+    assert f.vattn_fake_quiesce_count() == q1 and f.vattn_fake_fence_wait_count() == w1
+    lens[a2] = 64                                       # 1 needed: positions 4, 3, 2 (own) and 1 (inherited) go
+    d = p.alloc_new_batch_idx(250)
+    lens[d] = 250
+    p.step(lens, False)
+    assert p.pm.state()["mapped"][a2] == 1 and p.pm.state()["mapped"][d] == 4
+    assert f.vattn_fake_fence_wait_count() == w1 + 1 and f.vattn_fake_quiesce_count() == q1
+    assert fake_counters()["violations"] == 0 and fake_counters()["stale_vas"] == 0
+    p.pm.cleanup(); p.pm.close()
+
+
+def test_layer_ordered_mapper_failure_takes_the_whole_groups_back():
+    """VATTN_FLAG_LAYERED_ASYNC: the first layers of a new prompt's page-groups are mapped by step_async itself, the rest by the
+    mapper.  When the MAPPER's half fails (transient hipMemMap / hipMemCreate error), the failed groups must be rolled back in ALL
+    layers — also the synchronously mapped ones — or they stay mapped under a slot whose count no longer covers them and the next
+    grow at that position maps over them: the slot would be unusable for good."""
+    from tests.impls import fake, fake_mapped
+    from vattention_amd import _lib as L
+    cfg = dict(num_layers=8, num_kv_heads=2, head_size=128, max_batch_size=4, max_context_length=4096, itemsize=2,
+               page_size=32 << 10, megacache=False)          # 64 tokens per page
+    group = 2 * cfg["num_layers"] * cfg["page_size"]
+    p = ProductImpl(cfg, flags=L.FLAG_LAYERED_ASYNC)
+    p.pm.set_sync_layers(2)
+    p.reserve_physical_pages(40 * group)
+    s = p.alloc_new_batch_idx(1000)                      # 16 groups: 64 synchronous maps (2 layers), 192 on the mapper
+    lens = [0] * 4
+    lens[s] = 1000
+    fake().vattn_fake_fail_map_after(fake_counters()["n_map"] + 64 + 100)    # fails inside layer 5 of the mapper's half
+    p.step_async(lens)
+    with pytest.raises(RuntimeError, match="hipMemMap failed"):
+        p.pm.wait()
+    fake().vattn_fake_fail_map_after(1 << 62)
+    st = p.pm.state()
+    # layer-sorted execution: every group misses its later layers, so every group of the step goes back — in every layer
+    assert st["mapped"][s] == 0 and len(fake_mapped()) == 0 and st["pool"] == 40 * 16 and st["pagemap_rows"] == 0
+    assert sorted(st["pool_ids"]) == list(range(40 * 16))
+    assert p.pm.stats()["rollbacks"] == 1
+    p.step_async(lens)                                   # and the slot is usable again
+    p.pm.wait()
+    assert p.pm.state()["mapped"][s] == 16 and len(fake_mapped()) >= 16 * 16
+    assert fake_counters()["violations"] == 0
+    p.pm.cleanup(); p.pm.close()
+
+
 def test_layer_ordered_async_mapping():
     """VATTN_FLAG_LAYERED_ASYNC: step_async returns once layers [0, sync_layers) of a new prompt's pages are mapped; the mapper
     maps the remaining layers in order and wait_layer(l) gates layer l.  End state identical to the plain path."""

@@ -61,8 +61,7 @@ class VAttentionFlashAttentionPodWrapper(VAttentionFlashAttentionStreamsWrapper)
             return torch.zeros_like(query)
         if not getattr(self, "_fused", False):
             return super().forward(query, key, value, kv_cache, softmax_scale, layer_id)
-        if layer_id is not None:
-            _vattention.wait_layer(layer_id)
+        self._gate_layer(layer_id)
         output = torch.empty_like(query)
         tok = sum(self.prefill_query_lens)
         # the chunk's cache_flat launches run normally (they precede the fused launch on the stream); the two attention calls are

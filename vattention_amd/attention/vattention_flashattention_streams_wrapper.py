@@ -72,8 +72,7 @@ class VAttentionFlashAttentionStreamsWrapper(VAttentionFlashAttentionWrapper):
             return torch.zeros_like(query)
         if not self._overlap:                        # not a hybrid batch, or splitting the prefill beats overlapping it
             return super().forward(query, key, value, kv_cache, softmax_scale, layer_id)
-        if layer_id is not None:
-            _vattention.wait_layer(layer_id)         # layer-ordered page mapping (see the base wrapper)
+        self._gate_layer(layer_id)
         output = torch.empty_like(query)
         main = torch.cuda.current_stream(self.device)
         side = self.decode_stream

@@ -105,14 +105,24 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         # the cache engine passes the host copy it already has; a foreign caller costs one sync per iteration
         self._batch_index_host = list(batch_idx_host) if batch_idx_host is not None else [int(x) for x in batch_idx.tolist()]
 
+    @staticmethod
+    def _gate_layer(layer_id: Optional[int]) -> None:
+        """Layer-ordered page mapping (vattention.enable_layered_async): this layer's pages must be mapped before its first kernel
+        is launched.  A model that passes its layer index (llama.py:179-186) waits for that layer only; the reference's other models
+        (yi.py, mistral.py, qwen.py, falcon.py, internlm.py) call forward() WITHOUT layer_id — then the first forward() of the
+        iteration waits for every layer (nothing else is safe: the call could be any layer's)."""
+        if layer_id is not None:
+            _vattention.wait_layer(layer_id)
+        else:
+            _vattention.wait_all_layers()
+
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 kv_cache: Tuple[torch.Tensor, torch.Tensor], softmax_scale: float = 1.0,
                 layer_id: Optional[int] = None) -> torch.Tensor:
         assert self.is_metadata_initialized, "Metadata is not initialized."
         if self.is_profiling_iteration:
             return torch.zeros_like(query)       # memory-profiling pass: no attention (model_runner.py:192-201)
-        if layer_id is not None:
-            _vattention.wait_layer(layer_id)     # layer-ordered page mapping: this layer's pages must be mapped by now
+        self._gate_layer(layer_id)
         output = torch.empty_like(query)
         tok = self._forward_prefills(query, key, value, kv_cache, softmax_scale, layer_id, output)
         if self.decode_batch_size:

@@ -22,7 +22,12 @@
 namespace vattn_k {
 
 constexpr int HY_CU_SLOTS = 2048;                    // (xcc, se, sh, cu) keys
-constexpr int HY_CTL_INTS = 4 + HY_CU_SLOTS;         // next[2], exited, pad, arrivals[HY_CU_SLOTS]; then done[groups]
+constexpr int HY_CTL_INTS = 4 + HY_CU_SLOTS;         // next[2], exited, pad, arrivals[HY_CU_SLOTS]; then done[HY_DONE_CAP]
+// The merge counters done[(sequence, kv head, head block)] live in a region of FIXED capacity between the control words and the
+// split partials: the partials' offset must not depend on the decode batch (a workspace is reused by later launches with other
+// batch sizes, and a counter that lands on bytes an earlier launch filled with fp32 partials never reaches num_splits - 1: the
+// merge would silently not run).  Every counter is reset by the workgroup that merges its group, so the region stays zero.
+constexpr int HY_DONE_CAP = 1 << 16;
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void hybrid_kernel(vattn_attn_params pp, vattn_attn_params pd, int* ctl, int n_pre, int n_dec, int nqb,
@@ -96,8 +101,8 @@ static int hybrid_decode_splits(const vattn_attn_params* pd, int gblocks) {
     return want < 1 ? 1 : (int)want;
 }
 
-static size_t hybrid_ctl_bytes(const vattn_attn_params* pd, int gblocks) {
-    const size_t ints = (size_t)HY_CTL_INTS + (size_t)pd->b * pd->h_k * gblocks;
+static size_t hybrid_ctl_bytes() {
+    const size_t ints = (size_t)HY_CTL_INTS + (size_t)HY_DONE_CAP;
     return ((ints * sizeof(int)) + 255) & ~(size_t)255;
 }
 
@@ -105,14 +110,15 @@ size_t hybrid_workspace_bytes(const vattn_attn_params* pp, const vattn_attn_para
     (void)pp;
     const int gblocks = (pd->h / pd->h_k + 15) / 16;
     const int ds = hybrid_decode_splits(pd, gblocks);
-    return hybrid_ctl_bytes(pd, gblocks) + (ds > 1 ? (size_t)ds * pd->b * pd->h * (pd->d + 1) * sizeof(float) : 0);
+    return hybrid_ctl_bytes() + (ds > 1 ? (size_t)ds * pd->b * pd->h * (pd->d + 1) * sizeof(float) : 0);
 }
 
 template <typename T> static int launch_hybrid_t(const vattn_attn_params* pp, const vattn_attn_params* pd, void* ws, hipStream_t st) {
     const int gblocks = (pd->h / pd->h_k + 15) / 16;
     const int ds = hybrid_decode_splits(pd, gblocks);
     vattn_attn_params d2 = *pd;
-    d2.workspace = (char*)ws + hybrid_ctl_bytes(pd, gblocks);
+    d2.workspace = (char*)ws + hybrid_ctl_bytes();
+    if ((long)pd->b * pd->h_k * gblocks > HY_DONE_CAP) return fail(VATTN_K_ERR_UNSUPPORTED, "hybrid launch: more than 65536 (sequence, kv head, head block) decode groups");
     const int nqb = (pp->seqlen_q + 127) / 128;
     const long n_pre = (long)nqb * pp->b * pp->h, n_dec = (long)pd->b * pd->h_k * gblocks * ds;
     if (n_pre > 0x7fffffffL / 2 || n_dec > 0x7fffffffL / 2) return fail(VATTN_K_ERR_INVALID, "hybrid batch too large for the 32-bit work queues");

@@ -73,6 +73,7 @@ int PageManager::init() {
     mapped_pages_.assign(cfg_.max_batch_size, 0);
     lens_.assign(cfg_.max_batch_size, 0);
     reserved_.assign(cfg_.max_batch_size, 0);
+    inherited_.assign(cfg_.max_batch_size, 0);
 
     const int nt = cfg_.megacache ? 2 : 2 * (int)cfg_.num_layers;
     const uint64_t align = std::max<uint64_t>(cfg_.page_size, rec_gran);
@@ -164,10 +165,11 @@ int PageManager::plan_map_pair(int r, uint32_t layer, uint64_t off) {      // mu
     return VATTN_OK;
 }
 
-void PageManager::plan_unmap_pair(int r, uint32_t layer, uint64_t off) {   // mux.h:51-66
-    // a FREED slot's pages may still be read by kernels launched before the free: fence (or quiesce) before the unmap; an
-    // ACTIVE slot is only ever shrunk to the pages its current length needs, which no kernel in flight reads beyond
-    const uint8_t fence = active(r) ? 0 : 1;
+void PageManager::plan_unmap_pair(int r, uint32_t layer, uint64_t off, bool inherited) {   // mux.h:51-66
+    // a FREED slot's pages may still be read by kernels launched before the free: fence (or quiesce) before the unmap — and so may
+    // the pages a re-activated slot INHERITED from its previous occupant (`inherited`, see inherited_).  Pages mapped for an ACTIVE
+    // slot's current occupant only go when its current length no longer needs them, and no kernel in flight reads beyond that.
+    const uint8_t fence = (!active(r) || inherited) ? 1 : 0;
     auto key = std::make_tuple((uint64_t)r, off, (uint64_t)layer);
     auto it = pagemap_.find(key);
     const uint32_t k = it != pagemap_.end() ? it->second.first : 0, v = it != pagemap_.end() ? it->second.second : 0;
@@ -182,12 +184,14 @@ void PageManager::plan_unmap_pair(int r, uint32_t layer, uint64_t off) {   // mu
 
 void PageManager::unmap_req_page_one(int r) {    // vattention.cu:219-241, utils.h:193-204
     const uint64_t off = (uint64_t)r * virt_per_req_ + (mapped_pages_[r] - 1) * cfg_.page_size;
+    const bool inherited = mapped_pages_[r] - 1 < inherited_[r];
     if (cfg_.megacache) {
-        plan_unmap_pair(r, 0, off);
+        plan_unmap_pair(r, 0, off, inherited);
     } else {
-        for (uint32_t l = 0; l < cfg_.num_layers; l++) plan_unmap_pair(r, l, off);
+        for (uint32_t l = 0; l < cfg_.num_layers; l++) plan_unmap_pair(r, l, off, inherited);
     }
     mapped_pages_[r]--;
+    if (inherited_[r] > mapped_pages_[r]) inherited_[r] = mapped_pages_[r];
     if (!shared_.empty()) forget_shared_holder(r, mapped_pages_[r]);
 }
 
@@ -417,6 +421,7 @@ int PageManager::step_async(const uint64_t* lens, uint32_t n) {   // vattention.
             }
             return rc;
         }
+        layered_now_ = std::move(now);                   // mapper idle (joined above) and state_mu_ held: nobody reads it now
         layered_error_.store(0);
         layers_ready_.store(sync_layers_, std::memory_order_release);
         layered_pending_.store(1, std::memory_order_release);
@@ -445,9 +450,9 @@ int PageManager::wait_layer(uint32_t layer) {
         layer_cv_.wait(l, [&] { return layers_ready_.load(std::memory_order_acquire) > layer || !layered_pending_.load(); });
         layer_wait_ns_ += now_ns() - t0;
     }
-    const int e = layered_error_.load();
-    if (e) last_error_ = "layer-ordered mapping failed on the mapper thread (see the next step's error)";
-    return e;
+    // (no message is written here: last_error_ belongs to the calls that hold state_mu_, and the engine thread may be inside
+    // one of them; the C entry point reports a fixed text for this code, the next step()/wait() reports the driver's message)
+    return layered_error_.load();
 }
 
 uint32_t PageManager::layers_ready() {
@@ -497,7 +502,8 @@ int PageManager::premap(uint64_t seqlen) {
     }
     if (slot < 0) return -1;
     reserved_[slot] = 1;
-    if (be_.fence_record) be_.fence_record(be_.ctx, (uint32_t)slot, nullptr);      // a new occupant: the previous one's fence is void
+    // (the previous occupant's fence stays: it still guards the pages this slot inherits — inherited_ — until they are unmapped or
+    // the next free records a new one; pages mapped from here on have no reader before the slot is activated)
     if (required > mapped_pages_[slot] && required <= max_pages_per_req_) {
         const uint64_t need = required - mapped_pages_[slot];
         // pool dry: take the pages from finished, unreserved slots HERE — the unmaps (and the wait for those slots' fences) then
@@ -525,6 +531,7 @@ int PageManager::free_batch_idx(int slot, void* stream, bool with_fence) {   // 
     if (slot < 0 || slot >= (int)cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "slot out of range");
     lens_[slot] = 0;
     reserved_[slot] = 0;
+    inherited_[slot] = mapped_pages_[slot];             // whoever gets the slot next inherits these, possibly still being read
     // the point in the engine's stream after the last kernel that can read this slot's pages (plain free: no fence, a later
     // reclaim of the slot then synchronises the whole device)
     if (be_.fence_record && be_.fence_record(be_.ctx, (uint32_t)slot, with_fence ? (stream ? stream : (void*)-1) : nullptr) != 0)
@@ -909,6 +916,14 @@ int PageManager::wait_locked_free() {   // state_mu_ held; joins every queued ba
             failed.swap(failed_ops_);
             failed_at = failed_at_;
             have_failed_ = false;
+            if (failed_layered_) {
+                // the groups' first layers were mapped synchronously by step_async: they go back with the rest (otherwise they
+                // stay mapped in the driver and in pagemap_ under a slot whose mapped_pages_ no longer covers them — the next
+                // grow at that position would map over them and fail for good)
+                failed.insert(failed.begin(), layered_now_.begin(), layered_now_.end());
+                failed_at += layered_now_.size();
+                failed_layered_ = false;
+            }
         }
         e = async_error_;
         if (e) last_error_ = async_error_msg_;
@@ -985,6 +1000,7 @@ void PageManager::mapper_main() {
                 failed_ops_ = std::move(ops);
                 failed_at_ = failed_at;
                 have_failed_ = true;
+                failed_layered_ = layered;
             }
             inflight_--;
             if (inflight_ == 0) done_cv_.notify_all();

@@ -92,6 +92,11 @@ private:
     struct SharedGroup { std::vector<std::pair<uint32_t, uint64_t>> holders; };   // (slot, page position inside the slot)
     std::vector<SharedGroup> shared_;
     std::vector<uint8_t> reserved_;                               // slots handed out by premap() and not yet activated / freed
+    // inherited_[r]: the first inherited_[r] page positions of slot r were mapped when the slot was last FREED — kernels of the
+    // previous occupant launched before that free may still read them (the engine frees right after launching its last iteration),
+    // also after the slot has been handed to a new request.  Unmapping one of them needs the slot's fence (or a quiesce) whatever
+    // the slot's current state; positions at or above it were mapped for the current occupant and follow the active-slot rule.
+    std::vector<uint64_t> inherited_;
     std::atomic<int> fatal_{0};                                   // sticky: a failed unmap / set-access / TLB invalidation
     std::mutex state_mu_;
     std::vector<PhysOp> plan_;
@@ -108,7 +113,7 @@ private:
 
     // ---- planners (each mirrors one reference routine) ----
     int plan_map_pair(int r, uint32_t layer, uint64_t off);
-    void plan_unmap_pair(int r, uint32_t layer, uint64_t off);
+    void plan_unmap_pair(int r, uint32_t layer, uint64_t off, bool inherited);
     void drop_mapping(uint32_t page);          // refcount--, back to the pool at zero
     void forget_shared_holder(int r, uint64_t pos);
     void rollback_maps(const std::vector<PhysOp>& ops, size_t first_failed);   // state_mu_ held
@@ -155,6 +160,9 @@ private:
     std::vector<PhysOp> failed_ops_;
     size_t failed_at_ = 0;
     bool have_failed_ = false;
+    bool failed_layered_ = false;                // the failed batch was the mapper's half of a layer-ordered step
+    std::vector<PhysOp> layered_now_;            // the synchronous half (layers [0, sync_layers)) of the layer-ordered batch in flight:
+                                                 // a failure of the mapper's half takes the WHOLE page-groups back, these included
     std::atomic<int> fg_waiting_{0};             // a foreground flush wants exec_mu_: the idle pre-creation loop backs off
     // VATTN_FLAG_LAYERED_ASYNC
     uint32_t sync_layers_ = 2;

@@ -30,7 +30,7 @@ from . import kernels as K
 
 APPEND_ERR = "If key is supplied, it must have seqlen <= the seqlen of the KV cache"
 _workspaces = {}
-_rotary_cat = {}      # (cos ptr, sin ptr) -> the [S, rotary_dim] cat(cos, sin) tensor the kernels read
+_rotary_cat = {}      # (id(cos), id(sin), versions, dtype) -> (cos, sin, the [S, rotary_dim] cat(cos, sin) tensor the kernels read)
 
 
 def _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q):
@@ -41,13 +41,15 @@ def _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q
             raise NotImplementedError("fused rotary embedding implements the NeoX pairing only (pass rotary_interleaved=False)")
         if rotary_cos is None or rotary_sin is None:
             raise RuntimeError("rotary_cos and rotary_sin must be given together")
-        key = (rotary_cos.data_ptr(), rotary_sin.data_ptr(), tuple(rotary_cos.shape))
-        t = _rotary_cat.get(key)
-        if t is None:
+        # the entry holds the source tensors (their ids / addresses cannot be recycled while it lives) and is keyed on their
+        # versions (an in-place update of the tables makes a new entry) and on the query dtype
+        key = (id(rotary_cos), id(rotary_sin), rotary_cos._version, rotary_sin._version, q.dtype)
+        ent = _rotary_cat.get(key)
+        if ent is None:
             if len(_rotary_cat) > 8:
                 _rotary_cat.clear()
-            t = _rotary_cat[key] = torch.cat((rotary_cos, rotary_sin), dim=-1).to(q.dtype).contiguous()
-        _rotary_cos_sin = t
+            ent = _rotary_cat[key] = (rotary_cos, rotary_sin, torch.cat((rotary_cos, rotary_sin), dim=-1).to(q.dtype).contiguous())
+        _rotary_cos_sin = ent[2]
     t = _rotary_cos_sin
     if t.dtype != q.dtype or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
         raise RuntimeError("rotary cos/sin table must be a [positions, rotary_dim] GPU tensor of the query's dtype")

@@ -93,7 +93,9 @@ class PageManager:
         self._check(self._lib.vattn_cancel_premap(self._h, int(slot)))
 
     def wait_layer(self, layer: int) -> None:
-        self._check(self._lib.vattn_wait_layer(self._h, int(layer)))
+        if self._lib.vattn_wait_layer(self._h, int(layer)) != L.VATTN_OK:
+            # (vattn_wait_layer does not touch the manager's message buffer: include/vattn.h)
+            raise RuntimeError("layer-ordered mapping failed on the mapper thread; the next step()/wait() reports the driver's error")
 
     def layers_ready(self) -> int:
         return int(self._lib.vattn_layers_ready(self._h))

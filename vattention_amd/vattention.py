@@ -172,6 +172,17 @@ def wait_layer(layer_id: int) -> None:
 
 
 
+def wait_all_layers() -> None:
+    """Block until EVERY layer's pages of the current step are mapped.  What a caller that does not know its layer index must use
+    (the reference's yi / mistral / qwen / falcon / internlm models call wrapper.forward() with layer_id=None; only llama.py:179-186
+    passes it): the first such call of an iteration pays the whole wait, the following ones return at once."""
+    global _layered_pending
+    if not _layered_pending or _pm is None:
+        return
+    _pm.wait_layer(_pm.cfg.num_layers - 1)
+    _layered_pending = False
+
+
 def wait() -> None:
     """Join outstanding background mapping (the next step()/step_async() does this implicitly)."""
     _require().wait()
