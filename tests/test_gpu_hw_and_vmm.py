@@ -126,7 +126,7 @@ def test_sync_oom_raises_runtime_error():
 
 def test_remap_same_va_is_visible_to_kernels():
     """ROCm 7.2 / gfx950 keeps stale GPU translations after hipMemUnmap (+ hipMemMap of another handle at
-    the same VA) until the driver services an allocation (tools/remap_probe3/4.cpp).  The manager issues a
+    the same VA) until the driver services an allocation (tools/remap_probe4.cpp).  The manager issues a
     TLB invalidation after every batch that unmapped something; without it this test reads stale data and
     writes through stale translations corrupt pages that moved to other slots."""
     from vattention_amd import vattention
