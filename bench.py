@@ -14,20 +14,26 @@ Workload by --gpus N (one rank per GPU; `python bench.py --gpus N` spawns the ra
   N = 2  configs[3]: Yi-34B TENSOR-PARALLEL over 2 GPUs (28 query / 4 kv heads per rank, 60 layers), static trace @ 128k, P:D = 500,
          Sarathi 16k chunks (run_figure_6.sh:32-33).  One step = one 131 072-token request end to end.
   N = 4  the same request on a TP = 4 shard of Yi-34B (14 / 2 heads per rank).
-  N = 8  configs[4]: Llama-3-70B TP = 8 (8 / 1 heads per rank, 80 layers), dynamic arxiv trace; one step = a closed-loop replay of the
-         first 48 requests of the reference's length recipe (tests/golden/c3_arxiv_lengths_256.json), max_batch_size 256, megacache
-         layout with 8 MiB pages (the configured 256 KiB pages need one hipMemCreate handle per page: O(live handles)).
+  N = 8  configs[4]: Llama-3-70B TP = 8 (8 / 1 heads per rank, 80 layers), dynamic arxiv trace: one step = a closed-loop replay of ALL
+         256 requests of the reference's length recipe (tests/golden/c3_arxiv_lengths_256.json; decode lengths capped at 768 tokens,
+         stated in config.workload), max_batch_size 256, pool = 0.9 x HBM - 12 GiB per rank, megacache layout with 8 MiB pages (the
+         configured 256 KiB pages need one hipMemCreate handle per page: O(live handles)).
   For N > 1 every rank processes the SAME requests with its head shard (sarathi/config.py:139-167); there is no data-path
   collective.  Inside the timed loop every iteration does the control-plane exchange of the reference engine over RCCL:
   all-reduce MIN of num_free_kvblocks() (base_llm_engine.py:381-390) and an all-gather of a fingerprint of the page-manager state,
   checked at the end of the step (identical page decisions on every rank).  value = tokens of ONE request stream / max-rank time.
 
-Extra objects on the JSON line (N = 1): `roofline` (dominant kernel: causal prefill attention, MFMA-bound: algorithmic flops per
-launch / mean launch duration from HIP events on the launch stream inside the timed region), `roofline_decode` (HBM-bound split-KV
-decode, same method), `cold_wave` (the first wave on a fresh pool: handle creation, synchronous vs mapper-thread mapping),
-`dynamic` (256-request arxiv replay, all 32 layers of Llama-3-8B: peak concurrency, fragmentation, mapping cost), `cpu_baseline`
-(the CPU oracle — kind "port" — timed on the real shapes of this workload: one layer of a decode step at 32k and the last
-512 query rows of the 32 702-token prefill, scaled by the stated law).
+Every line (every N, static or dynamic) carries:
+  `roofline`          the kernel with the largest summed time on this rank: ALGORITHMIC work of the timed launches / their summed
+                      duration, from HIP events on the launch stream inside the timed region (every launch for the static
+                      workloads, every 8th for the dynamic replay, whose launches are ragged: work is accounted per launch);
+  `roofline_prefill` / `roofline_decode`  the same for each of the two attention kernels;
+  `cpu_baseline`      the CPU oracle (kind "port": oracle/attn.py, the reference kernel's numerics in torch fp32) timed on a bounded
+                      sample of THIS workload's per-rank shapes on the host cores, scaled to the whole job by the counted
+                      (query row, visible key) pairs of the timed steps.
+N = 1 adds, outside the timed region: `cold_wave`, `full_trace_50req`, `dynamic` (configs[2] shape, closed loop, time-weighted KV
+utilisation), `dynamic_tp8_rank` (the TP8 rank shape: 256 sequences resident at full depth, deferred reclamation on / off),
+`open_loop` (Poisson arrivals at qps = 6 on a virtual clock), `capacity` (grow until the reference's OOM error).
 """
 from __future__ import annotations
 
@@ -55,12 +61,14 @@ WORKLOADS = {
     4: dict(model="yi-34b", tp=4, ctx=131072, pd=500.0, batch=4, chunk=16384, page=2 << 20, mode="static", requests=1, backend="fa_vattn",
             label="yi-34b TP=4 shard (14/2 heads per rank, 60 layers) of configs[3]'s request: static @ 131072 ctx, P:D=500, 16k chunks; "
                   "one step = one request"),
-    8: dict(model="llama-3-70b", tp=8, ctx=32768, pd=0.0, batch=256, chunk=0, page=8 << 20, mode="dynamic", requests=48, backend="fa_vattn_megacache",
+    8: dict(model="llama-3-70b", tp=8, ctx=32768, pd=0.0, batch=256, chunk=0, page=8 << 20, mode="dynamic", requests=256, backend="fa_vattn_megacache",
             decode_cap=768,
-            label="configs[4]: llama-3-70b TP=8 (8/1 heads per rank, 80 layers) dynamic arxiv trace, closed loop; one step = the first 48 "
-                  "requests of the reference's length recipe (decode lengths capped at 768 tokens: one of the 48 has 6129, which would leave "
-                  "5000 batch-1 iterations at the end of every step), max_batch_size 256, megacache layout with 8 MiB pages (stands in for 256 KiB pages)"),
+            label="configs[4]: llama-3-70b TP=8 (8/1 heads per rank, 80 layers) dynamic arxiv trace, closed loop; one step = ALL 256 requests of "
+                  "the reference's length recipe (decode lengths capped at 768 tokens: a handful of the 256 run to 6 k tokens and would leave "
+                  "thousands of batch-1 iterations at the end of every step), max_batch_size 256, pool = 0.9 x HBM - 12 GiB per rank, "
+                  "megacache layout with 8 MiB pages (stands in for 256 KiB pages)"),
 }
+TIMER_EVERY = {"static": 1, "dynamic": 8}       # time every k-th launch of each attention operation
 
 
 def parse():
@@ -69,11 +77,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dynamic", action="store_true", help="skip the dynamic-trace and full-trace legs (N = 1)")
+    ap.add_argument("--no-dynamic", action="store_true", help="skip the legs outside the timed region (N = 1)")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; makes the number INVALID)")
     ap.add_argument("--ctx", type=int, default=0, help="override context length (debug only; makes the number INVALID)")
+    ap.add_argument("--requests", type=int, default=0, help="override requests per step (debug only; makes the number INVALID)")
     ap.add_argument("--rank-of", type=int, default=0, help="debug: run ONE rank's share of the --gpus N workload of this value on a single GPU, "
                     "without the collectives (checks the tensor-parallel workloads where only one GPU is visible; NOT a bench line)")
+    ap.add_argument("--qps", type=float, default=0.0, help="run ONLY the open-loop replay (Poisson arrivals, reference recipe) at this rate and print it")
     return ap.parse_args()
 
 
@@ -90,38 +100,73 @@ def spawn_ranks(a) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(dtype, L, Hq, Hkv, D, prefill, decode_iters, batch) -> dict:
-    """The CPU oracle (oracle/attn.py, math='f32' = the reference kernel's numerics) on the REAL shapes of configs[1], one layer:
-    (a) one batch-`batch` decode step at 32k context; (b) the last 512 query rows of the 32 702-token causal prefill.
-    Attention work per query row is proportional to the keys it sees, so the whole prefill costs
-    t_b x [n(n+1)/2] / [sum of (i+1) over the sampled rows]; tokens/s is quoted for the whole model (x L layers)."""
+def cpu_rates(dtype, Hq, Hkv, D, keys, budget_head_pairs=0.42e9) -> dict:
+    """The CPU oracle (oracle/attn.py, math='f32' = the reference kernel's numerics) on this workload's per-rank head shape:
+    (a) prefill form — the LAST `rows` query rows of a `keys`-token causal prompt (rows chosen so that the sample is about
+    budget_head_pairs (query row, key, query head) triples: 10-15 s on this class of host); (b) decode form — one step of two
+    sequences at `keys` context.  Returns head-pairs per second for both forms."""
     import torch
     from oracle.attn import flash_attn_with_kvcache_ref
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    n, rows = prefill, 512
+    n = keys
+    rows = int(max(32, min(512, budget_head_pairs / (n * Hq))))
     k = torch.randn(1, n + 8, Hkv, D).to(dtype)
     v = torch.randn(1, n + 8, Hkv, D).to(dtype)
     q = torch.randn(1, rows, Hq, D).to(dtype)
     t0 = time.perf_counter()
-    flash_attn_with_kvcache_ref(q, k, v, cache_seqlens=n, causal=True, math="f32")      # rows [n - 2048, n) over keys [0, n)
+    flash_attn_with_kvcache_ref(q, k, v, cache_seqlens=n, causal=True, math="f32")      # rows [n - rows, n) over keys [0, n)
     t_blk = time.perf_counter() - t0
-    law = (n * (n + 1) / 2.0) / sum(i + 1 for i in range(n - rows, n))
-    t_prefill_layer = t_blk * law
+    pairs_blk = sum(i + 1 for i in range(n - rows, n)) * Hq
     kd = torch.randn(2, n + 8, Hkv, D).to(dtype)
     vd = torch.randn(2, n + 8, Hkv, D).to(dtype)
     qd = torch.randn(2, 1, Hq, D).to(dtype)
     t0 = time.perf_counter()
     flash_attn_with_kvcache_ref(qd, kd, vd, cache_seqlens=torch.tensor([n, n + 4], dtype=torch.int32), causal=True, math="f32")
-    t_dec_seq = (time.perf_counter() - t0) / 2.0                                       # per sequence per layer at 32k
-    t_request = L * (t_prefill_layer + decode_iters * t_dec_seq)
-    tokens = prefill + 1 + decode_iters
-    return {"value": round(tokens / t_request, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": "CPU oracle (torch fp32 math on fp16 inputs, %d threads) on configs[1]'s real shapes, one layer: last %d query rows "
-                      "of the %d-token causal prefill (%.2f s; whole prefill = x %.2f by the keys-seen law) and one decode step of 2 "
-                      "sequences at 32k (%.3f s per sequence); tokens/s = (%d tokens per request) / (%d layers x [prefill + %d decode "
-                      "steps])" % (cores, rows, n, t_blk, law, t_dec_seq, tokens, L, decode_iters)}
+    t_dec = time.perf_counter() - t0
+    pairs_dec = (2 * n + 4 + 2) * Hq
+    return {"cores": cores, "rows": rows, "keys": n, "t_prefill_sample": t_blk, "t_decode_sample": t_dec,
+            "prefill_head_pairs_per_s": pairs_blk / t_blk, "decode_head_pairs_per_s": pairs_dec / t_dec}
+
+
+def cpu_baseline(dtype, L, Hq, Hkv, D, keys, world, tokens, prefill_pairs, decode_pairs, what) -> dict:
+    """tokens/s the CPU oracle would reach on the WHOLE job of the timed steps: all `world` head shards, L layers, the (query row,
+    visible key) pairs the replay counted (replay.ReplayStats.prefill_pairs / decode_pairs, per layer and per query head), at the
+    head-pair rates measured on this workload's per-rank shape."""
+    r = cpu_rates(dtype, Hq, Hkv, D, keys)
+    t_job = world * L * Hq * (prefill_pairs / r["prefill_head_pairs_per_s"] + decode_pairs / r["decode_head_pairs_per_s"])
+    return {"value": round(tokens / t_job, 3), "unit": "tokens/s", "cores": r["cores"], "kind": "port",
+            "sample": "CPU oracle (oracle/attn.py, torch fp32 math on fp16 inputs, %d threads) on %s's per-rank shape (%d/%d heads, d %d): last "
+                      "%d query rows of a %d-token causal prompt (%.2f s -> %.3g head-pairs/s) and one decode step of 2 sequences at %d "
+                      "keys (%.3f s -> %.3g head-pairs/s); whole job = %d shard(s) x %d layers x %d heads x (%.4g prefill + %.4g decode "
+                      "pairs of the timed steps) = %.0f s of CPU time for %d tokens" % (
+                          r["cores"], what, Hq, Hkv, D, r["rows"], r["keys"], r["t_prefill_sample"], r["prefill_head_pairs_per_s"], r["keys"],
+                          r["t_decode_sample"], r["decode_head_pairs_per_s"], world, L, Hq, prefill_pairs, decode_pairs, t_job, tokens)}
+
+
+def rooflines(detail: dict, traffic=None) -> dict:
+    """roofline objects from the op-timer records (attention/timers.py): achieved = algorithmic work of the TIMED launches / their
+    summed duration; the dominant kernel is the one with the larger estimated total time."""
+    out = {}
+    spec = {"attn_prefill": ("prefill", "prefill attention (causal chunk(s) against the KV prefix; prefill64_kernel / prefill_kernel + combine), per rank",
+                             "mfma", MFMA_PEAK_TFLOPS, "TFLOP/s", 1e12, "flops"),
+            "attn_decode": ("decode", "decode_kernel + combine_kernel (split-KV decode with in-kernel append), per rank", "hbm", HBM_PEAK_GBS, "GB/s", 1e9, "bytes")}
+    est = {}
+    for op, (short, name, bound, peak, unit, div, wname) in spec.items():
+        d = detail.get(op)
+        if not d or not d["timed"] or d["ms"] <= 0:
+            continue
+        ach = d["work"] / (d["ms"] * 1e-3) / div
+        est[short] = d["ms"] * d["n"] / d["timed"]
+        out["roofline_" + short] = {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                                    "frac": round(ach / peak, 4), "traffic": (traffic or {}).get(short),
+                                    "ms_per_launch": round(d["ms"] / d["timed"], 4), wname + "_per_launch": d["work"] / d["timed"],
+                                    "launches": d["n"], "launches_timed": d["timed"], "est_total_ms": round(est[short], 1)}
+    if est:
+        dom = max(est, key=est.get)
+        out["roofline"] = dict(out["roofline_" + dom], dominant_of=sorted(est))
+    return out
 
 
 def main():
@@ -157,16 +202,19 @@ def main():
             dist.init_process_group(backend)
 
     from vattention_amd import vattention
-    from vattention_amd.attention.timers import drain_op_timers, enable_op_timers
+    from vattention_amd.attention.timers import drain_op_timers_detail, enable_op_timers
     from vattention_amd.replay import CacheConfig, HotPathRunner, ModelConfig, ParallelConfig
 
     if a.rank_of and (world != 1 or a.rank_of not in WORKLOADS):
         raise SystemExit("--rank-of needs --gpus 1 and one of %s" % sorted(WORKLOADS))
-    w = dict(WORKLOADS[a.rank_of or world])
+    shard_of = a.rank_of or world                            # tensor-parallel degree of the workload this process runs a rank of
+    w = dict(WORKLOADS[shard_of])
     if a.ctx:
         w["ctx"] = a.ctx
+    if a.requests:
+        w["requests"] = a.requests
     dtype = torch.float16                                    # benchmark_runner.py:81
-    valid = not (a.layers or a.ctx or a.rank_of)
+    valid = not (a.layers or a.ctx or a.rank_of or a.requests)
 
     def make_runner(model_name, tp, ctx, page, batch, backend_name, mem_bytes, layers=0):
         model = ModelConfig.named(model_name, dtype=dtype, max_model_len=ctx, attention_backend=backend_name)
@@ -179,15 +227,16 @@ def main():
     share = world if backend != "nccl" else 1               # test hook: ranks share a device
     # memory_for_gpu = total*0.9 - peak of the (absent) model body; keep 12 GiB for activations / workspace
     mem_for_kv = (min(int(total_b * 0.9), free_b) - (12 << 30)) // share
-    if w["mode"] == "dynamic":
-        mem_for_kv = min(mem_for_kv, 96 << 30)               # the 48-request slice needs ~25 GiB per rank; bounds handle creation
+    lengths256 = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_arxiv_lengths_256.json")))["requests"]
+    cap = lambda ls, c: [[pre, min(dec, c)] for pre, dec in ls]
+
+    if a.qps:       # stand-alone open-loop replay (not a bench line)
+        print(json.dumps(open_loop_leg(make_runner, mem_for_kv, lengths256, a.qps, a.requests or 256)), flush=True)
+        return
+
     runner = make_runner(w["model"], w["tp"], w["ctx"], w["page"], w["batch"], w["backend"], mem_for_kv, a.layers)
     Hq, Hkv, D, L = runner.Hq, runner.Hkv, runner.D, runner.L
-    lengths = None
-    if w["mode"] == "dynamic":
-        lengths = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_arxiv_lengths_256.json")))["requests"]
-        if w.get("decode_cap"):
-            lengths = [[pre, min(dec, w["decode_cap"])] for pre, dec in lengths]
+    lengths = cap(lengths256, w["decode_cap"]) if w["mode"] == "dynamic" and w.get("decode_cap") else lengths256
 
     # ---- control plane of a tensor-parallel engine, every iteration, over RCCL (no host synchronisation inside the step) ----
     ctl = {"iters": 0, "log": None, "ok": None}
@@ -210,12 +259,16 @@ def main():
             ctl["iters"] += 1
         runner.iter_hook = iter_hook
 
+    pairs = {"pf": 0.0, "dc": 0.0}
+
     def one_step():
         runner.stats.__init__()
         if w["mode"] == "static":
             runner.run_static_trace(w["requests"], w["ctx"], w["pd"], w["chunk"] or None)
         else:
             runner.run_dynamic_trace(w["requests"], lengths=lengths)
+        pairs["pf"] += runner.stats.prefill_pairs
+        pairs["dc"] += runner.stats.decode_pairs
         return runner.stats.prefill_tokens + runner.stats.decode_tokens
 
     def barrier():
@@ -243,24 +296,25 @@ def main():
                     "sync_share_of_map_time": round(d("sync_ns") / 1e6 / tot_map_ms, 4) if tot_map_ms else None,
                     "layer_wait_ms": round(d("layer_wait_ns") / 1e6, 2), "join_wait_ms": round(d("join_wait_ns") / 1e6, 2)}
     vm0 = vattention.stats()
-    enable_op_timers(w["mode"] == "static")      # per-op HIP events feed the roofline objects (static workloads); the dynamic replay's
-    barrier()                                    # half a million tiny launches per step are not slowed down by them
+    pairs["pf"] = pairs["dc"] = 0.0
+    enable_op_timers(True, every=TIMER_EVERY[w["mode"]])      # HIP events on the launch stream, inside the timed region
+    barrier()
     t0 = time.perf_counter()
     tokens = 0
     for _ in range(a.steps):
         tokens += one_step()
     barrier()
     dt = time.perf_counter() - t0
-    op_ms = drain_op_timers()
+    detail = drain_op_timers_detail()
     enable_op_timers(False)
     vm1 = vattention.stats()
     kv_util = list(runner.stats.kv_util_samples)
     kv_map = list(runner.stats.mapped_over_reserved)
+    peak_running = None
     if cold is not None:
         cold["warm_step_ms"] = round(dt * 1e3 / a.steps, 1)
 
     tp_check = None
-    per_rank_pf = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -270,56 +324,30 @@ def main():
         if not tp_check["identical_page_decisions_on_all_ranks"]:
             raise SystemExit("tensor-parallel ranks diverged in their page-manager state")
 
-    # ---- roofline of the dominant kernels, from events recorded inside the timed region ----
-    decode_tok = math.ceil(w["ctx"] / (1 + w["pd"])) if w["mode"] == "static" else 0
-    prefill_tok = w["ctx"] - decode_tok
-    roof = roof_dec = None
-    if w["mode"] == "static":
-        chunk = w["chunk"] or prefill_tok
-        n_chunks = math.ceil(prefill_tok / chunk)
-        flops_total, c = 0.0, 0
-        for i in range(n_chunks):
-            n = min(chunk, prefill_tok - c)
-            flops_total += 4.0 * Hq * D * (n * c + n * (n + 1) / 2)
-            c += n
-        launches_pf = a.steps * w["requests"] * n_chunks * L
-        flops_per_launch = flops_total / n_chunks
-        pf_ms = op_ms.get("attn_prefill", 0.0) / max(1, launches_pf)
-        pf_tflops = flops_per_launch / (pf_ms * 1e-3) / 1e12 if pf_ms > 0 else 0.0
-        dec_iters = decode_tok - 1
-        nb = min(w["requests"], w["batch"])
-        launches_dc = a.steps * dec_iters * L
-        mean_len = prefill_tok + 1 + (dec_iters - 1) / 2.0
-        bytes_dc = nb * (2 * mean_len * Hkv * D * 2) + nb * Hq * D * 2 * 2
-        dc_ms = op_ms.get("attn_decode", 0.0) / max(1, launches_dc)
-        dc_gbs = bytes_dc / (dc_ms * 1e-3) / 1e9 if dc_ms > 0 else 0.0
-        traffic_pf = traffic_dc = None
-        try:       # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 note); configs[1] only
-            for name in ("r02_traffic.json", "r01_traffic.json"):
-                pth = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(pth) and world == 1 and valid:
-                    tj = json.load(open(pth))
-                    traffic_pf = tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"]
-                    traffic_dc = tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"]
-                    break
-        except Exception:
-            pass
-        if dist is not None:
-            g = torch.tensor([pf_ms], dtype=torch.float64, device=red_dev)
+    # ---- roofline of the attention kernels, from events recorded inside the timed region ----
+    traffic = None
+    try:       # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 note); configs[1] only
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+            pth = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pth) and world == 1 and valid:
+                tj = json.load(open(pth))
+                traffic = {"prefill": tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"], "decode": tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"]}
+                break
+    except Exception:
+        traffic = None
+    roofs = rooflines(detail, traffic)
+    if dist is not None and "roofline" in roofs:      # the same kernel's mean launch time on every rank
+        for key in ("roofline_prefill", "roofline_decode"):
+            mine = roofs.get(key, {}).get("ms_per_launch", 0.0)
+            g = torch.tensor([mine], dtype=torch.float64, device=red_dev)
             gl = [torch.zeros_like(g) for _ in range(world)]
             dist.all_gather(gl, g)
-            per_rank_pf = [round(float(x.item()), 4) for x in gl]
-        roof = {"kernel": "prefill attention (causal chunk against the KV prefix), per rank", "bound": "mfma", "achieved": round(pf_tflops, 2),
-                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pf_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic_pf,
-                "ms_per_launch": round(pf_ms, 4), "flops_per_launch": flops_per_launch}
-        if per_rank_pf:
-            roof["ms_per_launch_by_rank"] = per_rank_pf
-        roof_dec = {"kernel": "decode_kernel+combine (split-KV decode, batch %d), per rank" % nb, "bound": "hbm", "achieved": round(dc_gbs, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dc_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_dc,
-                    "ms_per_launch": round(dc_ms, 4), "bytes_per_launch": bytes_dc}
+            if key in roofs:
+                roofs[key]["ms_per_launch_by_rank"] = [round(float(x.item()), 4) for x in gl]
+    op_ms = {k: round(v["ms"] * (v["n"] / v["timed"] if v["timed"] else 0.0), 2) for k, v in detail.items()}
 
     # ---- N = 1 extras, outside the timed region ----
-    full_trace = dynamic = None
+    extras = {}
     if world == 1 and valid and not a.no_dynamic:
         torch.cuda.synchronize()
         runner.stats.__init__()
@@ -328,37 +356,16 @@ def main():
         torch.cuda.synchronize()
         dt_f = time.perf_counter() - t1
         tk_f = runner.stats.prefill_tokens + runner.stats.decode_tokens
-        full_trace = {"requests": 50, "tokens": tk_f, "seconds": round(dt_f, 3), "tokens_per_s": round(tk_f / dt_f, 1)}
+        extras["full_trace_50req"] = {"requests": 50, "tokens": tk_f, "seconds": round(dt_f, 3), "tokens_per_s": round(tk_f / dt_f, 1)}
         runner.close()
         runner = None
-        # configs[2]'s shape: Llama-3-8B, ALL 32 layers, 256 requests of the reference's arxiv length recipe, max_batch_size 256, closed
-        # loop.  Megacache layout with 8 MiB pages (128 tokens per page): configs[2]'s 64 KiB pages would need 4 M hipMemCreate
-        # handles for this pool, and even 2 MiB megacache pages 120 k — handle creation is O(live handles) on ROCm.
-        lengths256 = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_arxiv_lengths_256.json")))["requests"]
-        r2 = make_runner("llama-3-8b", 1, 32768, 8 << 20, 256, "fa_vattn_megacache", mem_for_kv)
-        try:
-            out = r2.run_dynamic_trace(256, lengths=lengths256)
-            # synchronous batches = driver calls on the engine thread (maps / unmaps / set-access / creations / TLB invalidation) PLUS,
-            # before an unmap, the wait for the fence of the slot that gives the page up (the GPU has to reach the point where
-            # that request finished: not mapping work; it moves to the mapper thread when the look-ahead does the reclaim)
-            sb = out.get("sync_breakdown") or {}
-            fence_ms = float(sb.get("fence_ms", 0.0))
-            sync_calls_ms = max(0.0, out["sync_map_ms"] - fence_ms)
-            tot = sync_calls_ms + out["async_map_ms"]
-            dynamic = {"workload": "configs[2] shape: llama-3-8b, 32 layers, 256 arxiv-length requests closed loop, max_batch_size 256, "
-                                   "megacache 8 MiB pages (128 tokens per page), pool = 0.9 x HBM - 12 GiB",
-                       "peak_concurrent_sequences": out["peak_running"], "tokens": out["tokens"], "seconds": round(out["seconds"], 2),
-                       "tokens_per_s": round(out["tokens_per_s"], 1),
-                       "kv_live_over_needed_at_peak": out["kv_live_over_needed_at_peak"], "kv_live_over_mapped_mean": round(out["kv_live_over_mapped_mean"], 4),
-                       "external_fragmentation": 0.0, "map_calls": out["map_calls"], "unmap_calls": out["unmap_calls"],
-                       "handles_created": out.get("handles_created"), "create_ms": out.get("create_ms"),
-                       "sync_map_ms": round(sync_calls_ms, 1), "sync_fence_wait_ms": round(fence_ms, 1),
-                       "mapper_thread_map_ms": round(out["async_map_ms"], 1),
-                       "sync_share_of_map_time": round(sync_calls_ms / tot, 4) if tot else None,
-                       "sync_map_share_of_wall": round(out["sync_map_ms"] / 1e3 / out["seconds"], 4),
-                       "sync_breakdown": out.get("sync_breakdown")}
-        finally:
-            r2.close()
+        extras["dynamic"] = dynamic_leg(make_runner, mem_for_kv, lengths256, "llama-3-8b", 1, "configs[2] shape: llama-3-8b TP=1, 32 layers",
+                                        None, dtype, not a.no_cpu_baseline)
+        extras["dynamic_tp8_rank"] = dynamic_leg(make_runner, mem_for_kv, cap(lengths256, 768), "llama-3-70b", 8,
+                                                 "one TP=8 rank of configs[4]: llama-3-70b, 8/1 heads, 80 layers (40 KB of KV per token: 256 sequences "
+                                                 "fit at full depth); decode lengths capped at 768", True, dtype, False)
+        extras["open_loop"] = open_loop_leg(make_runner, mem_for_kv, lengths256, 6.0, 256)
+        extras["capacity"] = capacity_leg(dev, mem_for_kv)
 
     if rank == 0:
         out = {
@@ -388,26 +395,160 @@ def main():
                              "sync_ms": round((vm1["sync_ns"] - vm0["sync_ns"]) / 1e6, 3),
                              "async_ms": round((vm1["async_ns"] - vm0["async_ns"]) / 1e6, 3),
                              "join_wait_ms": round((vm1["join_wait_ns"] - vm0["join_wait_ns"]) / 1e6, 3)},
-            "op_ms": {k: round(v, 2) for k, v in op_ms.items()},
+            "op_ms": op_ms,
         }
-        if roof:
-            out["roofline"] = roof
-            out["roofline_decode"] = roof_dec
+        out.update(roofs)
         if cold:
             out["cold_wave"] = cold
         if tp_check:
             out["tensor_parallel"] = tp_check
-        if full_trace:
-            out["full_trace_50req"] = full_trace
-        if dynamic:
-            out["dynamic"] = dynamic
-        if world == 1 and not a.no_cpu_baseline and w["mode"] == "static":
-            out["cpu_baseline"] = cpu_baseline(dtype, L, Hq, Hkv, D, prefill_tok, decode_tok - 1, w["batch"])
-        print(json.dumps(out), flush=True)
+        out.update(extras)
     if runner is not None:
         runner.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not a.no_cpu_baseline:
+            # after the timed region and after the ranks have parted: the oracle on this workload's per-rank shape, host cores only
+            keys = min(w["ctx"], 32768) if w["mode"] == "dynamic" else w["ctx"] - math.ceil(w["ctx"] / (1 + w["pd"]))
+            out["cpu_baseline"] = cpu_baseline(dtype, L, Hq, Hkv, D, keys, shard_of, tokens, pairs["pf"], pairs["dc"],
+                                               "configs[%d]" % {1: 1, 2: 3, 4: 3, 8: 4}[shard_of])
+        print(json.dumps(out), flush=True)
+
+
+def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, dtype, with_cpu) -> dict:
+    """A closed-loop replay of the 256-request arxiv-length recipe at FULL depth on a fresh (cold) pool: peak concurrency, internal
+    fragmentation at the peak, KV utilisation weighted by GPU time (steady-state window / drain tail), mapping cost split by thread.
+    Megacache layout with 8 MiB pages: 64 / 256 KiB pages would need 1-4 M hipMemCreate handles for this pool (O(live handles) on
+    ROCm).  ab_deferred: run the same replay again with set_deferred_reclamation(False) and report both."""
+    import torch
+    from vattention_amd import vattention
+    from vattention_amd.attention.timers import drain_op_timers_detail, enable_op_timers
+
+    def run(deferred: bool):
+        r = make_runner(model, tp, 32768, 8 << 20, 256, "fa_vattn_megacache", mem_for_kv)
+        try:
+            if not deferred:
+                r.engine.disable_deferred_reclamation()
+            r.time_iterations = True
+            enable_op_timers(True, every=TIMER_EVERY["dynamic"])
+            out = r.run_dynamic_trace(256, lengths=lengths)
+            det = drain_op_timers_detail()
+            enable_op_timers(False)
+            out["_stats"] = (r.stats.prefill_pairs, r.stats.decode_pairs, r.L, r.Hq, r.Hkv, r.D)
+            out["_roof"] = rooflines(det)
+            return out
+        finally:
+            r.close()
+
+    def digest(out):
+        # synchronous batches = driver calls on the engine thread (maps / unmaps / set-access / creations / TLB invalidation) PLUS,
+        # before an unmap, the wait for the fence of the slot that gives the page up (not mapping work; it moves to the mapper
+        # thread when the look-ahead does the reclaim)
+        sb = out.get("sync_breakdown") or {}
+        fence_ms = float(sb.get("fence_ms", 0.0))
+        sync_calls_ms = max(0.0, out["sync_map_ms"] - fence_ms)
+        tot = sync_calls_ms + out["async_map_ms"]
+        d = {"peak_concurrent_sequences": out["peak_running"], "tokens": out["tokens"], "seconds": round(out["seconds"], 2),
+             "tokens_per_s": round(out["tokens_per_s"], 1), "iterations": out["iters"],
+             "kv_live_over_needed_at_peak": out["kv_live_over_needed_at_peak"],
+             "kv_live_over_mapped_mean_per_iteration": round(out["kv_live_over_mapped_mean"], 4),
+             "kv_util_time_weighted": out.get("kv_util_time_weighted"),
+             "external_fragmentation": 0.0, "map_calls": out["map_calls"], "unmap_calls": out["unmap_calls"],
+             "handles_created": out.get("handles_created"), "create_ms": out.get("create_ms"),
+             "sync_map_ms": round(sync_calls_ms, 1), "sync_fence_wait_ms": round(fence_ms, 1),
+             "mapper_thread_map_ms": round(out["async_map_ms"], 1),
+             "sync_share_of_map_time": round(sync_calls_ms / tot, 4) if tot else None,
+             "sync_map_share_of_wall": round(out["sync_map_ms"] / 1e3 / out["seconds"], 4),
+             "sync_breakdown": out.get("sync_breakdown")}
+        d.update(out["_roof"])
+        return d
+
+    first = run(True)
+    res = {"workload": what + "; 256 arxiv-length requests (tests/golden/c3_arxiv_lengths_256.json) closed loop, vLLM scheduler, max_batch_size 256, "
+                              "megacache 8 MiB pages, pool = 0.9 x HBM - 12 GiB, cold pool"}
+    res.update(digest(first))
+    if with_cpu:
+        pf, dc, L, Hq, Hkv, D = first["_stats"]
+        res["cpu_baseline"] = cpu_baseline(dtype, L, Hq, Hkv, D, 16384, 1, first["tokens"], pf, dc, what.split(":")[0])
+    if ab_deferred:
+        second = digest(run(False))
+        res["deferred_reclamation_off"] = {k: second[k] for k in ("tokens_per_s", "seconds", "peak_concurrent_sequences", "kv_util_time_weighted",
+                                                                  "kv_live_over_mapped_mean_per_iteration", "map_calls", "unmap_calls",
+                                                                  "sync_map_ms", "sync_fence_wait_ms", "mapper_thread_map_ms")}
+    return res
+
+
+def open_loop_leg(make_runner, mem_for_kv, lengths, qps, requests) -> dict:
+    """The reference's OPEN-loop arrival process (poisson_request_interval_generator.py:9-21, seed 42, interval capped at 3/qps) on one
+    TP = 8 rank of Llama-3-70B (configs[4]: qps = 6), on a virtual clock: every iteration advances it by the measured GPU time of
+    its attention + KV work plus a stated stand-in for the transformer body this harness does not run — per token 2 x 70e9 / 8
+    flop at 1.0 PFLOP/s = 17.5 us, and never less than streaming the rank's weights once (70e9 x 2 B / 8 at 6 TB/s = 2.9 ms)."""
+    r = make_runner("llama-3-70b", 8, 32768, 8 << 20, 256, "fa_vattn_megacache", mem_for_kv)
+    try:
+        out = r.run_dynamic_trace(requests, lengths=lengths, qps=qps, body_time=(17.5e-6, 2.9e-3))
+    finally:
+        r.close()
+    ol = out["open_loop"]
+    ol.update({"workload": "one TP=8 rank of llama-3-70b (8/1 heads, 80 layers), %d arxiv-length requests, Poisson arrivals at qps=%g (reference recipe, "
+                           "seed 42), vLLM scheduler, megacache 8 MiB pages, admission look-ahead on" % (requests, qps),
+               "peak_concurrent_sequences": out["peak_running"], "iterations": out["iters"], "tokens": out["tokens"],
+               "gpu_seconds_wall": round(out["seconds"], 2), "tokens_per_virtual_s": round(out["tokens"] / ol["virtual_seconds"], 1),
+               "sync_map_ms_total": round(out["sync_map_ms"], 1), "mapper_thread_map_ms": round(out["async_map_ms"], 1),
+               "kv_util_time_weighted": out.get("kv_util_time_weighted")})
+    return ol
+
+
+def capacity_leg(dev, mem_for_kv) -> dict:
+    """Whole-HBM KV capacity (BASELINE configs[4] 'KV-capacity stress'): one TP = 8 rank of Llama-3-70B (80 layers x 1 kv head), 256
+    slots x 32 k, megacache with 8 MiB pages; every slot grows in steps until step() raises the reference's OOM error
+    (vattention.cu:295).  Reports what was mapped against the budget, how long the fill took and how many handles back it."""
+    import torch
+    from vattention_amd import vattention
+    L, kvh, D, B, ctx, page = 80, 1, 128, 256, 32768, 8 << 20
+    vattention.enable_layered_async(False)
+    ts = vattention.init_kvcache(L, kvh, D, B, ctx, dev.index or 0, torch.float16, page, True)
+    try:
+        npages = vattention.reserve_physical_pages(mem_for_kv)
+        lay = vattention.layout()
+        tpp = lay["tokens_per_page"]
+        lens = [0] * B
+        t0 = time.perf_counter()
+        err, steps = None, 0
+        grow = 8 * tpp
+        while err is None:
+            for i in range(B):
+                lens[i] = min(ctx, lens[i] + grow)
+            try:
+                vattention.step(lens, False)
+                steps += 1
+            except RuntimeError as e:
+                err = str(e)
+            if all(x == ctx for x in lens) and err is None:
+                break
+        fill_s = time.perf_counter() - t0
+        st, vs = vattention.state(), vattention.stats()
+        mapped_groups = sum(st["mapped"])
+        mapped_bytes = mapped_groups * 2 * page
+        # first and last mapped token rows are readable and writable
+        k = ts[0]
+        last = max(0, min(ctx, st["mapped"][0] * tpp) - 1)
+        k[0, 0].fill_(1.0)
+        k[0, last].fill_(2.0)
+        torch.cuda.synchronize()
+        ok = bool(float(k[0, 0, 0, 0, 0]) == 1.0 and float(k[0, last, L - 1, 0, D - 1]) == 2.0)
+        total_b = torch.cuda.mem_get_info(dev)[1]
+        t1 = time.perf_counter()
+    finally:
+        vattention.cleanup()
+    return {"workload": "one TP=8 rank of llama-3-70b: 80 layers x 1 kv head, 256 slots x 32768 tokens (320 GiB of virtual tensors), megacache 8 MiB pages "
+                        "(%d tokens per page), all slots grown in steps of 8 pages until the allocator's OOM error" % tpp,
+            "budget_bytes": int(mem_for_kv), "pool_pages": int(npages), "mapped_bytes": int(mapped_bytes),
+            "mapped_over_budget": round(mapped_bytes / mem_for_kv, 4), "mapped_over_hbm": round(mapped_bytes / total_b, 4),
+            "tokens_resident": int(mapped_groups * tpp), "fill_seconds": round(fill_s, 2), "grow_steps": steps,
+            "handles_created": int(vs["handles_created"]), "create_ms": round(vs["create_ns"] / 1e6, 1), "map_calls": int(vs["map_calls"]),
+            "oom_error": err, "first_and_last_rows_read_write": ok, "cleanup_seconds": round(time.perf_counter() - t1, 2)}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,46 @@
+"""bench.py's host-side helpers (no GPU): the roofline objects built from the op-timer records, the CPU-baseline arithmetic, the
+open-loop arrival recipe of the replay harness."""
+import math
+import random
+
+import torch
+
+import bench
+
+
+def test_rooflines_pick_the_dominant_kernel_and_scale_sampled_time():
+    detail = {"attn_prefill": {"ms": 10.0, "timed": 4, "n": 32, "work": 4 * 2.0e12},        # 4 timed launches of 2 TFLOP in 10 ms
+              "attn_decode": {"ms": 3.0, "timed": 10, "n": 10, "work": 10 * 1.2e9}}
+    r = bench.rooflines(detail, {"prefill": 123, "decode": 456})
+    assert r["roofline"]["bound"] == "mfma" and r["roofline"]["dominant_of"] == ["decode", "prefill"]
+    assert abs(r["roofline_prefill"]["achieved"] - 800.0) < 1e-6 and r["roofline_prefill"]["frac"] == 0.32
+    assert r["roofline_prefill"]["est_total_ms"] == 80.0 and r["roofline_prefill"]["launches_timed"] == 4
+    assert abs(r["roofline_decode"]["achieved"] - 4000.0) < 1e-6 and r["roofline_decode"]["unit"] == "GB/s"
+    assert r["roofline_prefill"]["traffic"] == 123 and r["roofline_decode"]["traffic"] == 456
+    only_dec = bench.rooflines({"attn_decode": detail["attn_decode"]})
+    assert only_dec["roofline"]["bound"] == "hbm" and "roofline_prefill" not in only_dec
+    assert bench.rooflines({}) == {}
+
+
+def test_cpu_baseline_scales_measured_rates_by_counted_pairs():
+    torch.manual_seed(0)
+    b = bench.cpu_baseline(torch.float16, 2, 4, 2, 64, 512, 2, 1000, 512 * 513 / 2.0, 3 * 512.0, "test")
+    assert b["kind"] == "port" and b["unit"] == "tokens/s" and b["cores"] >= 1 and b["value"] > 0
+    assert "2 shard(s) x 2 layers x 4 heads" in b["sample"]
+
+
+def test_open_loop_interval_recipe_matches_the_reference_generator():
+    """poisson_request_interval_generator.py:9-21 restated: random.Random(seed), interval = min(-ln(1 - U) / qps, 3 / qps)."""
+    qps, seed = 6.0, 42
+    rng = random.Random(seed)
+    want, t = [], 0.0
+    for _ in range(16):
+        t += min(-math.log(1.0 - rng.random()) / qps, 3.0 / qps)
+        want.append(t)
+    # the same arithmetic as replay.run_dynamic_trace's arrival table
+    arng = random.Random(seed)
+    got, t = [], 0.0
+    for _ in range(16):
+        t += min(-math.log(1.0 - arng.random()) / qps, 3.0 / qps)
+        got.append(t)
+    assert got == want and max(b - a for a, b in zip(got, got[1:])) <= 3.0 / qps + 1e-12

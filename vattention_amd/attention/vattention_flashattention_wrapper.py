@@ -80,6 +80,12 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                 dec.append(md.seq.get_len() - 1)
         self.prefill_query_lens = q_lens
         self.prefill_cache_lens = c_lens
+        # algorithmic work of this iteration's launches, per layer (only read by the op timers): prefill flops
+        # 4.Hq.D.(n.c + n(n+1)/2) per chunk, decode bytes sum_b 2.len_b.Hkv.D.itemsize + q, o
+        Hq, Hkv, D = self.num_q_heads, self.num_kv_heads, self.head_dim
+        self._pf_flops = [4.0 * Hq * D * (n * c + n * (n + 1) / 2.0) for c, n in zip(c_lens, q_lens)]
+        es = 2
+        self._dc_bytes = float(sum(2 * (l + 1) * Hkv * D * es for l in dec) + len(dec) * Hq * D * es * 2)
         if totals:      # one H2D copy for all prefills, then views
             starts = [sum(q_lens[:i]) for i in range(len(q_lens))]
             meta = torch.tensor([totals, starts, q_lens], dtype=torch.int32, device=self.device)
@@ -149,7 +155,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                         cache_flat(key[tok:tok + q_len].view(q_len, Hkv, D), value[tok:tok + q_len].view(q_len, Hkv, D),
                                    k_all[slot][c_len:], v_all[slot][c_len:], "auto")
                     tok += q_len
-            with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id):
+            with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id) as tm:
+                tm.work = sum(self._pf_flops)
                 flash_attn_varlen_with_kvcache(query[:tok].view(tok, Hq, D), k_all, v_all, self._prefill_starts, self._prefill_qlens,
                                                max(self.prefill_query_lens), self._prefill_totals, self.batch_index[:P],
                                                softmax_scale=softmax_scale, causal=True, out=output[:tok].view(tok, Hq, D),
@@ -170,7 +177,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                     cache_flat_rope(k, v, k_rows[c_len:], v_rows[c_len:], self._rotary, c_len)
                 else:
                     cache_flat(k, v, k_rows[c_len:], v_rows[c_len:], "auto")
-            with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id):
+            with self.get_timer(OperationMetrics.ATTN_PREFILL, layer_id) as tm:
+                tm.work = self._pf_flops[i]
                 # the kernel writes straight into this sequence's rows of `output` (no [q_len, Hq*D] copy afterwards)
                 flash_attn_with_kvcache(q, k_rows.unsqueeze(0), v_rows.unsqueeze(0),
                                         cache_seqlens=self.current_total_len_device_lst[i],
@@ -192,7 +200,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         sig = (query.stride(0), key.stride(0), value.stride(0), output.stride(0), k_all.stride(), v_all.stride(), tok, float(softmax_scale),
                query.dtype, k_all.dtype)
         if plan is not None and plan["sig"] == sig and not _FA._capture_active():
-            with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id):
+            with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id) as tm:
+                tm.work = self._dc_bytes
                 _FA.relaunch(plan["p"], query.data_ptr() + plan["q_off"], key.data_ptr() + plan["k_off"], value.data_ptr() + plan["v_off"],
                              output.data_ptr() + plan["o_off"], k_all.data_ptr(), v_all.data_ptr(), self.device)
             return
@@ -201,7 +210,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
             dq = query[tok:tok + nb].view(nb, 1, Hq, D)
             dk = key[tok:tok + nb].view(nb, 1, Hkv, D)
             dv = value[tok:tok + nb].view(nb, 1, Hkv, D)
-        with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id):
+        with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id) as tm:
+            tm.work = self._dc_bytes
             flash_attn_with_kvcache(dq, k_all[:, :self.max_cache_len], v_all[:, :self.max_cache_len], dk, dv,
                                     cache_seqlens=self.decode_cache_lens, block_table=None,
                                     softmax_scale=softmax_scale, causal=True,

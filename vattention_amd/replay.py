@@ -112,6 +112,13 @@ class ReplayStats:
     kv_util_samples: List[float] = field(default_factory=list)     # live-token bytes / mapped bytes
     mapped_over_reserved: List[float] = field(default_factory=list)
     kv_needed_samples: List[tuple] = field(default_factory=list)   # (live / needed-page tokens, active slots)
+    # attention work issued, per layer and per query head: (query row, visible key) pairs of the prefill form, keys read by the decode
+    # form — what bench.py's CPU baseline scales its measured pairs/s with
+    prefill_pairs: float = 0.0
+    decode_pairs: float = 0.0
+    iter_events: List[object] = field(default_factory=list)         # one HIP event per iteration end (time_iterations)
+    iter_phase: List[int] = field(default_factory=list)             # 0 = requests still waiting (steady state), 1 = drain tail
+    iter_util: List[tuple] = field(default_factory=list)            # per iteration: (live/mapped, live/needed, active slots, mapped/pool)
 
 
 class HotPathRunner:
@@ -141,6 +148,8 @@ class HotPathRunner:
         self.iter_hook = None       # called once per iteration right after engine.step (bench.py: the TP control-plane exchange)
         self.next_request = None    # (seq_id, context length) — or a list of them — the scheduler will admit next: pre-mapped under this iteration's forward
         self.admission_lookahead = True
+        self.time_iterations = False    # record one HIP event per iteration end (GPU time of every iteration: time-weighted KV utilisation)
+        self._phase = 0
         # Compute runs on a NON-BLOCKING stream: on ROCm 7.2 hipMemMap / hipMemUnmap wait for work queued on
         # the legacy default stream (and every blocking stream) but not for non-blocking streams
         # (tools/vmm_probe.cpp, profiles/r01_vmm_sync_probe_raw.txt), so this is what lets page mapping — on the
@@ -184,16 +193,24 @@ class HotPathRunner:
         for md in mds:                               # seq_manager.on_step_completed
             if md.is_prompt:
                 n = md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len)
+                c = md.seq.prompt_processed
+                self.stats.prefill_pairs += n * c + n * (n + 1) / 2.0
                 md.seq.prompt_processed += n
                 self.stats.prefill_tokens += n
                 if md.seq.prompt_done:
                     md.seq.output_len += 1           # the prefill iteration emits the first output token
                     self.stats.decode_tokens += 1
             else:
+                self.stats.decode_pairs += md.seq.get_len()
                 md.seq.output_len += 1
                 self.stats.decode_tokens += 1
         if self.sample_kv_util:
             self._sample_util()
+        if self.time_iterations:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(self.stream)
+            self.stats.iter_events.append(ev)
+            self.stats.iter_phase.append(self._phase)
         with torch.cuda.stream(self.stream):         # free_batch_idx records the slot's fence on the stream the kernels ran on
             self.engine.on_step_completion(mds)
         self.stats.iterations += 1
@@ -205,16 +222,21 @@ class HotPathRunner:
         tpp = self._tpp
         mapped_tokens = c["mapped_groups"] * tpp
         live = sum(self.engine.curr_seq_lens)
+        u_mapped = u_needed = None
         if mapped_tokens:
-            self.stats.kv_util_samples.append(live / mapped_tokens)
+            u_mapped = live / mapped_tokens
+            self.stats.kv_util_samples.append(u_mapped)
         if c["needed_groups"]:
             # internal fragmentation only: pages a LIVE sequence needs vs the tokens it holds (pages kept mapped under
             # finished slots by deferred reclamation are cache, reclaimable on demand, not fragmentation)
-            self.stats.kv_needed_samples.append((live / (c["needed_groups"] * tpp), c["active_slots"]))
+            u_needed = live / (c["needed_groups"] * tpp)
+            self.stats.kv_needed_samples.append((u_needed, c["active_slots"]))
         pages_per_group = 2 if self.engine.vattn_mega_cache else 2 * self.L
         reserved_tokens = (c["pool_pages"] // pages_per_group) * tpp + mapped_tokens
         if reserved_tokens:
             self.stats.mapped_over_reserved.append(mapped_tokens / reserved_tokens)
+        if self.time_iterations:
+            self.stats.iter_util.append((u_mapped, u_needed, c["active_slots"], mapped_tokens / reserved_tokens if reserved_tokens else None))
 
     def run_static_trace(self, num_requests: int, total_len: int, pd_ratio: float, chunk_size: Optional[int] = None) -> ReplayStats:
         """scripts/benchmark_e2e_static_trace.py: decode = ceil(total/(1+P:D)), prefill = total - decode
@@ -245,13 +267,20 @@ class HotPathRunner:
         return self.stats
 
     def run_dynamic_trace(self, num_requests: int, seed: int = 42, max_tokens: int = 32768, watermark: float = 0.01,
-                          lengths: Optional[List[List[int]]] = None) -> dict:
+                          lengths: Optional[List[List[int]]] = None, qps: Optional[float] = None,
+                          body_time=(0.0, 0.0)) -> dict:
         """Capacity / fragmentation stress in the shape of the reference's dynamic trace
         (scripts/benchmark_e2e_dynamic_trace.py:7-60: 256 requests, arxiv-summarisation lengths, vLLM scheduler,
         max_batch_size 256).  `lengths` = the request lengths the reference's recipe yields (fixture generated by
         oracle/gen_golden_c3_lengths.py); without it lengths are drawn from shifted log-normals fitted to the trace's marginals (prefill min 4097 / p50 7958 / p75 13186 / max 31805, decode min 105 / p50 332 /
-        p75 482; scripts/artifact_asplos25/traces/arxiv_sample.csv), total capped at max_tokens.  Arrivals are closed-loop
-        (every request is waiting at t=0): without the transformer body an open-loop qps=4 would leave the GPU idle.
+        p75 482; scripts/artifact_asplos25/traces/arxiv_sample.csv), total capped at max_tokens.
+        Arrivals: closed loop by default (every request waiting at t = 0: without the transformer body an open loop leaves the GPU
+        idle).  `qps` switches to the reference's OPEN loop (sarathi/benchmark/request_generator/
+        poisson_request_interval_generator.py:9-21: Python `random` seeded with `seed`, interval = min(-ln(1 - U)/qps, 3/qps)) on a
+        VIRTUAL clock: an iteration advances it by the GPU time of its attention + KV work (HIP events, one synchronisation per
+        iteration) plus max(body_time[0] x tokens of the iteration, body_time[1]) seconds, the stand-in for the transformer body this
+        harness does not run (GEMM time per token, and the weight-streaming floor of an iteration); a request is schedulable once
+        its arrival time has passed; an idle engine jumps to the next arrival.
         Admission is the reference's count-based rule (vattention_block_space_manager.py:36-66):
         free - promised - needed >= watermark."""
         import random
@@ -270,6 +299,13 @@ class HotPathRunner:
             tot = min(max_tokens, pre + dec)
             pre = min(pre, tot - 1)
             reqs.append(Sequence(i, pre, tot))
+        arrival = [0.0] * num_requests
+        if qps:
+            arng = random.Random(seed)        # the generator's own stream (poisson_request_interval_generator.py:12)
+            t_arr = 0.0
+            for i in range(num_requests):      # synthetic_request_generator.py: arrived_at = last_arrived_at + interval, from t = 0
+                t_arr += min(-math.log(1.0 - arng.random()) / qps, 3.0 / qps)
+                arrival[i] = t_arr
         waiting, running = list(reqs), []
         B = self.cache_cfg.max_batch_size
         total_groups = None
@@ -277,7 +313,17 @@ class HotPathRunner:
         vm0 = vattention.stats()
         import time as _t
         t0 = _t.perf_counter()
+        self.stats.iter_events, self.stats.iter_phase, self.stats.iter_util = [], [], []
+        timed = self.time_iterations or bool(qps)
+        keep_ti = self.time_iterations
+        self.time_iterations = timed
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(self.stream)
+        clock, last_ev = 0.0, ev0           # open loop: virtual seconds
+        finish_at, sync_ms_per_iter, prev_sync_ns = {}, [], vm0["sync_ns"]
         while waiting or running:
+            if qps and not running and waiting and arrival[waiting[0].seq_id] > clock:
+                clock = arrival[waiting[0].seq_id]                       # idle engine: jump to the next arrival
             free = vattention.num_free_kvblocks()
             if free >= (1 << 63):
                 free -= 1 << 64
@@ -290,6 +336,8 @@ class HotPathRunner:
             admitted, budget = [], max_tokens
             while waiting and len(running) < B:
                 s = waiting[0]
+                if arrival[s.seq_id] > clock:
+                    break
                 if s.prompt_len > budget or free - promised - pages(s.total_len) < wm:
                     break
                 waiting.pop(0)
@@ -299,25 +347,42 @@ class HotPathRunner:
                 promised += pages(s.total_len)
             if admitted:
                 mds = [SequenceMetadata(s, s.prompt_len, True) for s in admitted]
-            else:
+            elif running:
                 mds = [SequenceMetadata(s, 0, False) for s in running]
+            else:
+                raise RuntimeError("request %d (%d tokens) cannot be admitted into an EMPTY engine: the pool is too small for it" % (
+                    waiting[0].seq_id, waiting[0].total_len))
             # what the NEXT iteration will admit (same token budget and batch rule, free-block rule left to the real admission): the
             # mapper thread maps these prompts' pages while this iteration computes
             nxt, bud = [], max_tokens
             for s in waiting:
-                if len(running) + len(nxt) >= B or s.prompt_len > bud:
+                if len(running) + len(nxt) >= B or s.prompt_len > bud or arrival[s.seq_id] > clock:
                     break
                 nxt.append((s.seq_id, s.prompt_len))
                 bud -= s.prompt_len
             self.next_request = nxt or None
+            self._phase = 0 if waiting else 1
+            tokens_it = sum(md.seq.get_next_prompt_chunk_len(md.prompt_chunk_len) if md.is_prompt else 1 for md in mds)
             self.run_iteration(mds)
             out["iters"] += 1
+            if qps:
+                ev = self.stats.iter_events[-1]
+                ev.synchronize()
+                clock += last_ev.elapsed_time(ev) * 1e-3 + max(body_time[0] * tokens_it, body_time[1])
+                last_ev = ev
+                ns = vattention.stats()["sync_ns"]
+                sync_ms_per_iter.append((ns - prev_sync_ns) / 1e6)
+                prev_sync_ns = ns
+                for s in running:
+                    if s.is_finished():
+                        finish_at[s.seq_id] = clock
             running = [s for s in running if not s.is_finished()]
             if len(running) > out["peak_running"]:
                 out["peak_running"] = len(running)
             if self.stats.kv_util_samples and len(running) >= min(B, num_requests) * 3 // 4:
                 out["util_at_peak"].append(self.stats.kv_util_samples[-1])
         torch.cuda.synchronize()
+        self.time_iterations = keep_ti
         out["seconds"] = _t.perf_counter() - t0
         vm1 = vattention.stats()
         u = self.stats.kv_util_samples
@@ -344,7 +409,40 @@ class HotPathRunner:
                                "tlb_ms": round((vm1["sync_tlb_ns"] - vm0["sync_tlb_ns"]) / 1e6, 1)},
         })
         out.pop("util_at_peak")
+        if timed and self.stats.iter_events:
+            out["kv_util_time_weighted"] = self._time_weighted_util(ev0)
+        if qps:
+            lat = sorted((finish_at[r.seq_id] - arrival[r.seq_id]) / r.total_len for r in reqs if r.seq_id in finish_at)
+            sm = sorted(sync_ms_per_iter)
+            pct = lambda xs, q: xs[min(len(xs) - 1, int(q * len(xs)))] if xs else None
+            out["open_loop"] = {"qps": qps, "virtual_seconds": round(clock, 3), "body_seconds_per_token": body_time[0], "body_seconds_floor_per_iteration": body_time[1],
+                                "request_e2e_time_normalized_p50": pct(lat, 0.5), "request_e2e_time_normalized_p99": pct(lat, 0.99),
+                                "sync_map_ms_per_step_p50": pct(sm, 0.5), "sync_map_ms_per_step_p99": pct(sm, 0.99),
+                                "sync_map_ms_per_step_max": sm[-1] if sm else None}
         return out
+
+    def _time_weighted_util(self, ev0) -> dict:
+        """KV utilisation weighted by the GPU time of every iteration (HIP events), separately for the window in which requests are
+        still waiting to be admitted (steady state: the pool is the contended resource) and for the drain tail (no admissions left:
+        finished slots keep their pages under deferred reclamation because nobody needs them)."""
+        evs, ph, ut = self.stats.iter_events, self.stats.iter_phase, self.stats.iter_util
+        acc = {0: [0.0, 0.0, 0.0, 0.0, 0.0], 1: [0.0, 0.0, 0.0, 0.0, 0.0]}      # time, t*live/mapped, t*live/needed, t*mapped/pool, t with samples
+        prev = ev0
+        for ev, phase, u in zip(evs, ph, ut):
+            dt = prev.elapsed_time(ev)
+            prev = ev
+            a = acc[phase]
+            a[0] += dt
+            if u[0] is not None and u[1] is not None:
+                a[1] += dt * u[0]
+                a[2] += dt * u[1]
+                a[3] += dt * (u[3] or 0.0)
+                a[4] += dt
+        def summ(a):
+            return None if a[4] == 0 else {"gpu_ms": round(a[0], 1), "live_over_mapped": round(a[1] / a[4], 4),
+                                           "live_over_needed": round(a[2] / a[4], 4), "mapped_over_pool": round(a[3] / a[4], 4)}
+        both = [x + y for x, y in zip(acc[0], acc[1])]
+        return {"steady_state": summ(acc[0]), "drain_tail": summ(acc[1]), "whole_run": summ(both)}
 
     def close(self):
         self.engine.cleanup_kvcache()
