@@ -112,7 +112,7 @@ def test_decode_single_launch_merge_and_head_block_groups(B, G, Hkv, D, lens, dt
 @pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12, 14, 270, 526, 2574], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved", "w4q2_dma_pipelined", "w4q2_dma_dot2_rowsum", "w4q2_dma_kpad", "w4q2_dma_dot2_kpad"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("n,c,Hq,Hkv", [
-    (128, 0, 8, 2), (1, 5, 4, 4), (200, 0, 4, 1), (77, 333, 8, 4), (512, 1000, 4, 2), (130, 62, 2, 2), (64, 64, 4, 2),
+    (128, 0, 8, 2), (200, 0, 4, 1), (77, 333, 8, 4), (512, 1000, 4, 2), (130, 62, 2, 2), (64, 64, 4, 2),
 ])
 def test_prefill_chunk_parity(n, c, Hq, Hkv, dtype, variant):
     """Wrapper's prefill form (:151-166): cache_flat at offset c, then causal attention with cache_seqlens=[c+n]."""
@@ -129,8 +129,6 @@ def test_prefill_chunk_parity(n, c, Hq, Hkv, dtype, variant):
     cl = torch.tensor([c + n], dtype=torch.int32)
     kc1, vc1 = kc.clone(), vc.clone()
     cache_flat_ref(k, v, kc1[slot][c:], vc1[slot][c:])
-    if n == 1:
-        pytest.skip("seqlen_q == 1 takes the decode form; covered by test_decode_parity")
     ref64 = flash_attn_with_kvcache_ref(q, kc1[slot:slot + 1], vc1[slot:slot + 1], cache_seqlens=cl, causal=True)
     ref32 = flash_attn_with_kvcache_ref(q, kc1[slot:slot + 1], vc1[slot:slot + 1], cache_seqlens=cl, causal=True, math="f32")
     kg, vg = kc.to(DEV), vc.to(DEV)
@@ -141,6 +139,38 @@ def test_prefill_chunk_parity(n, c, Hq, Hkv, dtype, variant):
     torch.cuda.synchronize()
     assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)           # cache_flat bit-exact
     _check(out, ref64, ref32, dtype, "prefill n=%d c=%d" % (n, c))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("c,Hq,Hkv", [(5, 4, 4), (0, 8, 2), (777, 32, 4), (1599, 8, 1)])
+def test_one_token_prefill_chunk(c, Hq, Hkv, dtype):
+    """A ONE-token prefill chunk — what the Sarathi scheduler issues when a prompt's remainder is a single token
+    (vattention_flashattention_wrapper.py:151-166: cache_flat at offset c, then q [1, 1, Hq, D] with causal=True, cache_seqlens=[c+1],
+    no k / v arguments).  seqlen_q == 1 takes the decode form of the launch (causal is moot for one row, flash_api.cpp:1364) without
+    the in-kernel append; the token attends over the c cached keys and itself."""
+    from vattention_amd.cache_ops import cache_flat
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(1000 + c)
+    D, ctx = 128, 1600
+    kc = torch.randn(3, ctx, Hkv, D).to(dtype)
+    vc = torch.randn(3, ctx, Hkv, D).to(dtype)
+    q = torch.randn(1, 1, Hq, D).to(dtype)
+    k = torch.randn(1, Hkv, D).to(dtype)
+    v = torch.randn(1, Hkv, D).to(dtype)
+    slot = 2
+    cl = torch.tensor([c + 1], dtype=torch.int32)
+    kc1, vc1 = kc.clone(), vc.clone()
+    cache_flat_ref(k, v, kc1[slot][c:], vc1[slot][c:])
+    ref64 = flash_attn_with_kvcache_ref(q, kc1[slot:slot + 1], vc1[slot:slot + 1], cache_seqlens=cl, causal=True)
+    ref32 = flash_attn_with_kvcache_ref(q, kc1[slot:slot + 1], vc1[slot:slot + 1], cache_seqlens=cl, causal=True, math="f32")
+    kg, vg = kc.to(DEV), vc.to(DEV)
+    key_cache, value_cache = kg[slot].unsqueeze(0), vg[slot].unsqueeze(0)
+    cache_flat(k.to(DEV), v.to(DEV), key_cache.squeeze(0)[c:], value_cache.squeeze(0)[c:], "auto")
+    out = torch.full((1, 1, Hq, D), float("nan"), dtype=dtype, device=DEV)
+    flash_attn_with_kvcache(q.to(DEV), key_cache, value_cache, cache_seqlens=cl.to(DEV), causal=True, out=out, _max_seqlen_k=c + 1)
+    torch.cuda.synchronize()
+    assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)           # cache_flat bit-exact, nothing else written
+    _check(out, ref64, ref32, dtype, "one-token chunk at c=%d" % c)
 
 
 @pytest.mark.parametrize("Hq,Hkv", [(8, 1), (8, 2), (8, 4), (8, 8), (6, 3), (16, 16), (12, 4)])
