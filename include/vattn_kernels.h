@@ -79,11 +79,36 @@ typedef struct vattn_attn_params {
     int64_t rotary_row_stride;
     int32_t rotary_dim;
     int32_t rotary_reserved;
+    /* Length-balanced split-KV of a RAGGED decode batch (MI355X extension; all three zero otherwise).  The reference's heuristic
+     * (flash_api.cpp:258-323) gives every sequence of a batch the same number of splits, so a launch lasts as long as the longest
+     * sequence's split (a 30 k-token sequence beside 4 k-token ones: 3 x the average).  A caller that knows the lengths on the host
+     * (the attention wrapper does) asks vattn_decode_plan for work items of near-equal length — sequence b is cut into
+     * ceil(tiles_b / T) pieces of T 32-key tiles — copies the two tables to the device once per iteration and passes them with every
+     * layer's call.  decode form only; results equal the uniform split's up to the order of the fp32 merge. */
+    const struct vattn_decode_item* split_items;   /* device: num_split_items entries                         */
+    const int32_t* split_seq;                      /* device: int32[2 * b] = (first item, item count) per sequence */
+    int32_t num_split_items;
+    int32_t split_reserved;
 } vattn_attn_params;
+
+typedef struct vattn_decode_item {
+    int32_t b;            /* batch entry                                            */
+    int32_t tile_begin;   /* first 32-key tile of the piece                         */
+    int32_t tile_end;     /* one past its last tile                                 */
+    int32_t index_in_seq; /* 0 .. count-1 within the sequence                       */
+} vattn_decode_item;
 
 /* Bytes of split-KV workspace the call will need: the decode form's partials, or the prefill form's when its grid
  * would underfill the chip and the key range is split across workgroups (0 otherwise). */
 size_t vattn_attn_workspace_bytes(const vattn_attn_params* p);
+
+/* Host-side planner of the length-balanced decode split (see vattn_attn_params.split_items).  `p` describes the call (b, h, h_k, d,
+ * seqlen_knew, variant; pointers are not read), cache_seqlens_host[b] are the values the device array will hold.  Writes at most
+ * `cap` items and 2 * b ints of (first item, count); returns the number of items, 0 when the uniform split is at least as good
+ * (equal lengths, one sequence, batches whose uniform split is already balanced) or the tables would not fit, < 0 on bad arguments.
+ * Pure host arithmetic (no device access): usable, and tested, without a GPU. */
+int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqlens_host, vattn_decode_item* items_out, int32_t cap,
+                          int32_t* seq_out);
 
 /* flash_attn_with_kvcache: appends k_new/v_new (if given) and attends; prefill form (seqlen_q > 1,
  * causal chunk against the growing cache) and decode form (seqlen_q == 1, split-KV + combine). */

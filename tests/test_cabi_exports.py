@@ -124,8 +124,97 @@ def test_split_plans_from_the_workspace_query():
     assert pf_splits(2048, 32768, 8, 1, 0) <= 2          # without the lengths only the chunk itself is certain: 16 tiles
     assert pf_splits(512, 16384, 8, 1, 16384) == 8
     assert 2 <= pf_splits(1024, 65536, 28, 4, 65536) <= 8
+    lib = K.klib_lab()                                               # (a lab-only kernel: tools/lab/libvattn_lab.so)
     assert pf_splits(2048, 32768, 8, 1, 32768, variant=12) == 1      # the interleaved kernel has no split epilogue
+    lib = K.klib()
     assert pf_splits(300, 1400, 8, 2, 1200, splits=5) == 5           # forced
+
+
+def test_decode_plan_cuts_a_ragged_batch_into_equal_work_items():
+    """vattn_decode_plan (pure host code): every sequence's 32-key tiles are covered exactly once by contiguous, ordered pieces; the
+    longest piece is far shorter than the longest sequence's share under the uniform split; equal-length batches and single
+    sequences keep the uniform split (0 items); at most 128 pieces per sequence."""
+    import ctypes as C
+    import random
+    from vattention_amd import kernels as K
+    lib = K.klib()
+
+    def plan(lens, h, hk, knew=1, variant=0):
+        p = K.AttnParams()
+        p.b, p.seqlen_q, p.seqlen_k, p.seqlen_knew, p.h, p.h_k, p.d = len(lens), 1, 32768, knew, h, hk, 128
+        p.variant = variant
+        cap = 4 * len(lens) + 1024
+        items = (K.DecodeItem * cap)()
+        seq = (C.c_int32 * (2 * len(lens)))()
+        n = lib.vattn_decode_plan(C.byref(p), (C.c_int32 * len(lens))(*lens), items, cap, seq)
+        return n, [(items[i].b, items[i].tile_begin, items[i].tile_end, items[i].index_in_seq) for i in range(max(n, 0))], list(seq)
+
+    rng = random.Random(5)
+    # one TP=8 rank of Llama-3-70B: the 256 sequences of the reference's dynamic trace (prompt lengths 4 k .. 29 k, median 7 k) on one
+    # kv head, each a few hundred tokens into its decode phase
+    import json
+    import os
+    trace = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_arxiv_lengths_256.json")))["requests"]
+    lens = [pre + rng.randint(1, 300) for pre, _ in trace]
+    n, items, seq = plan(lens, 8, 1)
+    assert 256 < n <= 768, n                                     # one round of the 768 resident workgroups
+    longest = max(te - tb for _, tb, te, _ in items)
+    uniform = max((l + 1 + 31) // 32 for l in lens) / 3.0        # the uniform heuristic gives 256 x 3 = 768 workgroups
+    assert longest * 1.8 < uniform, (longest, uniform)
+    for b, l in enumerate(lens):
+        first, cnt = seq[2 * b], seq[2 * b + 1]
+        tiles = (l + 1 + 31) // 32
+        mine = items[first:first + cnt]
+        assert 1 <= cnt <= 128 and all(it[0] == b for it in mine) and [it[3] for it in mine] == list(range(cnt))
+        assert mine[0][1] == 0 and mine[-1][2] == tiles and all(a[2] == c[1] for a, c in zip(mine, mine[1:]))
+    assert sum(seq[1::2]) == n
+    # Llama-3-8B, 8 kv heads, 200 sequences: the batch alone exceeds a round; long sequences are cut to about the mean length
+    lens = [rng.randint(4000, 32000) for _ in range(200)]
+    n, items, seq = plan(lens, 32, 8)
+    assert 200 < n <= 2 * 200 + 8
+    # equal lengths, a single sequence, a nearly uniform batch: keep the uniform split
+    assert plan([32767] * 16, 32, 4)[0] == 0
+    assert plan([20000], 32, 4)[0] == 0
+    assert plan([30000 + i for i in range(16)], 32, 4)[0] == 0
+    # a prefill-form call has no plan
+    p = K.AttnParams()
+    p.b, p.seqlen_q, p.h, p.h_k, p.d = 4, 5, 8, 2, 128
+    assert lib.vattn_decode_plan(C.byref(p), (C.c_int32 * 4)(1, 2, 3, 4), (K.DecodeItem * 8)(), 8, (C.c_int32 * 8)()) == 0
+    # one 128 k sequence beside short ones: never more than 128 pieces of a sequence
+    n, items, seq = plan([131000] + [600] * 40, 8, 1)
+    assert n > 0 and max(seq[1::2]) <= 128
+
+
+def test_product_library_holds_no_measurement_scaffolding():
+    """The shipped libvattn_amd.so instantiates the kernels the launch plans choose and nothing else: ONE prefill64 build per dtype
+    (the timing ablations with wrong results, the alternative schedules, the hand-interleaved 8-wave kernel, the plain-read operand
+    paths and the in-launch merge protocols live in tools/lab/libvattn_lab.so, built with -DVATTN_LAB), and it reads no environment
+    variable to pick a kernel build."""
+    import re
+    import subprocess
+    from vattention_amd import _lib as L
+    from vattention_amd import kernels as K
+    L.lib()
+    so = L.LIB_PATH if hasattr(L, "LIB_PATH") else None
+    if so is None:
+        import os
+        so = os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvattn_amd.so")
+    syms = subprocess.run(["nm", "--defined-only", so], capture_output=True, text=True, check=True).stdout      # (mangled names)
+    p64 = set(re.findall(r"prefill64_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E", syms))
+    assert p64 == {("DF16_", "128", "24", "4"), ("DF16b", "128", "24", "4")}, p64
+    assert "prefill_ilv_kernel" not in syms
+    # prefill_kernel<T, HD, USE_TR, WAVES, QC, MSUM> / decode_kernel<T, HD, USE_TR, NB, W>: plain-read (USE_TR = false) operand paths
+    # and the row-sums-by-MFMA build are lab-only
+    pk = re.findall(r"prefill_kernelI(?:DF16_|DF16b)Li\d+ELb(\d)ELi\d+ELi\d+ELb(\d)E", syms)
+    assert pk and all(tr == "1" and msum == "0" for tr, msum in pk), pk
+    dk = re.findall(r"decode_kernelI(?:DF16_|DF16b)Li\d+ELb(\d)E", syms)
+    assert dk and all(tr == "1" for tr in dk), dk
+    strings = subprocess.run(["strings", so], capture_output=True, text=True, check=True).stdout
+    assert "VATTN_PREFILL64_BUILD" not in strings
+    # which variants need the lab library
+    assert not K.needs_lab(0) and not K.needs_lab(14) and not K.needs_lab(8) and not K.needs_lab(2 | 64) and not K.needs_lab(65536)
+    for v in (1, 4, 12, 16, 270, 526, 2574, 512, 1024, 16384, 32768):
+        assert K.needs_lab(v), v
 
 
 def test_layout_policy_moves_huge_pools_to_megacache():

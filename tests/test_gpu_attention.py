@@ -28,7 +28,7 @@ def _check(out_gpu, ref64, ref32, dtype, what):
         "%s: kernel err %.3e vs reference-numerics err %.3e" % (what, err.max().item(), e_ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["tr_read", "plain_read"])
+@pytest.mark.parametrize("variant", [0, 1, 65536, 131072], ids=["tr_read", "plain_read", "wg512", "wg1024"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("B,G,Hkv,lens", [
     (1, 8, 4, [777]),                    # Yi-6B group size
@@ -139,6 +139,55 @@ def test_prefill_chunk_parity(n, c, Hq, Hkv, dtype, variant):
     torch.cuda.synchronize()
     assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)           # cache_flat bit-exact
     _check(out, ref64, ref32, dtype, "prefill n=%d c=%d" % (n, c))
+
+
+@pytest.mark.parametrize("variant", [0, 65536, 131072], ids=["wg256", "wg512", "wg1024"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("Hq,Hkv,lens", [
+    (8, 1, [5000, 31, 900, 2100, 64, 1, 3333, 12000, 700, 450]),          # one TP=8 rank: ragged contexts on ONE kv head
+    (32, 8, [9000, 400, 2048, 6000]),                                      # Llama-3-8B heads
+    (14, 2, [11000, 100, 100, 100, 100, 100, 5000]),                       # G = 7
+], ids=["tp8_rank", "llama8b", "g7"])
+def test_decode_length_balanced_plan(Hq, Hkv, lens, dtype, variant):
+    """A ragged decode batch through the length-balanced plan (vattn_decode_plan: `_cache_seqlens_host` on the Python side) — pieces
+    of near-equal length instead of the same number of splits for every sequence — against the oracle, fused append bit-exact, and
+    against the uniform split of the same call (same values up to the order of the fp32 merge)."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    import vattention_amd.flash_attn as FA
+    torch.manual_seed(99)
+    B, D, ctx = len(lens), 128, max(lens) + 40
+    slots = B + 3
+    kc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    vc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    q = torch.randn(B, 1, Hq, D).to(dtype)
+    kn = torch.randn(B, 1, Hkv, D).to(dtype)
+    vn = torch.randn(B, 1, Hkv, D).to(dtype)
+    idx = torch.randperm(slots)[:B].to(torch.int32)
+    cl = torch.tensor(lens, dtype=torch.int32)
+    max_len = max(lens) + 1
+    kc1, vc1 = kc.clone(), vc.clone()
+    ref64 = flash_attn_with_kvcache_ref(q, kc1[:, :max_len], vc1[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+    kc2, vc2 = kc.clone(), vc.clone()
+    ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :max_len], vc2[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
+    outs = []
+    for host in (lens, None):
+        kg, vg = kc.to(DEV), vc.to(DEV)
+        cap = []
+        out = flash_attn_with_kvcache(q.to(DEV), kg[:, :max_len], vg[:, :max_len], kn.to(DEV), vn.to(DEV), cache_seqlens=cl.to(DEV),
+                                      cache_batch_idx=idx.to(DEV), causal=True, _variant=variant, _cache_seqlens_host=host, _params_out=cap)
+        torch.cuda.synchronize()
+        if host is not None:
+            assert cap[0].num_split_items > B, "the ragged batch did not get a plan"
+        else:
+            assert cap[0].num_split_items == 0
+        _check(out, ref64, ref32, dtype, "ragged decode, %s" % ("length-balanced plan" if host else "uniform split"))
+        assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)
+        # the same parameter block again (what layers 1..L-1 of an iteration do)
+        out2 = torch.empty_like(out)
+        FA.relaunch(cap[0], q.to(DEV).data_ptr(), kn.to(DEV).data_ptr(), vn.to(DEV).data_ptr(), out2.data_ptr(), kg.data_ptr(), vg.data_ptr(), torch.device(DEV))
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu())
+    assert (outs[0] - outs[1]).abs().max().item() <= (2e-3 if dtype == torch.float16 else 1.6e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])

@@ -35,7 +35,7 @@ def params(q, kc, vc, cl, idx=None, kn=None, vn=None, causal=True, splits=0, var
     p.is_causal, p.dtype, p.num_splits, p.softmax_scale, p.variant = int(causal), (1 if q.dtype == torch.bfloat16 else 0), splits, q.shape[3] ** -0.5, variant
     p.max_seqlen_k_hint = kc.shape[1]        # the benchmark caches are exactly as long as the sequences
     keep = [out, q, kc, vc, cl, idx, kn, vn]
-    need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
+    need = K.klib_for(p.variant).vattn_attn_workspace_bytes(C.byref(p))
     if need:
         w = torch.empty(need // 4 + 1, dtype=torch.float32, device=DEV)
         p.workspace = w.data_ptr()
@@ -44,9 +44,10 @@ def params(q, kc, vc, cl, idx=None, kn=None, vn=None, causal=True, splits=0, var
 
 
 def time_ms(p, warmup=2, iters=5):
-    ms = K.klib().vattn_time_attn(C.byref(p), torch.cuda.current_stream().cuda_stream, warmup, iters)
+    lib = K.klib_for(p.variant)       # product library unless the variant names a lab build
+    ms = lib.vattn_time_attn(C.byref(p), torch.cuda.current_stream().cuda_stream, warmup, iters)
     if ms < 0:
-        raise RuntimeError(K.last_error())
+        raise RuntimeError(K.last_error(lib))
     return ms
 
 
@@ -149,4 +150,9 @@ if __name__ == "__main__":
             print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3] + (", prefill64 build %d" % ((v >> 8) & 15) if (v >> 8) & 15 else ""), {0: "default plan", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups", 7: "4 waves x 64 rows, LDS-DMA ring, in-wave software pipeline (prefill64)"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
-        decode(variant)
+        dvs = [variant]
+        if "--dvariants" in sys.argv:
+            dvs = [int(x) for x in sys.argv[sys.argv.index("--dvariants") + 1].split(",")]
+        for v in dvs:
+            print("-- decode variant %d (%s) --" % (v, "512-thread workgroups" if v & 65536 else "1024-thread workgroups" if v & 131072 else "256-thread workgroups (default)"))
+            decode(v)

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VATTN_LIB_OVERRIDE") or os.path.join(_HERE, "libvattn_amd.so")   # override: debug/ablation builds only
+LIB_PATH = os.path.join(_HERE, "libvattn_amd.so")
 
 
 class VattnConfig(C.Structure):

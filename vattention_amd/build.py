@@ -3,6 +3,7 @@
   vattention_amd/libvattn_amd.so        page manager + HIP VMM backend + gfx950 kernels  (hipcc)
   vattention_amd/_vtensor*.so           torch binding: tensor over a raw VA             (g++)
   tests/native/libvattn_fake_backend.so host-only physical backend for CPU tests        (g++)
+  tools/lab/libvattn_lab.so             the kernels + measurement scaffolding (-DVATTN_LAB), for kbench and the variant tests
 hipcc cross-compiles gfx950 without a GPU.  Artefacts are git-ignored but travel with gpurun.
 """
 from __future__ import annotations
@@ -48,7 +49,36 @@ def build_lib(force=False):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
             list(ex.map(lambda so: _run([hipcc, *flags, "-c", so[0], "-o", so[1]]), zip(srcs, objs)))
-        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-pthread", *objs, "-o", out])
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-pthread", "-Wl,-Bsymbolic", *objs, "-o", out])
+    return out
+
+
+LAB_SOURCES = ("attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "decode_kernels.hip", "cache_kernels.hip", "hybrid_kernels.hip")
+
+
+def build_lab(force=False):
+    """tools/lab/libvattn_lab.so: the KERNEL sources compiled with -DVATTN_LAB — the product kernels plus the measurement scaffolding
+    (alternative operand paths and schedules, in-launch merge protocols, timing ablations with wrong results) that tools/kbench.py
+    and the variant tests select through `variant` bits the product library rejects.  Test / measurement infrastructure: nothing in
+    vattention_amd/ loads it unless a caller passes such a variant (kernels.klib_lab)."""
+    outdir = os.path.join(ROOT, "tools", "lab")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "libvattn_lab.so")
+    srcs = [os.path.join(CSRC, f) for f in LAB_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
+                   os.path.join(ROOT, "include", "vattn_kernels.h")]
+    if force or _newer(out, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-unused-value", "-Wno-inline-asm"]
+        objdir = os.path.join(ROOT, "build", "obj_lab")
+        os.makedirs(objdir, exist_ok=True)
+        objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+            list(ex.map(lambda so: _run([hipcc, *flags, "-c", so[0], "-o", so[1]]), zip(srcs, objs)))
+        # -Bsymbolic: this library's calls bind to ITS OWN definitions — it exports the same C ABI (and the same C++ helpers and kernel
+        # launch stubs) as the product library that is already loaded with RTLD_GLOBAL, and must not be interposed by it
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-Wl,-Bsymbolic", *objs, "-o", out])
     return out
 
 
@@ -106,6 +136,7 @@ def build_reference_pyref():
 
 def build_all(force=False):
     build_lib(force)
+    build_lab(force)
     build_vtensor(force)
     build_fake_backend(force)
     build_reference_oracle()

@@ -173,6 +173,7 @@ __global__ void selftest_dma_high_kernel(int* res, const unsigned* gsrc) {
 // Counters of the single-launch merges (split-KV decode, KV-split prefill) for launches on stream `st`: created (and zeroed, stream-ordered) on first use, never while
 // the stream is being captured into a graph (then the caller takes the two-launch form; a warm-up call before capture creates it).
 int* merge_counters(hipStream_t st, size_t n_ints) {
+    if (!kLab) return nullptr;        // the in-launch merges of the stand-alone launches are measurement scaffolding (measured slower)
     struct Buf { int* p; size_t n; };
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, Buf> bufs;
@@ -232,6 +233,12 @@ int validate(const vattn_attn_params* p) {
     }
     if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
         return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
+    if (p->split_items && p->seqlen_q != 1) return fail(VATTN_K_ERR_INVALID, "split_items (length-balanced plan) applies to the decode form only");
+    if (!kLab) {
+        const int til = (p->variant >> 1) & 7;
+        if ((p->variant & ~kProductVariantMask) || !(til == 0 || til == 1 || til == 4 || til == 7))
+            return fail(VATTN_K_ERR_INVALID, "variant selects a measurement build that this library does not contain (tools/lab/libvattn_lab.so, -DVATTN_LAB)");
+    }
     return VATTN_K_OK;
 }
 
@@ -254,6 +261,10 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (p->k_new && p->seqlen_knew > 0 && !p->cache_seqlens) return fail(VATTN_K_ERR_INVALID, "If key is supplied, seqlens_k must also be passed in");
     return p->seqlen_q == 1 ? launch_decode_form(p, st) : launch_prefill_form(p, st);
+}
+
+int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqlens_host, vattn_decode_item* items_out, int32_t cap, int32_t* seq_out) {
+    return decode_plan(p, cache_seqlens_host, items_out, cap, seq_out);
 }
 
 size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode) {

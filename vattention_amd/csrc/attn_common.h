@@ -24,6 +24,21 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kLog2e = 1.4426950408889634f;
 
+// Two builds of these sources.  The PRODUCT library (libvattn_amd.so) instantiates the kernels the launch plans choose, and accepts
+// only the `variant` bits that select between them (explicit tiling / workgroup order / workgroup shape: what a benchmark needs to
+// A/B the plan against its alternatives).  The LAB library (-DVATTN_LAB, tools/lab/libvattn_lab.so, built by vattention_amd/build.py
+// for tools/kbench.py and the variant tests) adds the measurement scaffolding: alternative operand paths and schedules, the
+// in-launch merge protocols that measured slower than two launches, and timing ablations whose RESULTS ARE WRONG.
+#ifdef VATTN_LAB
+constexpr bool kLab = true;
+#else
+constexpr bool kLab = false;
+#endif
+// variant bits of vattn_attn_params a product build accepts: bits 1-3 tiling {0 plan, 1 = 8 waves x 32 rows, 4 = 4 waves x 32 rows,
+// 7 = prefill64}; bits 5-6 workgroup order; bit 7 one 16-head block per decode workgroup; bits 12-13 role policy of the fused
+// launch; bits 16-17 decode workgroup shape
+constexpr int kProductVariantMask = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | (3 << 16);
+
 template <typename T> struct Tr;
 template <> struct Tr<_Float16> {
     using v8 = f16x8;
@@ -234,6 +249,7 @@ void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, in
 int* merge_counters(hipStream_t st, size_t n_ints);                      // attn_api.hip: zeroed per-(device, stream) counters, NULL while capturing
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
 size_t decode_workspace_bytes(const vattn_attn_params* p);
+int decode_plan(const vattn_attn_params* p, const int32_t* lens, vattn_decode_item* items, int cap, int32_t* seq);   // decode_kernels.hip
 int launch_hybrid(const vattn_attn_params* prefill, const vattn_attn_params* decode, void* ws, hipStream_t st);   // hybrid_kernels.hip
 size_t hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode);
 

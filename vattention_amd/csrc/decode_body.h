@@ -1,6 +1,8 @@
 // decode_body.h — the split-KV decode workgroup (see decode_kernels.hip for the overview) as a device function plus the kernel
 // that maps a grid onto it.  Included by decode_kernels.hip and hybrid_kernels.hip.
 #pragma once
+#include <type_traits>
+
 #include "attn_common.h"
 
 namespace vattn_k {
@@ -14,9 +16,12 @@ constexpr int DC_BN = 32;     // keys per wave tile
 // NB: 16-head blocks per workgroup (round 2).  With G > 16 query heads per kv head the blocks gb*NB .. gb*NB + NB-1 share ONE pass
 // over the K/V rows: the K fragments (registers) and the V^T staging (LDS) of a tile feed NB score / output MFMA chains.  NB = 2
 // keeps the kernel inside the 168-register budget of three workgroups per CU; wider groups run as ceil(G/32) such workgroups.
-template <typename T, int HD, bool USE_TR, int NB = 1>
+// W:  waves per workgroup (4 = 256 threads, three workgroups per CU; 8 = 512 threads, two per CU: 16 waves per CU instead of 12 and a
+//     third fewer partials for the same number of resident wave-tiles).
+template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES>
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
-                                            const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0) {
+                                            const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0,
+                                            const int item = -1, const int item_tb = 0, const int item_te = 0) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
@@ -41,14 +46,14 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     // each sequence divides ITS OWN length evenly over the splits (balanced for ragged batches)
     const int ntiles_total = (Lk + DC_BN - 1) / DC_BN;
     const int tiles_per_split = (ntiles_total + num_splits - 1) / num_splits;
-    const int tile_begin = split * tiles_per_split;
-    const int tile_end = min(ntiles_total, tile_begin + tiles_per_split);
+    // item >= 0: a piece [item_tb, item_te) of a length-balanced plan (vattn_decode_plan) instead of split `split` of num_splits
+    const int tile_begin = item >= 0 ? item_tb : split * tiles_per_split;
+    const int tile_end = min(ntiles_total, item >= 0 ? item_te : tile_begin + tiles_per_split);
 
     // Fused append (seqlen_knew == 1): the new K/V row sits at key index Lk-1.  Every workgroup that reads the tile
     // holding it substitutes the row from k_new/v_new in registers; the gb == 0 workgroup also stores it into the
     // cache (flash_attn_interface.py:1168-1176: append, then attend).  No inter-workgroup ordering is needed.
     const int new_key = fused_append ? Lk - 1 : -1;
-    const int new_tile = fused_append ? new_key / DC_BN : -1;
 
     const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
     const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
@@ -79,6 +84,21 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
         }
     }
 
+    // W > 4 (two 8-wave or one 16-wave workgroup per CU: 128 registers per lane): the Q^T fragments live in LDS (one copy per workgroup,
+    // every wave holds the same values) and are re-read for each tile's score MFMAs instead of occupying 4 x KK registers for the
+    // whole key walk — LDS bandwidth is idle in this kernel, registers are what bounds the waves (and so the bytes) in flight
+    constexpr bool QLDS = W > DC_WAVES;
+    char* const qsm = smem + W * 16 * HD * 4 + W * 16 * 4 * 2;
+    if constexpr (QLDS) {
+        if (wave == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) *(V8*)(qsm + ((nb * KK + kk) * 64 + lane) * 16) = qf[nb][kk];
+        }
+        __syncthreads();
+    }
+
     f32x4 o[NB][DB];
     float m_run[NB], l_run[NB];
 #pragma unroll
@@ -95,68 +115,73 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
     const T* kbase_u = uniform_ptr(kbase);
     const T* vbase_u = uniform_ptr(vbase);
-    unsigned koff[2], voff[VPASS];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) koff[kb] = (unsigned)(16 * kb + l15) * k_rs_bytes + (unsigned)g4 * 16u;
-#pragma unroll
-    for (int ps = 0; ps < VPASS; ps++) {
-        const int idx = ps * 64 + lane;
-        voff[ps] = (unsigned)(idx / CPR) * v_rs_bytes + (unsigned)(idx % CPR) * 16u;
-    }
+    // per-lane byte offsets inside a tile: ONE live register each; the row groups of the further instructions are wave-uniform
+    // multiples of the row stride added per instruction (in the VGPR offset: the instruction's scalar offset is EXCLUDED from the
+    // descriptor's bounds check, and the bound is what keeps the loads off unmapped pages), the k-steps travel in the immediate
+    const unsigned koff0 = (unsigned)l15 * k_rs_bytes + (unsigned)g4 * 16u;
+    const unsigned voff0 = (unsigned)(lane / CPR) * v_rs_bytes + (unsigned)(lane % CPR) * 16u;
+    const unsigned k_kb_step = __builtin_amdgcn_readfirstlane(16u * k_rs_bytes);
+    const unsigned v_ps_step = __builtin_amdgcn_readfirstlane((unsigned)(64 / CPR) * v_rs_bytes);
     auto load_tile = [&](int tile) {
         const int k0 = tile * DC_BN;
         int rem = Lk - k0;
         rem = rem < 0 ? 0 : (rem > DC_BN ? DC_BN : rem);
         const __amdgpu_buffer_rsrc_t kr = make_rsrc(kbase_u + (int64_t)k0 * p.k_row_stride, (unsigned)rem * k_rs_bytes);
         const __amdgpu_buffer_rsrc_t vr = make_rsrc(vbase_u + (int64_t)k0 * p.v_row_stride, (unsigned)rem * v_rs_bytes);
+        // (opaque copies: the per-instruction offsets are re-derived from ONE register each with a v_add per load instead of being
+        // hoisted out of the key loop into ten loop-invariant registers — registers are what bounds the waves in flight here)
+        unsigned ko = koff0, vo = voff0;
+        asm volatile("" : "+v"(ko), "+v"(vo));
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-            for (int kk = 0; kk < KK; kk++) kreg[kb][kk] = buf_load16(kr, koff[kb] + 64u * kk);
+            for (int kk = 0; kk < KK; kk++) kreg[kb][kk] = buf_load16(kr, ko + (unsigned)kb * k_kb_step + 64u * kk);
 #pragma unroll
-        for (int ps = 0; ps < VPASS; ps++) vreg[ps] = buf_load16(vr, voff[ps]);
-        if (tile == new_tile) {      // wave-uniform, at most once per workgroup
-            const T* kn = (const T*)p.k_new + (int64_t)b * p.knew_batch_stride + (int64_t)hk * p.knew_head_stride;
-            const T* vn = (const T*)p.v_new + (int64_t)b * p.vnew_batch_stride + (int64_t)hk * p.vnew_head_stride;
-            T* kc = (T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride + (int64_t)new_key * p.k_row_stride;
-            T* vc = (T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride + (int64_t)new_key * p.v_row_stride;
+        for (int ps = 0; ps < VPASS; ps++) vreg[ps] = buf_load16(vr, vo + (unsigned)ps * v_ps_step);
+    };
+    // the new K/V row (fused append) replaces its row of the LAST tile in registers; the gb == 0 workgroup also stores it
+    auto substitute_new_row = [&](int k0) {
+        const T* kn = (const T*)p.k_new + (int64_t)b * p.knew_batch_stride + (int64_t)hk * p.knew_head_stride;
+        const T* vn = (const T*)p.v_new + (int64_t)b * p.vnew_batch_stride + (int64_t)hk * p.vnew_head_stride;
+        T* kc = (T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride + (int64_t)new_key * p.k_row_stride;
+        T* vc = (T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride + (int64_t)new_key * p.v_row_stride;
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-                if (k0 + 16 * kb + l15 == new_key) {
-                    V8 kn8[KK];
+        for (int kb = 0; kb < 2; kb++)
+            if (k0 + 16 * kb + l15 == new_key) {
+                V8 kn8[KK];
 #pragma unroll
-                    for (int kk = 0; kk < KK; kk++) kn8[kk] = as_v8<V8>(*(const uint4*)(kn + 32 * kk + 8 * g4));
-                    if (rope) {                  // the new key is rotated before it is attended and before it is stored
+                for (int kk = 0; kk < KK; kk++) kn8[kk] = as_v8<V8>(*(const uint4*)(kn + 32 * kk + 8 * g4));
+                if (rope) {                  // the new key is rotated before it is attended and before it is stored
 #pragma unroll
-                        for (int kk = 0; kk < KK / 2; kk++) {
-                            V8 c, s;
-                            rope_load<T>(p, (int64_t)new_key, 32 * kk + 8 * g4, c, s);
-                            rope8<T>(kn8[kk], kn8[kk + KK / 2], c, s);
-                        }
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < KK; kk++) {
-                        uint4 v;
-                        __builtin_memcpy(&v, &kn8[kk], 16);
-                        kreg[kb][kk] = v;
-                        if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(kc + 32 * kk + 8 * g4) = v;
+                    for (int kk = 0; kk < KK / 2; kk++) {
+                        V8 c, s;
+                        rope_load<T>(p, (int64_t)new_key, 32 * kk + 8 * g4, c, s);
+                        rope8<T>(kn8[kk], kn8[kk + KK / 2], c, s);
                     }
                 }
 #pragma unroll
-            for (int ps = 0; ps < VPASS; ps++) {
-                const int idx = ps * 64 + lane;
-                if (k0 + idx / CPR == new_key) {
-                    const uint4 v = *(const uint4*)(vn + (idx % CPR) * 8);
-                    vreg[ps] = v;
-                    if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(vc + (idx % CPR) * 8) = v;
+                for (int kk = 0; kk < KK; kk++) {
+                    uint4 v;
+                    __builtin_memcpy(&v, &kn8[kk], 16);
+                    kreg[kb][kk] = v;
+                    if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(kc + 32 * kk + 8 * g4) = v;
                 }
+            }
+#pragma unroll
+        for (int ps = 0; ps < VPASS; ps++) {
+            const int idx = ps * 64 + lane;
+            if (k0 + idx / CPR == new_key) {
+                const uint4 v = *(const uint4*)(vn + (idx % CPR) * 8);
+                vreg[ps] = v;
+                if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(vc + (idx % CPR) * 8) = v;
             }
         }
     };
-
-    int tile = __builtin_amdgcn_readfirstlane(tile_begin + wave);
-    load_tile(tile < tile_end ? tile : ntiles_total);     // past the end: every lane out of range, no access
-    for (; tile < tile_end; tile += DC_WAVES) {
+    // One 32-key tile of this wave: V registers -> wave-private LDS, S^T = K.Q^T on the register-resident K fragments, request the
+    // wave's next tile into the freed registers, online softmax, O^T += V^T.P^T.  RAGGED: the sequence's last tile (keys at or
+    // beyond Lk are masked) — a literal at both call sites, so the steady-state loop carries no mask and no append code.
+    auto process_tile = [&](auto ragged_tag, const int tile, const int next_tile) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int k0 = tile * DC_BN;
         // ---- V: registers -> wave-private LDS ([d/16][key][16 d]) ----
 #pragma unroll
@@ -165,24 +190,34 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             const int row = idx / CPR, c = idx % CPR;
             *(uint4*)(vsm + (c >> 1) * VSUB + row * 32 + ((c & 1) << 4)) = vreg[ps];
         }
-        // ---- S^T = K.Q^T on the register-resident K fragments (every head block of the group uses the same fragments) ----
+        // ---- S^T = K.Q^T (every head block of the group uses the same K fragments) ----
         f32x4 s[NB][2];
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++)
+        for (int nb = 0; nb < NB; nb++) {
+            V8 qt[KK];
+            if constexpr (QLDS) {
+                asm volatile("" ::: "memory");                // a fresh read per tile (not hoisted back into registers)
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) qt[kk] = *(const V8*)(qsm + ((nb * KK + kk) * 64 + lane) * 16);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) qt[kk] = qf[nb][kk];
+            }
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
                 s[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < KK; kk++) s[nb][kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qf[nb][kk], s[nb][kb]);
+                for (int kk = 0; kk < KK; kk++) s[nb][kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qt[kk], s[nb][kb]);
             }
-        // prefetch the wave's next tile while this one is being consumed (out of range past the split's end)
-        load_tile(tile + DC_WAVES < tile_end ? tile + DC_WAVES : ntiles_total);
+        }
+        // request the wave's next tile while this one is being consumed (past the end: every lane out of range, no access)
+        if (!RAGGED) load_tile(next_tile);
 
         // s[nb][kb][r] = S^T[key = k0 + 16*kb + 4*g4 + r][head row l15 of block nb]
         V8 pf[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
-            if (k0 + DC_BN > Lk) {
+            if (RAGGED) {
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -239,12 +274,33 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             for (int nb = 0; nb < NB; nb++) o[nb][db] = X::mfma16(a, pf[nb], o[nb][db]);
         }
         __builtin_amdgcn_wave_barrier();
+    };
+
+    // This wave's tiles: tile_begin + wave, + W, ... below tile_end.  The sequence's LAST tile (the only one that can be ragged, and
+    // the one that holds the appended row) is always the last tile of whichever wave owns it: it is taken out of the steady-state
+    // loop and processed after it.
+    const int last_tile = ntiles_total - 1;
+    const bool special_last = fused_append || (Lk % DC_BN) != 0;
+    const int first = __builtin_amdgcn_readfirstlane(tile_begin + wave);
+    const bool own_last = special_last && last_tile >= first && last_tile < tile_end && ((last_tile - first) % W) == 0;
+    const int loop_end = own_last ? last_tile : tile_end;          // wave-uniform
+    if (first < loop_end) {
+        load_tile(first);
+        for (int tile = first; tile < loop_end; tile += W) {
+            const int nxt = tile + W;
+            process_tile(std::false_type{}, tile, nxt < loop_end ? nxt : ntiles_total);
+        }
+    }
+    if (own_last) {
+        load_tile(last_tile);
+        if (fused_append) substitute_new_row(last_tile * DC_BN);
+        process_tile(std::true_type{}, last_tile, ntiles_total);
     }
 
-    // ---- merge the 4 waves (each holds a partial softmax over its own tiles), one head block after the other ----
+    // ---- merge the W waves (each holds a partial softmax over its own tiles), one head block after the other ----
     float* osm = (float*)smem;                          // [wave][16 rows][HD]
-    float* msm = (float*)(smem + DC_WAVES * 16 * HD * 4);   // [wave][16] m, then [wave][16] l
-    float* lsm = msm + DC_WAVES * 16;
+    float* msm = (float*)(smem + W * 16 * HD * 4);   // [wave][16] m, then [wave][16] l
+    float* lsm = msm + W * 16;
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         float lr = l_run[nb];
@@ -261,33 +317,33 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             lsm[wave * 16 + l15] = lr;
         }
         __syncthreads();
-        for (int idx = tid; idx < 16 * HD; idx += 64 * DC_WAVES) {
+        for (int idx = tid; idx < 16 * HD; idx += 64 * W) {
             const int row = idx / HD, d = idx % HD;
             const int rh = (gb * NB + nb) * 16 + row;
             if (rh >= G) continue;
             float mx = -INFINITY;
 #pragma unroll
-            for (int w = 0; w < DC_WAVES; w++) mx = fmaxf(mx, msm[w * 16 + row]);
+            for (int w = 0; w < W; w++) mx = fmaxf(mx, msm[w * 16 + row]);
             float acc = 0.f, lsum = 0.f;
             const float mxs = (mx == -INFINITY) ? 0.f : mx * sc;
 #pragma unroll
-            for (int w = 0; w < DC_WAVES; w++) {
+            for (int w = 0; w < W; w++) {
                 const float f = fast_exp2(msm[w * 16 + row] * sc - mxs);
                 acc += f * osm[(w * 16 + row) * HD + d];
                 lsum += f * lsm[w * 16 + row];
             }
             const int hh = hk * G + rh;
             const float inv = (lsum == 0.f || lsum != lsum) ? 1.f : 1.f / lsum;
-            if (num_splits == 1) {
+            if (num_splits == 1 && item < 0) {
                 ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d] = X::cvt(acc * inv);
                 if (p.softmax_lse && d == 0)
                     p.softmax_lse[(int64_t)b * p.h + hh] = (lsum == 0.f) ? INFINITY : (mx * p.softmax_scale + __logf(lsum));
             } else {
                 float* oacc = (float*)p.workspace;
-                float* lacc = oacc + (int64_t)num_splits * p.b * p.h * HD;
-                const int64_t row_idx = ((int64_t)split * p.b + b) * p.h + hh;
+                float* lacc = oacc + (item >= 0 ? (int64_t)p.num_split_items : (int64_t)num_splits * p.b) * p.h * HD;
+                const int64_t row_idx = item >= 0 ? (int64_t)item * p.h + hh : ((int64_t)split * p.b + b) * p.h + hh;
                 const float lv = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
-                if (merge_mode == 2) {      // handed to the merging workgroup inside this launch: device-scope stores (attn_common.h)
+                if (kLab && merge_mode == 2) {      // handed to the merging workgroup inside this launch: device-scope stores (attn_common.h)
                     store_dev(oacc + row_idx * HD + d, acc * inv);
                     if (d == 0) store_dev(lacc + row_idx, lv);
                 } else {
@@ -376,11 +432,18 @@ __device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params
 
 // gblocks = head-block GROUPS per kv head (ceil(ceil(G/16) / NB)).  `done`: NULL = partials are merged by combine_kernel in a second
 // launch; else one zero-initialised int per (sequence, kv head, group): single-launch merge.
-template <typename T, int HD, bool USE_TR, int NB>
-__global__ __launch_bounds__(64 * DC_WAVES, (HD > 128 || (HD == 128 && NB > 1)) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done, int merge_mode) {
+template <typename T, int HD, bool USE_TR, int NB, int W = DC_WAVES>
+__global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB > 1)) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done, int merge_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;
     int split, hk, gb, b;
+    if (p.split_items != nullptr) {
+        // length-balanced plan: blockIdx.x = work item (a piece of ONE sequence), blockIdx.y = (kv head, head-block group)
+        const vattn_decode_item it = p.split_items[blockIdx.x];
+        decode_body<T, HD, USE_TR, NB, W>(p, 2, gblocks, fused_append, it.index_in_seq, blockIdx.y / gblocks, blockIdx.y % gblocks, it.b, smem, 0,
+                                          (int)blockIdx.x, it.tile_begin, it.tile_end);
+        return;
+    }
     if (gridDim.y == 1 && gridDim.z == 1 && gblocks > 1) {
         // G > 32 query heads per kv head (MQA models): the head-block groups of one (split, kv head, sequence) read the
         // SAME K/V rows.  1-D grid laid out so that those sibling workgroups get consecutive slots on ONE XCD (ids 8 apart):
@@ -400,8 +463,8 @@ __global__ __launch_bounds__(64 * DC_WAVES, (HD > 128 || (HD == 128 && NB > 1)) 
         gb = blockIdx.y % gblocks;
         b = blockIdx.z;
     }
-    decode_body<T, HD, USE_TR, NB>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0);
-    if (done != nullptr && num_splits > 1)
+    decode_body<T, HD, USE_TR, NB, W>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0);
+    if (kLab && W == DC_WAVES && done != nullptr && num_splits > 1)
         decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket, merge_mode);
 }
 

@@ -60,6 +60,47 @@ __global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int n
 }
 
 
+// The same merge for a length-balanced plan (vattn_decode_plan): sequence b owns items [first, first + count) — count differs per
+// sequence — and item i's partial rows are (i * h + head).
+template <typename T, int HD>
+__global__ __launch_bounds__(128) void combine_items_kernel(vattn_attn_params p) {
+    __shared__ float wsm[128];
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;                  // b * h + head
+    const int hh = (int)(row % p.h);
+    const int b = (int)(row / p.h);
+    const int tid = threadIdx.x;
+    const int first = p.split_seq[2 * b], cnt = p.split_seq[2 * b + 1];      // cnt <= 128
+    const float* oacc = (const float*)p.workspace;
+    const float* lacc = oacc + (int64_t)p.num_split_items * p.h * HD;
+    const float my = (tid < cnt) ? lacc[(int64_t)(first + tid) * p.h + hh] : -INFINITY;
+    float mx = my;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
+    const float mxs = (mx == -INFINITY) ? 0.f : mx;
+    const float w = (tid < cnt) ? fast_exp2(my - mxs) : 0.f;
+    float ws = w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ws += xor_shuffle(ws, o);
+    if ((tid & 63) == 0) red[2 + (tid >> 6)] = ws;
+    wsm[tid] = w;
+    __syncthreads();
+    const float wsum = red[2] + red[3];
+    const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+    if (tid < HD) {
+        const float* src = oacc + ((int64_t)first * p.h + hh) * HD + tid;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int s = 0; s < cnt; s++) acc += wsm[s] * src[(int64_t)s * p.h * HD];
+        ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
+    }
+    if (p.softmax_lse && tid == 0)
+        p.softmax_lse[(int64_t)b * p.h + hh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+}
+
 // Split count for the decode form.  The kernel is built for 3 workgroups per CU (<= 168 VGPRs, 33 KiB LDS), i.e.
 // 768 resident workgroups on 256 CUs; like the reference's heuristic (flash_api.cpp:258-323) pick the smallest
 // split count whose last "round" of workgroups is nearly full, but against THIS chip's residency.
@@ -102,39 +143,72 @@ static inline int decode_groups(const vattn_attn_params* p) {
 // multi-XCD part each one writes back and invalidates the XCD's L2 — B1 @ 32 k 23.7 -> 41.5 us, B16 @ 32 k 203 -> 243 us
 // (profiles/r02_kbench_decode_merge.txt).  The group counters live in a small library-owned device buffer per (device, stream),
 // zeroed when it is created; the kernel leaves them zero.
-static inline long decode_slots(const vattn_attn_params* p) { return (p->d == 128 && decode_nb(p) == 2) ? 512 : 768; }   // resident workgroups
+// Workgroup shape (decode_body.h: W waves per workgroup).  Variant bit 16: 8 waves (two workgroups per CU); bit 17: 16 waves (one).
+static inline int decode_shape(const vattn_attn_params* p) {
+    if (p->d != 128 || decode_nb(p) != 1) return 0;      // the alternative shapes exist for d = 128, one head block per workgroup
+    return (p->variant & 65536) ? 1 : (p->variant & 131072) ? 2 : 0;      // 1: 8 waves (512 slots), 2: 16 waves (256 slots)
+}
+static inline long decode_slots(const vattn_attn_params* p) {      // resident workgroups
+    if (decode_shape(p) == 1) return 512;
+    if (decode_shape(p) == 2) return 256;
+    return (p->d == 128 && decode_nb(p) == 2) ? 512 : 768;
+}
 static inline bool decode_inline_merge(const vattn_attn_params* p, int splits, int groups) {
     (void)groups;
     return splits > 1 && (p->variant & (512 | 1024)) != 0;      // bit 9: fence protocol, bit 10: device-scope accesses, no fence
 }
-template <typename T, int HD, int NB> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
-    const bool use_tr = (p->variant & 1) == 0;
+template <typename T, int HD, int NB, int W = DC_WAVES> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
+    const bool use_tr = (p->variant & 1) == 0 || W != DC_WAVES;
     const int groups = decode_groups(p);
-    const int splits = pick_splits(p, groups, decode_slots(p));
+    const bool planned = p->split_items != nullptr;
+    if (planned && (!p->split_seq || p->num_split_items <= 0)) return fail(VATTN_K_ERR_INVALID, "split_items needs split_seq and num_split_items");
+    const int splits = planned ? 2 : pick_splits(p, groups, decode_slots(p));
     if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
-    dim3 grid(splits, p->h_k * groups, p->b), block(64 * DC_WAVES);
-    if (groups > 1 && !(p->variant & 64)) {            // sibling groups share an XCD (variant bit 6: plain 3-D grid, for A/B)
+    dim3 grid(splits, p->h_k * groups, p->b), block(64 * W);
+    if (planned) grid = dim3((unsigned)p->num_split_items, p->h_k * groups, 1);
+    if (groups > 1 && !(p->variant & 64) && !planned) {            // sibling groups share an XCD (variant bit 6: plain 3-D grid, for A/B)
         const long w = (long)splits * p->h_k * p->b;
         grid = dim3((unsigned)(((w + 7) / 8) * 8 * groups));
     }
-    const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;   // merge area >= V staging (4*8 KiB)
+    const size_t smem = (size_t)W * 16 * HD * 4 + W * 16 * 4 * 2 + (W > DC_WAVES ? NB * (HD / 32) * 1024 : 0);   // merge area >= V staging (W x 8 KiB), then Q^T fragments
+    if (smem > 48 * 1024) {
+        static const bool once = [] {
+            (void)hipFuncSetAttribute((const void*)decode_kernel<T, HD, true, NB, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)W * 16 * HD * 4 + W * 16 * 4 * 2 + NB * (HD / 32) * 1024));
+            return true;
+        }();
+        (void)once;
+    }
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
     const vattn_attn_params& q = *p;
-    int* done = decode_inline_merge(p, splits, groups) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
+    int* done = (W == DC_WAVES && !planned && decode_inline_merge(p, splits, groups)) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
     const bool inline_merge = done != nullptr;
     const int mm = !inline_merge ? 0 : (p->variant & 1024) ? 2 : 1;
-    if (use_tr)
-        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
-    else
-        hipLaunchKernelGGL((decode_kernel<T, HD, false, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
-    if (splits > 1 && !inline_merge) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, splits, 1);
+    if constexpr (W != DC_WAVES) {
+        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB, W>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
+    } else {
+        bool plain = false;
+        if constexpr (kLab) {      // variant bit 0: V^T fragments by plain LDS reads
+            if (!use_tr) {
+                hipLaunchKernelGGL((decode_kernel<T, HD, false, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
+                plain = true;
+            }
+        }
+        if (!plain) hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
+    }
+    if (planned) hipLaunchKernelGGL((combine_items_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q);
+    else if (splits > 1 && !inline_merge) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, splits, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;
 }
 
 template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hipStream_t st) {
+    if constexpr (HD == 128) {
+        const int shape = decode_shape(p);
+        if (shape == 1) return launch_decode_nb<T, 128, 1, 8>(p, st);
+        if (shape == 2) return launch_decode_nb<T, 128, 1, 16>(p, st);
+    }
     return decode_nb(p) == 2 ? launch_decode_nb<T, HD, 2>(p, st) : launch_decode_nb<T, HD, 1>(p, st);
 }
 
@@ -144,7 +218,66 @@ int launch_decode_form(const vattn_attn_params* p, hipStream_t st) {
     return f16 ? launch_decode_t<_Float16, 128>(p, st) : launch_decode_t<__bf16, 128>(p, st);
 }
 
+// Length-balanced split of a ragged decode batch (include/vattn_kernels.h, vattn_decode_plan).  Every sequence is cut into pieces of at
+// most T tiles; T is the smallest piece length for which the pieces of ALL sequences fit the resident workgroups in one round
+// (slots / (kv heads x head-block groups) items), or — when the batch alone exceeds a round — about two pieces per sequence on
+// average, so that the dispatcher packs rounds of near-equal workgroups instead of waiting for the longest sequence.  Pieces shorter
+// than 22 tiles (704 keys) cost more in prologue / merge than they return (pick_splits' measurement).
+int decode_plan(const vattn_attn_params* p, const int32_t* lens, vattn_decode_item* items, int cap, int32_t* seq) {
+    if (!p || !lens || !items || !seq || p->b <= 0 || p->h_k <= 0 || p->h <= 0) return VATTN_K_ERR_INVALID;
+    if (p->seqlen_q != 1 || p->b < 2) return 0;
+    const int groups = decode_groups(p);
+    if (groups > 1) return 0;                          // MQA groups wider than 32 heads keep the XCD-sibling grid
+    const long slots = decode_slots(p);
+    const long gps = (long)p->h_k * groups;
+    long total = 0, longest = 0;
+    for (int b = 0; b < p->b; b++) {
+        const long lk = (long)(lens[b] < 0 ? 0 : lens[b]) + p->seqlen_knew;
+        const long t = (lk + DC_BN - 1) / DC_BN;
+        total += t;
+        longest = t > longest ? t : longest;
+    }
+    if (total <= 0) return 0;
+    // what the uniform split would do: every sequence S splits, the launch lasts as long as the longest sequence's share
+    vattn_attn_params u = *p;
+    u.split_items = nullptr;
+    const long S = pick_splits(&u, groups, slots);
+    const long uniform_makespan = (longest + S - 1) / S;
+    long target = slots / gps;                          // items that make one round
+    if (target < 2L * p->b) target = 2L * p->b;
+    long T = (total + (target - p->b) - 1) / (target - p->b);
+    const long kMinTiles = 22;
+    if (T < kMinTiles) T = kMinTiles;
+    if (longest > 128 * T) T = (longest + 127) / 128;   // the merge handles at most 128 pieces per sequence
+    // the balanced plan must shorten the launch noticeably: its longest item is T tiles, and it adds partial traffic for every piece
+    if (T * 100 > uniform_makespan * 85) return 0;
+    int n = 0;
+    for (int b = 0; b < p->b; b++) {
+        const long lk = (long)(lens[b] < 0 ? 0 : lens[b]) + p->seqlen_knew;
+        const long t = (lk + DC_BN - 1) / DC_BN;
+        long cnt = (t + T - 1) / T;
+        if (cnt < 1) cnt = 1;
+        // equal pieces inside the sequence (not T, T, ..., remainder): the same count, no runt
+        const long per = cnt ? (t + cnt - 1) / cnt : 0;
+        seq[2 * b] = n;
+        seq[2 * b + 1] = (int32_t)cnt;
+        for (long j = 0; j < cnt; j++) {
+            if (n >= cap) return 0;
+            long tb = j * per, te = tb + per;
+            if (tb > t) tb = t;
+            if (te > t) te = t;
+            items[n].b = b;
+            items[n].tile_begin = (int32_t)tb;
+            items[n].tile_end = (int32_t)te;
+            items[n].index_in_seq = (int32_t)j;
+            n++;
+        }
+    }
+    return n;
+}
+
 size_t decode_workspace_bytes(const vattn_attn_params* p) {
+    if (p->split_items) return (size_t)(p->num_split_items > 0 ? p->num_split_items : 0) * p->h * (p->d + 1) * sizeof(float);
     const int groups = decode_groups(p);
     const int splits = pick_splits(p, groups, decode_slots(p));
     if (splits <= 1) return 0;

@@ -21,7 +21,6 @@
 // (bottom-right causal), softmax.h:69-157 (fp32 max/sum via exp2, P rounded to the I/O dtype before PV),
 // flash_fwd_kernel.h:57-499 (the operator's non-split kernel), :1116-1297 (split combine, here combine_rows_kernel).
 // Every K/V access is bounded by a buffer descriptor that ends at the sequence's visible length.
-#include <cstdlib>
 #include "attn_common.h"
 
 namespace vattn_k {
@@ -555,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                     f32x4 w;
 #pragma unroll
                     for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
-                    if (merge_mode == 2) {
+                    if (kLab && merge_mode == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) store_dev(opart + 32 * db + 8 * tq + 4 * g + e, w[e]);
                     } else {
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 }
             if (g == 0) {
                 const float lv = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_log2 + __log2f(l_tot));
-                if (merge_mode == 2) store_dev(lpart + row, lv);
+                if (kLab && merge_mode == 2) store_dev(lpart + row, lv);
                 else lpart[row] = lv;
             }
         } else if (my_q < Sq) {
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     }
     (void)sc_ln;
     // single-launch merge of the key-range shares (attn_common.h)
-    if (nsplit > 1 && done != nullptr)
+    if (kLab && nsplit > 1 && done != nullptr)
         prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, done + ((int64_t)b * p.h + h) * nqb + qb, (int*)(smem + VBASE + 3 * S::kTileBytes), merge_mode);
 }
 
@@ -636,32 +635,32 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
     hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit, done, merge_mode);
 }
 
-// variant bits 8-11 select a build of the kernel (tools/kbench.py): 0 = product; 1-3, 10-12 = schedule variants; 4-9 = timing
-// ablations (wrong results)
+// Product: ONE build per dtype (padded K image, 24 exp2 pairs in phase A, fragment ring of 4).  The lab library (-DVATTN_LAB) adds the
+// schedule variants and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 1, 3, 10 = correct alternatives;
+// 4-9 = ablations whose RESULTS ARE WRONG).
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
-    static const int env_sel = [] { const char* e = getenv("VATTN_PREFILL64_BUILD"); return e ? atoi(e) & 15 : 0; }();   // measurement hook
-    const int sel = ((p->variant >> 8) & 15) ? ((p->variant >> 8) & 15) : env_sel;
-    // product build: padded K image (ABL bit 7; 28 fewer VALU instructions per tile than the XOR-swizzled image, same time within noise)
+#ifdef VATTN_LAB
+    const int sel = (p->variant >> 8) & 15;
     if (p->dtype == VATTN_DTYPE_BF16) {
-        if (sel == 1) launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode);
-        else if (sel == 3) launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done, merge_mode);
-        else launch64_t<__bf16, 128, 24, 4>(p, st, nsplit, done, merge_mode);
-        return;
+        if (sel == 1) return launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode);
+        if (sel == 3) return launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done, merge_mode);
+    } else {
+        switch (sel) {
+            case 1: case 10: return launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode);   // row sums by v_dot2c over the packed P (no
+                                                                     // gain: the dot instructions serialise with the MFMA pipe, profiles/r02_issue_probe.txt)
+            case 3: return launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done, merge_mode);                    // XOR-swizzled K image (round 2's first layout)
+            case 4: return launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no LDS-DMA in the steady state
+            case 5: return launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no fma / exp2 / row sums
+            case 6: return launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no per-tile wait + barrier
+            case 7: return launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit, done, merge_mode);             // no LDS fragment reads
+            case 8: return launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode);           // MFMAs + fragment reads + barrier
+            case 9: return launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode);  // MFMAs only
+            default: break;
+        }
     }
-    switch (sel) {
-        case 1: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;   // row sums by v_dot2c over the packed P (no gain: the
-                                                                               // dot instructions serialise with the MFMA pipe, profiles/r02_issue_probe.txt)
-        case 2: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode); break;        // = product
-        case 10: launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;  // = build 1
-        case 3: launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done, merge_mode); break;          // XOR-swizzled K image (the round's first layout)
-        case 4: launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;          // no LDS-DMA in the steady state
-        case 5: launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;          // no fma / exp2 / row sums
-        case 6: launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;          // no per-tile wait + barrier
-        case 7: launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;         // no LDS fragment reads
-        case 8: launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;       // MFMAs + fragment reads + barrier
-        case 9: launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode); break;   // MFMAs only
-        default: launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode); break;
-    }
+#endif
+    if (p->dtype == VATTN_DTYPE_BF16) launch64_t<__bf16, 128, 24, 4>(p, st, nsplit, done, merge_mode);
+    else launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode);
 }
 
 }  // namespace vattn_k

@@ -340,7 +340,7 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
                     f32x4 w;
 #pragma unroll
                     for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
-                    if (merge_mode == 2) {
+                    if (kLab && merge_mode == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) store_dev(opart + 32 * db + 8 * tq + 4 * g + e, w[e]);
                     } else {
@@ -349,7 +349,7 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
                 }
             if (g == 0) {
                 const float lv = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_run[qc] * sc + __log2f(l_tot));
-                if (merge_mode == 2) store_dev(lpart + row, lv);
+                if (kLab && merge_mode == 2) store_dev(lpart + row, lv);
                 else lpart[row] = lv;
             }
         } else if (my_q < Sq) {
@@ -394,7 +394,7 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
         }
     }
     // single-launch merge of the key-range shares (attn_common.h): the workgroup that completes the block's last share merges them
-    if (nsplit > 1 && merge_counter != nullptr)
+    if (kLab && nsplit > 1 && merge_counter != nullptr)
         prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, merge_counter, s_ticket, merge_mode);
 }
 

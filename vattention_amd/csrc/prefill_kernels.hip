@@ -20,6 +20,7 @@ namespace vattn_k {
 namespace vattn_k {
 
 
+#ifdef VATTN_LAB
 // --------------------------------------------------------------------------------------------
 // Interleaved, software-pipelined prefill (8 waves x 32 query rows, d = 128): S(t+1) = K(t+1).Q^T is accumulated while
 // the softmax of tile t is evaluated, then P(t).V(t); K runs one tile ahead of V in LDS (iteration t reads K[(t+1)&1] and
@@ -300,6 +301,8 @@ __global__ __launch_bounds__(512, 2) void prefill_ilv_kernel(vattn_attn_params p
     }
 }
 
+#endif  // VATTN_LAB
+
 // Same merge for the KV-split prefill form, where there are b * sq * h output rows (tens of thousands) and at most 16
 // partials each: one WAVE per row (4 rows per 256-thread block), lane l < splits holds partial l's LSE, the weights are
 // broadcast by readlane, every lane owns two adjacent d.
@@ -376,6 +379,7 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
     // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
     if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6 || pl.tiling == 7))) pl.tiling = 1;
+    if (!kLab && (pl.tiling == 2 || pl.tiling == 6)) pl.tiling = 1;     // lab-only kernels (validate() rejects them before this)
     if (pl.tiling == 6 && (p->q_lens || p->rotary_cos_sin)) pl.tiling = 1;      // the interleaved kernel has no batched-chunk / fused-RoPE form
     if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
     // keys an average query block sees; without a host-side length only the chunk itself is certain
@@ -495,16 +499,20 @@ template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(
     const size_t smem = PfSmem<HD>::kTotal;
     static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
-        (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, false, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
+        if constexpr (kLab) (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, false, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
         return true;
     }();
     (void)attr_once;
     int* done = prefill_merge_counters(p, st, nsplit, nqb);
     const int mm = done ? prefill_merge_mode(p, nsplit) : 0;
-    if (use_tr)
-        hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
-    else
-        hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
+    bool plain = false;
+    if constexpr (kLab) {      // variant bit 0: V^T fragments by plain LDS reads instead of ds_read_b64_tr_b16
+        if (!use_tr) {
+            hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
+            plain = true;
+        }
+    }
+    if (!plain) hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
     if (nsplit > 1 && !done) {
         const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
         hipLaunchKernelGGL((combine_rows_kernel<T, HD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, nsplit, p->seqlen_q, rows);
@@ -526,7 +534,9 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
                 hipLaunchKernelGGL((combine_rows_kernel<T, 128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, pl.nsplit, p->seqlen_q, rows);
             }
             launched = true;
-        } else if (pl.tiling == 2) {
+        }
+#ifdef VATTN_LAB
+        else if (pl.tiling == 2) {
             launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);
             launched = true;
         } else if (pl.tiling == 6) {
@@ -541,10 +551,13 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
             hipLaunchKernelGGL((prefill_ilv_kernel<T>), grid, dim3(512), PfSmem<128>::kTotal, st, *p, order, nqb);
             launched = true;
         }
+#endif
     }
     if (launched) {
     } else if (pl.tiling == 4) launch_prefill<T, HD, 4, 1, false>(p, st, use_tr, pl.nsplit);
+#ifdef VATTN_LAB
     else if ((p->variant & 16) && HD == 128) launch_prefill<T, HD == 128 ? 128 : HD, 8, 1, HD == 128>(p, st, use_tr, pl.nsplit);      // denominator on the matrix pipe
+#endif
     else launch_prefill<T, HD, 8, 1, false>(p, st, use_tr, pl.nsplit);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));

@@ -99,7 +99,7 @@ def hybrid_attn(prefill_call, decode_call, device, _role_mode: int = 0) -> None:
     (pp, keep_p), (pd, keep_d) = cap
     if _role_mode:
         pp.variant = (pp.variant & ~(3 << 12)) | ((_role_mode & 3) << 12)
-    lib = K.klib()
+    lib = K.klib_lab() if (K.needs_lab(pp.variant) or K.needs_lab(pd.variant)) else K.klib()
     need = lib.vattn_hybrid_workspace_bytes(C.byref(pp), C.byref(pd))
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _hybrid_ws.get(key)
@@ -108,7 +108,7 @@ def hybrid_attn(prefill_call, decode_call, device, _role_mode: int = 0) -> None:
         _hybrid_ws[key] = ws
     rc = lib.vattn_hybrid_attn(C.byref(pp), C.byref(pd), ws.data_ptr(), K.current_stream_ptr(device))
     if rc != 0:
-        raise RuntimeError(K.last_error())
+        raise RuntimeError(K.last_error(lib))
     del keep_p, keep_d
 
 
@@ -131,14 +131,14 @@ def _launch(p, dev, keep=()):
     if _capture is not None:
         _capture.append((p, keep))
         return
-    lib = K.klib()
+    lib = K.klib_for(p.variant)          # the product library; the lab build only for measurement variants (tests, kbench)
     need = lib.vattn_attn_workspace_bytes(C.byref(p))
     if need:
         ws = _workspace(need, dev)       # kept alive by the per-(device, stream) cache until a larger one replaces it
         p.workspace = ws.data_ptr()
     rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), K.current_stream_ptr(dev))
     if rc != 0:
-        raise RuntimeError(K.last_error())
+        raise RuntimeError(K.last_error(lib))
 
 
 def _check_cuda(*ts):
@@ -152,7 +152,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             cache_batch_idx: Optional[torch.Tensor] = None, cache_leftpad=None, block_table=None,
                             softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                             rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
-                            out=None, _variant=0, _max_seqlen_k: int = 0, _rotary_cos_sin=None, _params_out=None):
+                            out=None, _variant=0, _max_seqlen_k: int = 0, _rotary_cos_sin=None, _params_out=None,
+                            _cache_seqlens_host=None):
     rot = _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q)
     if block_table is not None:
         raise NotImplementedError("paged KV (block_table) is what vAttention replaces; not supported")
@@ -229,12 +230,39 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
     if rot is not None:
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
-    _launch(p, dev, keep=(q, k, v, k_cache, v_cache, cache_seqlens, cache_batch_idx, out, lse, rot))
+    plan = None
+    if _cache_seqlens_host is not None and Sq == 1 and B > 1 and num_splits == 0:
+        plan = _decode_plan(p, _cache_seqlens_host, dev)      # ragged batch: work items of near-equal length (None: uniform split)
+    _launch(p, dev, keep=(q, k, v, k_cache, v_cache, cache_seqlens, cache_batch_idx, out, lse, rot, plan))
     if _params_out is not None and not return_softmax_lse:
         # the caller may re-issue this call through relaunch(): the block keeps the index / length / rotary tensors it points to alive
-        p._keep = (cache_seqlens, cache_batch_idx, rot)
+        p._keep = (cache_seqlens, cache_batch_idx, rot, plan)
         _params_out.append(p)
     return (out, lse) if return_softmax_lse else out
+
+
+def _decode_plan(p, lens_host, dev):
+    """Length-balanced split of a ragged decode batch (include/vattn_kernels.h, vattn_decode_plan): the host-side lengths -> two small
+    device tables, attached to the parameter block.  One H2D copy; the attention wrapper builds it for layer 0 of an iteration and
+    the other layers re-issue the same block."""
+    B = p.b
+    if len(lens_host) != B:
+        raise RuntimeError("_cache_seqlens_host must have one entry per batch element")
+    cap = 4 * B + 1024
+    lens = (C.c_int32 * B)(*[int(x) for x in lens_host])
+    items = (K.DecodeItem * cap)()
+    seq = (C.c_int32 * (2 * B))()
+    n = K.klib().vattn_decode_plan(C.byref(p), lens, items, cap, seq)
+    if n < 0:
+        raise RuntimeError("vattn_decode_plan: bad arguments")
+    if n == 0:
+        return None
+    flat = torch.empty(4 * n + 2 * B, dtype=torch.int32)
+    C.memmove(flat.data_ptr(), items, 16 * n)
+    C.memmove(flat.data_ptr() + 16 * n, seq, 8 * B)
+    t = flat.to(dev, non_blocking=True)
+    p.split_items, p.split_seq, p.num_split_items = t.data_ptr(), t.data_ptr() + 16 * n, n
+    return t
 
 
 def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,

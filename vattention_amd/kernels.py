@@ -27,16 +27,27 @@ class AttnParams(C.Structure):
         ("is_causal", i32), ("dtype", i32), ("num_splits", i32), ("softmax_scale", C.c_float), ("variant", i32),
         ("max_seqlen_k_hint", i32),
         ("rotary_cos_sin", vp), ("rotary_row_stride", i64), ("rotary_dim", i32), ("rotary_reserved", i32),
+        ("split_items", vp), ("split_seq", vp), ("num_split_items", i32), ("split_reserved", i32),
     ]
 
 
+class DecodeItem(C.Structure):
+    _fields_ = [("b", i32), ("tile_begin", i32), ("tile_end", i32), ("index_in_seq", i32)]
+
+
 _bound = False
+_lab = None
+# variant bits the PRODUCT library accepts (csrc/attn_common.h, kProductVariantMask) and the tilings among bits 1-3
+PRODUCT_VARIANT_MASK = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | (3 << 16)
+PRODUCT_TILINGS = (0, 1, 4, 7)
 
 
-def klib():
-    global _bound
-    lib = L.lib()
-    if not _bound:
+def needs_lab(variant: int) -> bool:
+    return bool(variant & ~PRODUCT_VARIANT_MASK) or ((variant >> 1) & 7) not in PRODUCT_TILINGS
+
+
+def _bind(lib):
+    if True:
         lib.vattn_attn_workspace_bytes.restype = C.c_size_t
         lib.vattn_attn_workspace_bytes.argtypes = [C.POINTER(AttnParams)]
         lib.vattn_flash_attn_with_kvcache.restype = i32
@@ -56,12 +67,41 @@ def klib():
         lib.vattn_time_attn.restype = C.c_float
         lib.vattn_time_attn.argtypes = [C.POINTER(AttnParams), vp, i32, i32]
         lib.vattn_kernels_last_error.restype = C.c_char_p
+        lib.vattn_decode_plan.restype = i32
+        lib.vattn_decode_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(DecodeItem), i32, C.POINTER(i32)]
+    return lib
+
+
+def klib():
+    """The product kernels (libvattn_amd.so)."""
+    global _bound
+    lib = L.lib()
+    if not _bound:
+        _bind(lib)
         _bound = True
     return lib
 
 
-def last_error() -> str:
-    return klib().vattn_kernels_last_error().decode()
+def klib_lab():
+    """tools/lab/libvattn_lab.so: the same kernels built with -DVATTN_LAB (measurement scaffolding: alternative schedules, merge
+    protocols, timing ablations).  Only reached through variants the product library rejects (tests, tools/kbench.py)."""
+    global _lab
+    if _lab is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lab", "libvattn_lab.so")
+        if not os.path.exists(path):
+            raise RuntimeError("lab kernels requested (variant bits outside the product set) but tools/lab/libvattn_lab.so is missing: "
+                               "run vattention_amd/build.py")
+        _lab = _bind(C.CDLL(path))
+    return _lab
+
+
+def klib_for(variant: int):
+    return klib_lab() if needs_lab(int(variant)) else klib()
+
+
+def last_error(lib=None) -> str:
+    return (lib or klib()).vattn_kernels_last_error().decode()
 
 
 def current_stream_ptr(device) -> int:
