@@ -106,6 +106,7 @@ size_t vattn_attn_workspace_bytes(const vattn_attn_params* p);
  * seqlen_knew, variant; pointers are not read), cache_seqlens_host[b] are the values the device array will hold.  Writes at most
  * `cap` items and 2 * b ints of (first item, count); returns the number of items, 0 when the uniform split is at least as good
  * (equal lengths, one sequence, batches whose uniform split is already balanced) or the tables would not fit, < 0 on bad arguments.
+ * p->num_splits = -T forces pieces of T tiles (tests, A/B measurements); the call itself is then made with num_splits = 0.
  * Pure host arithmetic (no device access): usable, and tested, without a GPU. */
 int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqlens_host, vattn_decode_item* items_out, int32_t cap,
                           int32_t* seq_out);

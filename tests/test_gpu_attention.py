@@ -170,24 +170,27 @@ def test_decode_length_balanced_plan(Hq, Hkv, lens, dtype, variant):
     kc2, vc2 = kc.clone(), vc.clone()
     ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :max_len], vc2[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     outs = []
-    for host in (lens, None):
+    # (a batch this small keeps the uniform split on its own: pieces of 7 / 40 tiles are forced, as a batch of hundreds would get)
+    for host, tiles in ((lens, 7), (lens, 40), (None, 0)):
         kg, vg = kc.to(DEV), vc.to(DEV)
         cap = []
         out = flash_attn_with_kvcache(q.to(DEV), kg[:, :max_len], vg[:, :max_len], kn.to(DEV), vn.to(DEV), cache_seqlens=cl.to(DEV),
-                                      cache_batch_idx=idx.to(DEV), causal=True, _variant=variant, _cache_seqlens_host=host, _params_out=cap)
+                                      cache_batch_idx=idx.to(DEV), causal=True, _variant=variant, _cache_seqlens_host=host, _params_out=cap,
+                                      _plan_tiles=tiles)
         torch.cuda.synchronize()
         if host is not None:
-            assert cap[0].num_split_items > B, "the ragged batch did not get a plan"
+            assert cap[0].num_split_items >= B + (2 if tiles == 7 else 1), "the ragged batch did not get a plan"
         else:
             assert cap[0].num_split_items == 0
-        _check(out, ref64, ref32, dtype, "ragged decode, %s" % ("length-balanced plan" if host else "uniform split"))
+        _check(out, ref64, ref32, dtype, "ragged decode, %s" % ("length-balanced plan, %d tiles per piece" % tiles if host else "uniform split"))
         assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)
         # the same parameter block again (what layers 1..L-1 of an iteration do)
         out2 = torch.empty_like(out)
         FA.relaunch(cap[0], q.to(DEV).data_ptr(), kn.to(DEV).data_ptr(), vn.to(DEV).data_ptr(), out2.data_ptr(), kg.data_ptr(), vg.data_ptr(), torch.device(DEV))
         torch.cuda.synchronize()
         outs.append(out.float().cpu())
-    assert (outs[0] - outs[1]).abs().max().item() <= (2e-3 if dtype == torch.float16 else 1.6e-2)
+    for o in outs[:2]:
+        assert (o - outs[2]).abs().max().item() <= (2e-3 if dtype == torch.float16 else 1.6e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])

@@ -1,0 +1,37 @@
+"""Gate on the prefill launch plan (csrc/prefill_kernels.hip, plan_prefill): on the short / underfilled shapes where the plan has to
+choose a tiling and a KV split, the DEFAULT plan must not lose to any explicit tiling of the product library by more than 3 %
+(+ a 3 us allowance for launch jitter on these 40-200 us kernels).  Timed through the C ABI (vattn_time_attn, HIP events on the launch
+stream), best of three repetitions of 20 launches each."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+SHAPES = [("small 2k (32/4 heads)", 32, 4, 2048, 0), ("llama70b/tp8 2k", 8, 1, 2048, 0), ("llama70b/tp8 4k", 8, 1, 4096, 0),
+          ("llama70b/tp8 8k", 8, 1, 8192, 0), ("yi6b chunk4k@0", 32, 4, 4096, 0), ("llama8b chunk512@8k", 32, 8, 512, 7680),
+          ("llama70b/tp8 chunk512@16k", 8, 1, 512, 15872), ("llama70b/tp8 chunk2k@30k", 8, 1, 2048, 30720)]
+
+
+@pytest.mark.parametrize("name,Hq,Hkv,n,c", SHAPES, ids=[s[0] for s in SHAPES])
+def test_default_plan_is_not_beaten_by_an_explicit_tiling(name, Hq, Hkv, n, c):
+    from tools.kbench import params
+    from vattention_amd import kernels as K
+    torch.manual_seed(0)
+    q = torch.randn(1, n, Hq, 128, device=DEV, dtype=torch.float16)
+    kc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+    vc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+    cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    times = {}
+    for variant in (0, 2, 8, 14):                       # plan, 8 waves x 32 rows, 4 waves x 32 rows, prefill64
+        p, keep = params(q, kc, vc, cl, variant=variant)
+        best = min(K.klib().vattn_time_attn(C.byref(p), st, 3, 20) for _ in range(3))
+        assert best > 0, K.last_error()
+        times[variant] = best
+        del keep
+    explicit = min(times[v] for v in (2, 8, 14))
+    print("%s: plan %.4f ms, explicit tilings %s" % (name, times[0], {v: round(times[v], 4) for v in (2, 8, 14)}))
+    assert times[0] <= explicit * 1.03 + 0.003, "%s: default plan %.4f ms loses to an explicit tiling (%s)" % (name, times[0], times)

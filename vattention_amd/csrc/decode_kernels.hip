@@ -241,6 +241,7 @@ int decode_plan(const vattn_attn_params* p, const int32_t* lens, vattn_decode_it
     // what the uniform split would do: every sequence S splits, the launch lasts as long as the longest sequence's share
     vattn_attn_params u = *p;
     u.split_items = nullptr;
+    u.num_splits = u.num_splits < 0 ? 0 : u.num_splits;
     const long S = pick_splits(&u, groups, slots);
     const long uniform_makespan = (longest + S - 1) / S;
     long target = slots / gps;                          // items that make one round
@@ -248,9 +249,11 @@ int decode_plan(const vattn_attn_params* p, const int32_t* lens, vattn_decode_it
     long T = (total + (target - p->b) - 1) / (target - p->b);
     const long kMinTiles = 22;
     if (T < kMinTiles) T = kMinTiles;
+    const bool forced = p->num_splits < 0;              // num_splits = -T: pieces of T tiles whatever the heuristic says (tests, A/B)
+    if (forced) T = -(long)p->num_splits;
     if (longest > 128 * T) T = (longest + 127) / 128;   // the merge handles at most 128 pieces per sequence
     // the balanced plan must shorten the launch noticeably: its longest item is T tiles, and it adds partial traffic for every piece
-    if (T * 100 > uniform_makespan * 85) return 0;
+    if (!forced && T * 100 > uniform_makespan * 85) return 0;
     int n = 0;
     for (int b = 0; b < p->b; b++) {
         const long lk = (long)(lens[b] < 0 ? 0 : lens[b]) + p->seqlen_knew;

@@ -153,7 +153,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                             rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
                             out=None, _variant=0, _max_seqlen_k: int = 0, _rotary_cos_sin=None, _params_out=None,
-                            _cache_seqlens_host=None):
+                            _cache_seqlens_host=None, _plan_tiles: int = 0):
     rot = _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q)
     if block_table is not None:
         raise NotImplementedError("paged KV (block_table) is what vAttention replaces; not supported")
@@ -232,7 +232,10 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
     plan = None
     if _cache_seqlens_host is not None and Sq == 1 and B > 1 and num_splits == 0:
+        if _plan_tiles:                                        # (tests / A-B: pieces of exactly this many 32-key tiles)
+            p.num_splits = -int(_plan_tiles)
         plan = _decode_plan(p, _cache_seqlens_host, dev)      # ragged batch: work items of near-equal length (None: uniform split)
+        p.num_splits = 0
     _launch(p, dev, keep=(q, k, v, k_cache, v_cache, cache_seqlens, cache_batch_idx, out, lse, rot, plan))
     if _params_out is not None and not return_softmax_lse:
         # the caller may re-issue this call through relaunch(): the block keeps the index / length / rotary tensors it points to alive
