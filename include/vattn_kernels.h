@@ -89,7 +89,29 @@ typedef struct vattn_attn_params {
     const int32_t* split_seq;                      /* device: int32[2 * b] = (first item, item count) per sequence */
     int32_t num_split_items;
     int32_t split_reserved;
+    /* Work list of an underfilled / unbalanced PREFILL launch (MI355X extension; all zero otherwise; d = 128).  A causal prompt on a
+     * tensor-parallel shard has few heads and query blocks whose key walk grows linearly: the launch lasts as long as its longest
+     * block, and cutting EVERY block's key range in n shares multiplies the fp32 partial traffic by n.  vattn_prefill_plan lists the
+     * (entry, head, 256-row query block, key-tile range) pieces longest first and cuts only the blocks longer than the per-CU average:
+     * short blocks write their output directly, long ones write partials that vattn merges (one wave per row) in a second launch.  The
+     * caller copies the tables to the device — once per iteration, the plan depends on the lengths only — and passes them with every
+     * layer's call.  Results equal the default launch's up to the order of the fp32 merge. */
+    const struct vattn_prefill_item* pf_items;     /* device: num_pf_items pieces, longest first                                */
+    const struct vattn_prefill_item* pf_blocks;    /* device: num_pf_blocks SPLIT query blocks (what the merge pass walks)      */
+    int32_t num_pf_items, num_pf_blocks;
+    int32_t pf_part_rows;                          /* fp32 partial rows of all split blocks (sizes the workspace)               */
+    int32_t pf_reserved;
 } vattn_attn_params;
+
+typedef struct vattn_prefill_item {
+    int32_t b, h, qb;     /* batch entry, query head, 256-row query block                                                    */
+    int32_t tile_begin;   /* first 64-key tile of the piece (pf_blocks: unused)                                              */
+    int32_t tile_end;     /* one past its last tile                                                                          */
+    int32_t nshares;      /* pieces the query block was cut into; 1 = this piece writes the output rows itself               */
+    int32_t part_row;     /* nshares > 1: first of this piece's 256 partial rows (pf_blocks: of the block's share 0; share s
+                             sits 256 * s rows further)                                                                      */
+    int32_t reserved;
+} vattn_prefill_item;
 
 typedef struct vattn_decode_item {
     int32_t b;            /* batch entry                                            */
@@ -110,6 +132,14 @@ size_t vattn_attn_workspace_bytes(const vattn_attn_params* p);
  * Pure host arithmetic (no device access): usable, and tested, without a GPU. */
 int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqlens_host, vattn_decode_item* items_out, int32_t cap,
                           int32_t* seq_out);
+
+/* Host-side planner of the prefill work list (see vattn_attn_params.pf_items).  `p` describes the call (b, seqlen_q, h, h_k, d,
+ * is_causal; pointers are not read); q_lens_host[b] are the chunk lengths (NULL: every entry has seqlen_q rows), k_lens_host[b] the
+ * visible keys of each entry (cache length + new tokens).  Writes at most cap_items / cap_blocks entries and counts_out[3] =
+ * {items, split blocks, partial rows}; returns the number of items, 0 when the default launch is at least as good (grids that fill
+ * the chip with balanced work, head dimensions other than 128) or a table would not fit, < 0 on bad arguments.  Pure host arithmetic. */
+int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
+                           int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* counts_out);
 
 /* flash_attn_with_kvcache: appends k_new/v_new (if given) and attends; prefill form (seqlen_q > 1,
  * causal chunk against the growing cache) and decode form (seqlen_q == 1, split-KV + combine). */

@@ -185,6 +185,75 @@ def test_decode_plan_cuts_a_ragged_batch_into_equal_work_items():
     assert n > 0 and max(seq[1::2]) <= 128
 
 
+def test_prefill_plan_lists_every_key_tile_once_and_cuts_only_long_blocks():
+    """vattn_prefill_plan (pure host code): the pieces of every (entry, head, 256-row query block) cover its key tiles exactly once;
+    pieces are listed longest first; only blocks longer than the per-CU average are cut (at most 16 shares), each split block owns
+    256 partial rows per share; grids of several balanced rounds, d != 128 and the decode form keep the default launch."""
+    import ctypes as C
+    from vattention_amd import kernels as K
+    lib = K.klib()
+
+    def plan(q_lens, k_lens, h, hk, causal=1, d=128, uniform_sq=None):
+        B = len(k_lens)
+        p = K.AttnParams()
+        p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal = B, (uniform_sq or max(q_lens)), h, hk, d, causal
+        nblk = sum((q + 255) // 256 for q in (q_lens or [uniform_sq] * B)) * h
+        ci, cb = 17 * nblk + 16, nblk + 16
+        items, blocks, counts = (K.PrefillItem * ci)(), (K.PrefillItem * cb)(), (C.c_int32 * 3)()
+        ql = (C.c_int32 * B)(*q_lens) if q_lens else None
+        n = lib.vattn_prefill_plan(C.byref(p), ql, (C.c_int32 * B)(*k_lens), items, ci, blocks, cb, counts)
+        f = lambda a, m: [(a[i].b, a[i].h, a[i].qb, a[i].tile_begin, a[i].tile_end, a[i].nshares, a[i].part_row) for i in range(m)]
+        return n, f(items, max(n, 0)), f(blocks, counts[1]), list(counts)
+
+    def tiles(sq, lk, qb, causal=True):
+        n_end = min(lk, qb * 256 + 256 + (lk - sq)) if causal else lk
+        return (max(n_end, 0) + 63) // 64
+
+    def check(q_lens, k_lens, h, hk):
+        n, items, blocks, counts = plan(q_lens, k_lens, h, hk)
+        assert n > 0 and counts[0] == n and counts[1] == len(blocks)
+        lens = [te - tb for _, _, _, tb, te, _, _ in items]
+        assert lens == sorted(lens, reverse=True)
+        cover = {}
+        for b, hh, qb, tb, te, ns, pr in items:
+            cover.setdefault((b, hh, qb), []).append((tb, te, ns, pr))
+        W = 0
+        for e, (sq, lk) in enumerate(zip(q_lens, k_lens)):
+            for qb in range((sq + 255) // 256):
+                t = tiles(sq, lk, qb)
+                for hh in range(h):
+                    pcs = sorted(cover.pop((e, hh, qb)))
+                    assert pcs[0][0] == 0 and pcs[-1][1] == t and all(a[1] == c[0] for a, c in zip(pcs, pcs[1:])), (e, hh, qb, pcs, t)
+                    assert all(x[2] == len(pcs) for x in pcs) and len(pcs) <= 16
+                    if len(pcs) > 1:
+                        rows = sorted(x[3] for x in pcs)
+                        assert rows == [rows[0] + 256 * i for i in range(len(pcs))] and (e, hh, qb, 0, 0, len(pcs), rows[0]) in blocks
+                    else:
+                        assert pcs[0][3] == -1
+                    W += t
+        assert not cover
+        avg = max(16, -(-W // 256))
+        assert max(lens) <= avg + 1 or max(lens) * 16 >= max(tiles(sq, lk, (sq - 1) // 256) for sq, lk in zip(q_lens, k_lens))
+        assert counts[2] == 256 * sum(ns for *_, ns, _ in blocks)
+        return n, lens, counts
+
+    # one TP=8 rank of Llama-3-70B (8 query heads): whole prompts of 8 k / 4 k / 2 k, a 7 k prompt, a batch of three prompts
+    n, lens, counts = check([8192], [8192], 8, 1)
+    assert 256 < n < 520 and max(lens) <= 67                   # only the upper half of the blocks is cut (in two)
+    check([4096], [4096], 8, 1)
+    check([2048], [2048], 8, 1)
+    check([7344], [7344], 8, 1)
+    check([12001, 900, 600], [12001, 900, 600], 8, 1)           # one long prompt beside short ones: its last blocks outlast the average
+    assert plan([12001, 4119, 7000], [12001, 4119, 7000], 8, 1)[0] == 0      # three rounds of blocks, none longer than a CU's share
+    check([2048], [32768], 8, 1)                                # a 2 k chunk on a 30 k prefix: 64 equal blocks, four shares each
+    check([300, 1, 700], [1300, 50, 700], 4, 2)                 # ragged small chunks (incl. a one-token entry)
+    # keep the default launch: a grid of many balanced rounds, d = 64, the decode form
+    assert plan([32702], [32702], 32, 4)[0] == 0
+    assert plan([16384], [131072], 28, 4)[0] == 0
+    assert plan([4096], [4096], 8, 1, d=64)[0] == 0
+    assert plan(None, [5000, 6000], 8, 1, uniform_sq=1)[0] == 0
+
+
 def test_product_library_holds_no_measurement_scaffolding():
     """The shipped libvattn_amd.so instantiates the kernels the launch plans choose and nothing else: ONE prefill64 build per dtype
     (the timing ablations with wrong results, the alternative schedules, the hand-interleaved 8-wave kernel, the plain-read operand
@@ -212,8 +281,8 @@ def test_product_library_holds_no_measurement_scaffolding():
     strings = subprocess.run(["strings", so], capture_output=True, text=True, check=True).stdout
     assert "VATTN_PREFILL64_BUILD" not in strings
     # which variants need the lab library
-    assert not K.needs_lab(0) and not K.needs_lab(14) and not K.needs_lab(8) and not K.needs_lab(2 | 64) and not K.needs_lab(65536)
-    for v in (1, 4, 12, 16, 270, 526, 2574, 512, 1024, 16384, 32768):
+    assert not K.needs_lab(0) and not K.needs_lab(14) and not K.needs_lab(8) and not K.needs_lab(2 | 64)
+    for v in (1, 4, 12, 16, 270, 526, 2574, 512, 1024, 16384, 32768, 65536, 131072):
         assert K.needs_lab(v), v
 
 

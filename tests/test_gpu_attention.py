@@ -141,6 +141,62 @@ def test_prefill_chunk_parity(n, c, Hq, Hkv, dtype, variant):
     _check(out, ref64, ref32, dtype, "prefill n=%d c=%d" % (n, c))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("Hq,Hkv,chunks", [
+    (8, 1, [(0, 2048)]),                                  # a TP=8 shard's whole prompt: the upper query blocks are cut, the lower are not
+    (8, 1, [(0, 1500)]),                                  # ragged last block
+    (8, 1, [(3000, 700)]),                                # a chunk on a prefix: equal blocks, all cut
+    (8, 2, [(0, 1300), (200, 1), (640, 300)]),            # batched chunks of different lengths incl. a one-token entry (varlen form)
+    (4, 4, [(0, 520), (0, 2100)]),                        # MHA, two prompts
+], ids=["tp8_2k", "tp8_1500", "chunk700_at_3000", "varlen3", "mha2"])
+def test_prefill_work_list_matches_the_oracle(Hq, Hkv, chunks, dtype):
+    """Prefill launches driven by a host-planned work list (vattn_prefill_plan: pieces longest first, only long query blocks cut,
+    partials merged by combine_blocks_kernel) against the oracle, and against the default launch of the same call."""
+    from vattention_amd import flash_attn as FA
+    from vattention_amd import kernels as K
+    from vattention_amd.flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
+    torch.manual_seed(31)
+    D, P = 128, len(chunks)
+    ctx = max(c + n for c, n in chunks) + 9
+    slots = P + 2
+    kc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    vc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    T = sum(n for _, n in chunks)
+    q = torch.randn(T, Hq, D).to(dtype)
+    sl = torch.randperm(slots)[:P].to(torch.int32)
+    q_lens, k_lens = [n for _, n in chunks], [c + n for c, n in chunks]
+    refs64, refs32, tok = [], [], 0
+    for i, (c, n) in enumerate(chunks):
+        s_ = int(sl[i])
+        for math, dst in (({}, refs64), ({"math": "f32"}, refs32)):
+            dst.append(flash_attn_with_kvcache_ref(q[tok:tok + n].unsqueeze(0), kc[s_:s_ + 1].clone(), vc[s_:s_ + 1].clone(),
+                                                   cache_seqlens=torch.tensor([c + n], dtype=torch.int32), causal=True, **math)[0])
+        tok += n
+    ref64, ref32 = torch.cat(refs64), torch.cat(refs32)
+    kg, vg, qg = kc.to(DEV), vc.to(DEV), q.to(DEV)
+    p = K.AttnParams()
+    p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal = P, max(q_lens), Hq, Hkv, D, 1
+    plan = FA.prefill_plan(p, q_lens, k_lens, torch.device(DEV))
+    assert plan.t is not None and plan.n_items > 0, "this underfilled launch did not get a work list"
+    outs = []
+    for pl in (plan, None):
+        out = torch.full((T, Hq, D), float("nan"), dtype=dtype, device=DEV)
+        if P == 1:
+            s_ = int(sl[0])
+            flash_attn_with_kvcache(qg.unsqueeze(0), kg[s_:s_ + 1], vg[s_:s_ + 1], cache_seqlens=torch.tensor(k_lens, dtype=torch.int32, device=DEV),
+                                    causal=True, out=out.unsqueeze(0), _max_seqlen_k=k_lens[0], _pf_plan=pl)
+        else:
+            starts = torch.tensor([sum(q_lens[:i]) for i in range(P)], dtype=torch.int32, device=DEV)
+            flash_attn_varlen_with_kvcache(qg, kg, vg, starts, torch.tensor(q_lens, dtype=torch.int32, device=DEV), max(q_lens),
+                                           torch.tensor(k_lens, dtype=torch.int32, device=DEV), sl.to(DEV), causal=True, out=out,
+                                           _max_seqlen_k=max(k_lens), _pf_plan=pl)
+        torch.cuda.synchronize()
+        assert not torch.isnan(out.float()).any(), "rows left unwritten (%s)" % ("work list" if pl else "default launch")
+        _check(out, ref64, ref32, dtype, "prefill, %s" % ("work list: %d pieces, %d split blocks" % (plan.n_items, plan.n_blocks) if pl else "default launch"))
+        outs.append(out.float().cpu())
+    assert (outs[0] - outs[1]).abs().max().item() <= (2e-3 if dtype == torch.float16 else 1.6e-2)
+
+
 @pytest.mark.parametrize("variant", [0, 65536, 131072], ids=["wg256", "wg512", "wg1024"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("Hq,Hkv,lens", [

@@ -89,9 +89,20 @@ def prefill(variant):
             vc = vc[:, :1].expand(-1, c + n, -1, -1).contiguous()
         cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
         p, keep = params(q, kc, vc, cl, variant=variant, splits=PF_SPLITS)
+        tag = ""
+        if WORKLIST:          # host-planned work list (vattn_prefill_plan) where the planner wants one
+            from vattention_amd import flash_attn as FA
+            pl = FA.prefill_plan(p, [n], [c + n], DEV)
+            if pl.t is not None:
+                pl.attach(p)
+                need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
+                w = torch.empty(need // 4 + 1, dtype=torch.float32, device=DEV)
+                p.workspace = w.data_ptr()
+                keep += [pl, w]
+                tag = "  [work list: %d pieces, %d split blocks]" % (pl.n_items, pl.n_blocks)
         ms = time_ms(p, 1, 3 if n > 10000 else 10)
         fl = 4.0 * Hq * 128 * (n * c + n * (n + 1) / 2)
-        print("  %-26s n=%6d c=%6d Hq=%2d Hkv=%d : %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)" % (name, n, c, Hq, Hkv, ms, fl / ms / 1e9, fl / ms / 1e9 / 25))
+        print("  %-26s n=%6d c=%6d Hq=%2d Hkv=%d : %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)%s" % (name, n, c, Hq, Hkv, ms, fl / ms / 1e9, fl / ms / 1e9 / 25, tag))
         del keep
 
 
@@ -108,8 +119,12 @@ def decode(variant):
             continue
         torch.manual_seed(0)
         q = torch.randn(B, 1, Hq, 128, device=DEV, dtype=DTYPE)
-        kc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=DTYPE)
-        vc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=DTYPE)
+        if MEGA > 1:      # megacache layout [slots, ctx, L, Hkv, D]: one layer's view has a row stride of L x Hkv x D elements
+            kc = torch.randn(slots, ctx, MEGA, Hkv, 128, device=DEV, dtype=DTYPE)[:, :, MEGA // 2]
+            vc = torch.randn(slots, ctx, MEGA, Hkv, 128, device=DEV, dtype=DTYPE)[:, :, MEGA // 2]
+        else:
+            kc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=DTYPE)
+            vc = torch.randn(slots, ctx, Hkv, 128, device=DEV, dtype=DTYPE)
         kn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=DTYPE)
         vn = torch.randn(B, 1, Hkv, 128, device=DEV, dtype=DTYPE)
         cl = torch.full((B,), ctx - 1, dtype=torch.int32, device=DEV)
@@ -124,6 +139,8 @@ def decode(variant):
 
 
 ONLY = None
+WORKLIST = False
+MEGA = 1
 DTYPE = torch.float16
 SPLITS = (0,)
 PF_SPLITS = 0
@@ -132,6 +149,9 @@ if __name__ == "__main__":
     variant = 0
     if "--splits" in sys.argv:
         SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
+    WORKLIST = "--worklist" in sys.argv
+    if "--mega" in sys.argv:      # decode only: K/V as one layer's view of a megacache tensor with this many layers
+        MEGA = int(sys.argv[sys.argv.index("--mega") + 1])
     if "--bf16" in sys.argv:
         DTYPE = torch.bfloat16
     if "--pf-splits" in sys.argv:

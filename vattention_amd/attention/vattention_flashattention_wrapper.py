@@ -59,6 +59,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         self.decode_batch_size = 0
         self._decode_lens_host: List[int] = []
         self._dec_plan = None       # per-iteration launch plan of the decode call (built by layer 0, replayed by the other layers)
+        self._pf_plans = {}         # per-iteration prefill work lists (flash_attn.prefill_plan), keyed by call site; same for every layer
 
     def get_cache_block(self, num_blocks: int, **kwargs):
         return None          # vAttention has no block tables
@@ -67,6 +68,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         self.is_profiling_iteration = False
         self.is_metadata_initialized = True
         self._dec_plan = None
+        self._pf_plans = {}
         q_lens, c_lens, totals, dec = [], [], [], []
         for md in seq_metadata_list:
             if md.is_prompt:
@@ -161,7 +163,9 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                                max(self.prefill_query_lens), self._prefill_totals, self.batch_index[:P],
                                                softmax_scale=softmax_scale, causal=True, out=output[:tok].view(tok, Hq, D),
                                                num_splits=num_splits, _rotary_cos_sin=self._rotary,
-                                               _max_seqlen_k=max(c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)))
+                                               _max_seqlen_k=max(c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)),
+                                               _pf_plan=self._prefill_plan("varlen", self.prefill_query_lens,
+                                                                           [c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)]))
             return tok
         tok = 0
         for i, (c_len, q_len) in enumerate(zip(self.prefill_cache_lens, self.prefill_query_lens)):
@@ -184,9 +188,22 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                         cache_seqlens=self.current_total_len_device_lst[i],
                                         causal=True, softmax_scale=softmax_scale,
                                         out=output[tok:tok + q_len].view(1, q_len, Hq, D), _max_seqlen_k=c_len + q_len,
-                                        num_splits=num_splits, _rotary_cos_sin=self._rotary)
+                                        num_splits=num_splits, _rotary_cos_sin=self._rotary,
+                                        _pf_plan=self._prefill_plan(i, [q_len], [c_len + q_len]) if q_len > 1 else None)
             tok += q_len
         return tok
+
+    def _prefill_plan(self, key, q_lens, k_lens):
+        """The work list of one prefill call site of this iteration (flash_attn.prefill_plan: host arithmetic + one small H2D copy),
+        built by the first layer that gets here and shared by the others — it depends on the lengths only."""
+        pl = self._pf_plans.get(key)
+        if pl is None and self.head_dim == 128:
+            import ctypes as C
+            from .. import kernels as K
+            p = K.AttnParams()
+            p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal = len(q_lens), max(q_lens), self.num_q_heads, self.num_kv_heads, self.head_dim, 1
+            pl = self._pf_plans[key] = _FA.prefill_plan(p, q_lens, k_lens, self.device)
+        return pl
 
     def _forward_decodes(self, query, key, value, kv_cache, softmax_scale, layer_id, output, tok: int) -> None:
         """ONE batched decode call: new K/V appended in-kernel at cache_seqlens of the slots named by cache_batch_idx.

@@ -233,6 +233,7 @@ int validate(const vattn_attn_params* p) {
     }
     if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
         return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
+    if (p->pf_items && (p->seqlen_q == 1 || p->d != 128)) return fail(VATTN_K_ERR_INVALID, "pf_items (prefill work list) applies to the prefill form with head dimension 128");
     if (p->split_items && p->seqlen_q != 1) return fail(VATTN_K_ERR_INVALID, "split_items (length-balanced plan) applies to the decode form only");
     if (!kLab) {
         const int til = (p->variant >> 1) & 7;
@@ -265,6 +266,11 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
 
 int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqlens_host, vattn_decode_item* items_out, int32_t cap, int32_t* seq_out) {
     return decode_plan(p, cache_seqlens_host, items_out, cap, seq_out);
+}
+
+int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
+                           int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* counts_out) {
+    return prefill_worklist(p, q_lens_host, k_lens_host, items_out, cap_items, blocks_out, cap_blocks, counts_out);
 }
 
 size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode) {

@@ -35,9 +35,8 @@ constexpr bool kLab = true;
 constexpr bool kLab = false;
 #endif
 // variant bits of vattn_attn_params a product build accepts: bits 1-3 tiling {0 plan, 1 = 8 waves x 32 rows, 4 = 4 waves x 32 rows,
-// 7 = prefill64}; bits 5-6 workgroup order; bit 7 one 16-head block per decode workgroup; bits 12-13 role policy of the fused
-// launch; bits 16-17 decode workgroup shape
-constexpr int kProductVariantMask = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | (3 << 16);
+// 7 = prefill64}; bits 5-6 workgroup order; bit 7 one 16-head block per decode workgroup; bits 12-13 role policy of the fused launch
+constexpr int kProductVariantMask = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12);
 
 template <typename T> struct Tr;
 template <> struct Tr<_Float16> {
@@ -245,6 +244,8 @@ int fail(int code, const char* msg);                                    // attn_
 void launch_append(const vattn_attn_params* p, hipStream_t st);         // cache_kernels.hip
 int launch_prefill_form(const vattn_attn_params* p, hipStream_t st);    // prefill_kernels.hip (seqlen_q > 1)
 size_t prefill_workspace_bytes(const vattn_attn_params* p);
+int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const int32_t* k_lens, vattn_prefill_item* items, int cap_items,
+                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts);   // prefill_kernels.hip
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode);   // prefill64_kernels.hip (d = 128); done: counters of the single-launch merge or NULL
 int* merge_counters(hipStream_t st, size_t n_ints);                      // attn_api.hip: zeroed per-(device, stream) counters, NULL while capturing
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)

@@ -143,9 +143,11 @@ static inline int decode_groups(const vattn_attn_params* p) {
 // multi-XCD part each one writes back and invalidates the XCD's L2 — B1 @ 32 k 23.7 -> 41.5 us, B16 @ 32 k 203 -> 243 us
 // (profiles/r02_kbench_decode_merge.txt).  The group counters live in a small library-owned device buffer per (device, stream),
 // zeroed when it is created; the kernel leaves them zero.
-// Workgroup shape (decode_body.h: W waves per workgroup).  Variant bit 16: 8 waves (two workgroups per CU); bit 17: 16 waves (one).
+// Workgroup shape (decode_body.h: W waves per workgroup).  LAB ONLY — variant bit 16: 8 waves (two workgroups per CU); bit 17: 16 waves
+// (one): both measured slower than the 4-wave product shape (B16 @ 32 k: 0.192 ms vs 0.207 / 0.204, profiles/r03_kbench_decode_shapes.txt:
+// the pure-read probe's gain from wider workgroups does not carry over to a kernel whose waves each own a register-resident tile).
 static inline int decode_shape(const vattn_attn_params* p) {
-    if (p->d != 128 || decode_nb(p) != 1) return 0;      // the alternative shapes exist for d = 128, one head block per workgroup
+    if (!kLab || p->d != 128 || decode_nb(p) != 1) return 0;      // the alternative shapes exist for d = 128, one head block per workgroup
     return (p->variant & 65536) ? 1 : (p->variant & 131072) ? 2 : 0;      // 1: 8 waves (512 slots), 2: 16 waves (256 slots)
 }
 static inline long decode_slots(const vattn_attn_params* p) {      // resident workgroups
@@ -204,11 +206,13 @@ template <typename T, int HD, int NB, int W = DC_WAVES> int launch_decode_nb(con
 }
 
 template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hipStream_t st) {
+#ifdef VATTN_LAB
     if constexpr (HD == 128) {
         const int shape = decode_shape(p);
         if (shape == 1) return launch_decode_nb<T, 128, 1, 8>(p, st);
         if (shape == 2) return launch_decode_nb<T, 128, 1, 16>(p, st);
     }
+#endif
     return decode_nb(p) == 2 ? launch_decode_nb<T, HD, 2>(p, st) : launch_decode_nb<T, HD, 1>(p, st);
 }
 

@@ -147,7 +147,20 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     const int g = lane >> 5;
 
     int b, h, qb, split;
-    if (!wg_to_work(p, order, nqb, nsplit, b, h, qb, split)) return;
+    // host-planned work list (vattn_prefill_plan): blockIdx.x = one piece, longest pieces first; else the grid orders of wg_to_work
+    const bool listed = p.pf_items != nullptr;
+    int it_tb = 0, it_te = 0, it_row = -1;
+    if (listed) {
+        const vattn_prefill_item it = p.pf_items[blockIdx.x];
+        b = __builtin_amdgcn_readfirstlane(it.b);
+        h = __builtin_amdgcn_readfirstlane(it.h);
+        qb = __builtin_amdgcn_readfirstlane(it.qb);
+        it_tb = __builtin_amdgcn_readfirstlane(it.tile_begin);
+        it_te = __builtin_amdgcn_readfirstlane(it.tile_end);
+        it_row = __builtin_amdgcn_readfirstlane(it.nshares > 1 ? it.part_row : -1);
+        split = 0;
+    } else if (!wg_to_work(p, order, nqb, nsplit, b, h, qb, split)) return;
+    const bool partial = listed ? it_row >= 0 : nsplit > 1;       // this workgroup publishes an fp32 partial instead of output rows
     const int hk = h / (p.h / p.h_k);                          // GQA: head h uses kv head h / (Hq/Hkv)
     const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
     int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
@@ -165,7 +178,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     if (n_end < 0) n_end = 0;
     const int nt_all = (n_end + PF_BN - 1) / PF_BN;
     int tb = 0, nt = nt_all;                                   // this workgroup's key tiles [tb, nt)
-    if (nsplit > 1) {
+    if (listed) {
+        tb = min(nt_all, it_tb);
+        nt = min(nt_all, it_te);
+    } else if (nsplit > 1) {
         const int per = (nt_all + nsplit - 1) / nsplit;
         tb = min(nt_all, split * per);
         nt = min(nt_all, tb + per);
@@ -542,11 +558,12 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         const float l_tot = l_loc + swap_halves(l_loc);
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
         const float m_log2 = -nmsub[qc];                      // running max of softmax_scale*log2e*q.k
-        if (my_q < Sq && nsplit > 1) {
-            // KV-split: normalised fp32 partial + its log2-domain LSE; combine_rows_kernel merges the nsplit partials of a row
-            const int64_t row = (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
+        if (my_q < Sq && partial) {
+            // KV-split: normalised fp32 partial + its log2-domain LSE; combine_rows_kernel (work list: combine_blocks_kernel) merges the
+            // partials of a row
+            const int64_t row = listed ? (int64_t)it_row + (my_q - q_wg0) : (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
             float* opart = (float*)p.workspace + row * HD;
-            float* lpart = (float*)p.workspace + (int64_t)nsplit * p.b * p.seqlen_q * p.h * HD;
+            float* lpart = (float*)p.workspace + (listed ? (int64_t)p.pf_part_rows : (int64_t)nsplit * p.b * p.seqlen_q * p.h) * HD;
 #pragma unroll
             for (int db = 0; db < DB; db++)
 #pragma unroll
@@ -619,7 +636,8 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
-    if (nsplit > 1) {
+    if (p->pf_items) grid = dim3((unsigned)p->num_pf_items);      // one workgroup per listed piece
+    else if (nsplit > 1) {
         if (order == 0) {
             vattn_attn_params q = *p;
             q.variant = (p->variant & ~(3 << 5)) | (2 << 5);

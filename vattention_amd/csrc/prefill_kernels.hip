@@ -7,6 +7,8 @@
 //   prefill_ilv_kernel  : the same data flow software-pipelined with a hand-written issue order (variant 12)
 // Semantics: /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, flash_api.cpp:1291-1578, mask.h:164-196
 // (bottom-right causal), softmax.h:69-157 (fp32 max/sum, exp2, P rounded to the I/O dtype before PV).
+#include <algorithm>
+
 #include "attn_common.h"
 
 namespace vattn_k {
@@ -348,6 +350,50 @@ __global__ __launch_bounds__(256) void combine_rows_kernel(vattn_attn_params p, 
         p.softmax_lse[((int64_t)b * p.h + hh) * sq + q] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
 }
 
+// Merge of a work-list launch (vattn_prefill_plan): only the SPLIT query blocks have partials; block sb's share s holds its 256 rows at
+// partial rows [part_row + 256 s, +256).  One wave per output row as in combine_rows_kernel; 64 four-wave workgroups per block.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void combine_blocks_kernel(vattn_attn_params p) {
+    const int lane = threadIdx.x & 63;
+    const vattn_prefill_item blk = p.pf_blocks[blockIdx.x >> 6];
+    const int r = ((blockIdx.x & 63) << 2) + (threadIdx.x >> 6);        // row inside the 256-row block
+    const int b = blk.b, hh = blk.h, q = blk.qb * 256 + r;
+    const int sq = p.q_lens ? p.q_lens[b] : p.seqlen_q;
+    if (q >= sq) return;
+    const int ns = blk.nshares;                                          // <= 16
+    const int64_t q_first = p.q_start ? p.q_start[b] : 0;
+    const float* oacc = (const float*)p.workspace;
+    const float* lacc = oacc + (int64_t)p.pf_part_rows * HD;
+    const int64_t row0 = (int64_t)blk.part_row + r;
+    const float my = (lane < ns) ? lacc[row0 + 256 * (int64_t)lane] : -INFINITY;
+    float mx = my;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));
+    mx = __shfl(mx, 0, 64);
+    const float mxs = (mx == -INFINITY) ? 0.f : mx;
+    const float w = (lane < ns) ? fast_exp2(my - mxs) : 0.f;
+    float wsum = w;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) wsum += xor_shuffle(wsum, o);
+    wsum = __shfl(wsum, 0, 64);
+    const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+    if (2 * lane < HD) {
+        const float* src = oacc + row0 * HD + 2 * lane;
+        float a0 = 0.f, a1 = 0.f;
+        for (int s = 0; s < ns; s++) {
+            const float ws = __shfl(w, s, 64);
+            const float2 v = *(const float2*)(src + (int64_t)s * 256 * HD);
+            a0 += ws * v.x;
+            a1 += ws * v.y;
+        }
+        T* dst = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + q) * p.o_row_stride + (int64_t)hh * p.o_head_stride + 2 * lane;
+        dst[0] = Tr<T>::cvt(a0 * inv);
+        dst[1] = Tr<T>::cvt(a1 * inv);
+    }
+    if (p.softmax_lse && lane == 0)
+        p.softmax_lse[((int64_t)b * p.h + hh) * p.seqlen_q + q] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+}
+
 // variant bits 5-6: workgroup order (wg_to_work): 0 = default (XCD-grouped when the kv heads divide the 8 XCDs),
 // 1 = block-major per head (3-D grid), 2 = heaviest-first across heads, 3 = XCD-grouped
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out) {
@@ -463,7 +509,9 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     }
     const int ns8 = pick(wg8, 256);
     if (ns8 == 1) { pl.tiling = 4; return pl; }                      // cannot split (short prefix): more, smaller workgroups
-    if (wg8 * ns8 >= 192) { pl.nsplit = ns8; return pl; }
+    // (a causal whole prompt of at most half a round of 8-wave workgroups — Llama-70B/TP8 4 k: 128 — does better as twice as many
+    // 4-wave workgroups with the same shares: 0.074 vs 0.079 ms, tests/test_gpu_plan_gate.py)
+    if (wg8 * ns8 >= 192 && (uniform || wg8 > 128)) { pl.nsplit = ns8; return pl; }
     pl.tiling = 4;
     pl.nsplit = pick(wg4, 512);
     return pl;
@@ -522,6 +570,17 @@ template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(
 template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, hipStream_t st) {
     const bool use_tr = (p->variant & 1) == 0;
     if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
+    if constexpr (HD == 128) {
+        if (p->pf_items) {        // host-planned work list: prefill64 pieces longest first, then the merge of the split blocks
+            if (p->num_pf_items <= 0 || (p->num_pf_blocks > 0 && (!p->pf_blocks || !p->workspace)))
+                return fail(VATTN_K_ERR_INVALID, "pf_items needs num_pf_items, and pf_blocks + a workspace when blocks are split");
+            launch_prefill64(p, st, 1, nullptr, 0);
+            if (p->num_pf_blocks > 0) hipLaunchKernelGGL((combine_blocks_kernel<T, 128>), dim3((unsigned)p->num_pf_blocks * 64), dim3(256), 0, st, *p);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
+            return VATTN_K_OK;
+        }
+    }
     const PrefillPlan pl = plan_prefill(p);
     if (pl.nsplit > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "KV-split prefill needs a workspace (vattn_attn_workspace_bytes)");
     bool launched = false;
@@ -564,6 +623,77 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     return VATTN_K_OK;
 }
 
+// Work list of a prefill launch (include/vattn_kernels.h, vattn_prefill_plan).  W = key tiles walked by all (entry, head, query block)
+// triples; one 256-row workgroup per CU, so the launch cannot end before W / 256 tile steps.  Blocks longer than that average are cut
+// into ceil(tiles / T) equal pieces, T = max(16 tiles, the average); every piece is one workgroup, dispatched longest first.
+int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const int32_t* k_lens, vattn_prefill_item* items, int cap_items,
+                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts) {
+    if (!p || !k_lens || !items || !blocks || !counts || p->b <= 0 || p->h <= 0 || p->seqlen_q <= 0) return VATTN_K_ERR_INVALID;
+    counts[0] = counts[1] = counts[2] = 0;
+    if (p->d != 128 || p->seqlen_q == 1) return 0;
+    const long kSlots = 256;                           // one prefill64 workgroup per CU
+    long W = 0, longest = 0, nblk = 0;
+    auto tiles_of = [&](int e, int qb) -> long {
+        const long sq = q_lens ? q_lens[e] : p->seqlen_q, lk = k_lens[e];
+        long n_end = lk;
+        if (p->is_causal) { const long lim = (long)qb * 256 + 256 + (lk - sq); n_end = lim < lk ? lim : lk; }
+        if (n_end < 0) n_end = 0;
+        return (n_end + PF_BN - 1) / PF_BN;
+    };
+    for (int e = 0; e < p->b; e++) {
+        const long sq = q_lens ? q_lens[e] : p->seqlen_q;
+        for (int qb = 0; qb < (sq + 255) / 256; qb++) {
+            const long t = tiles_of(e, qb);
+            W += t * p->h;
+            nblk += p->h;
+            longest = t > longest ? t : longest;
+        }
+    }
+    if (W <= 0 || nblk <= 0) return 0;
+    const long avg = (W + kSlots - 1) / kSlots;
+    // grids of several rounds of workgroups whose longest is no longer than ~a round's share are balanced by the dispatcher's
+    // longest-first order already (and keep the XCD-grouped order that lets the heads of a kv group share their K/V stream in L2)
+    if (nblk >= 4 * kSlots || (nblk >= kSlots && longest * 4 <= avg * 5)) return 0;
+    long T = avg < 16 ? 16 : avg;
+    if (longest > 16 * T) T = (longest + 15) / 16;     // the merge takes at most 16 shares per block
+    int n = 0, nb = 0;
+    long part_rows = 0;
+    for (int e = 0; e < p->b; e++) {
+        const long sq = q_lens ? q_lens[e] : p->seqlen_q;
+        for (int qb = 0; qb < (sq + 255) / 256; qb++) {
+            const long t = tiles_of(e, qb);
+            long ns = (t + T - 1) / T;
+            if (ns < 1) ns = 1;
+            const long per = (t + ns - 1) / ns;
+            for (int h = 0; h < p->h; h++) {
+                if (ns > 1) {
+                    if (nb >= cap_blocks) return 0;
+                    blocks[nb] = vattn_prefill_item{e, h, qb, 0, 0, (int32_t)ns, (int32_t)part_rows, 0};
+                    nb++;
+                }
+                for (long s_ = 0; s_ < ns; s_++) {
+                    if (n >= cap_items) return 0;
+                    long tb = s_ * per, te = tb + per;
+                    if (tb > t) tb = t;
+                    if (te > t) te = t;
+                    items[n] = vattn_prefill_item{e, h, qb, (int32_t)tb, (int32_t)te, (int32_t)ns, ns > 1 ? (int32_t)(part_rows + 256 * s_) : -1, 0};
+                    n++;
+                }
+                if (ns > 1) part_rows += 256 * ns;
+                if (part_rows > 0x7fffffffL - 4096) return 0;
+            }
+        }
+    }
+    // longest first (stable: pieces of one length keep their (entry, block, head) order, so the heads of a kv group stay neighbours)
+    std::stable_sort(items, items + n, [](const vattn_prefill_item& a, const vattn_prefill_item& c) {
+        return (a.tile_end - a.tile_begin) > (c.tile_end - c.tile_begin);
+    });
+    counts[0] = n;
+    counts[1] = nb;
+    counts[2] = (int32_t)part_rows;
+    return n;
+}
+
 int launch_prefill_form(const vattn_attn_params* p, hipStream_t st) {
     const bool f16 = p->dtype == VATTN_DTYPE_F16;
     if (p->d == 64) return f16 ? launch_prefill_t<_Float16, 64>(p, st) : launch_prefill_t<__bf16, 64>(p, st);
@@ -571,6 +701,7 @@ int launch_prefill_form(const vattn_attn_params* p, hipStream_t st) {
 }
 
 size_t prefill_workspace_bytes(const vattn_attn_params* p) {
+    if (p->pf_items) return (size_t)(p->pf_part_rows > 0 ? p->pf_part_rows : 0) * (p->d + 1) * sizeof(float);
     const int ns = plan_prefill(p).nsplit;
     return ns > 1 ? (size_t)ns * p->b * p->seqlen_q * p->h * (p->d + 1) * sizeof(float) : 0;
 }

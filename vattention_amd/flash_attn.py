@@ -153,7 +153,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                             rotary_interleaved=True, alibi_slopes=None, num_splits=0, return_softmax_lse=False,
                             out=None, _variant=0, _max_seqlen_k: int = 0, _rotary_cos_sin=None, _params_out=None,
-                            _cache_seqlens_host=None, _plan_tiles: int = 0):
+                            _cache_seqlens_host=None, _plan_tiles: int = 0, _pf_plan=None):
     rot = _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q)
     if block_table is not None:
         raise NotImplementedError("paged KV (block_table) is what vAttention replaces; not supported")
@@ -231,6 +231,15 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     if rot is not None:
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
     plan = None
+    if Sq > 1 and D == 128 and num_splits == 0 and k is None and not _capture_active():
+        # prefill form: a work list for underfilled / unbalanced grids.  `_pf_plan`: a plan object built earlier for the same lengths
+        # (the wrapper: one per iteration), or "host" = build it here from _cache_seqlens_host (the visible keys of every entry)
+        if isinstance(_pf_plan, _PrefillPlan):
+            plan = _pf_plan
+        elif _pf_plan == "host" and _cache_seqlens_host is not None:
+            plan = prefill_plan(p, None, _cache_seqlens_host, dev)
+        if plan is not None:
+            plan.attach(p)
     if _cache_seqlens_host is not None and Sq == 1 and B > 1 and num_splits == 0:
         if _plan_tiles:                                        # (tests / A-B: pieces of exactly this many 32-key tiles)
             p.num_splits = -int(_plan_tiles)
@@ -242,6 +251,48 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
         p._keep = (cache_seqlens, cache_batch_idx, rot, plan)
         _params_out.append(p)
     return (out, lse) if return_softmax_lse else out
+
+
+class _PrefillPlan:
+    """Device tables of a prefill work list (vattn_prefill_plan) — or the fact that the default launch is as good (tables None).  Built
+    from host-side lengths only, so the attention wrapper builds it for layer 0 of an iteration and hands the same object to the
+    other layers' calls (`_pf_plan`)."""
+    __slots__ = ("t", "n_items", "n_blocks", "part_rows")
+
+    def __init__(self, t=None, n_items=0, n_blocks=0, part_rows=0):
+        self.t, self.n_items, self.n_blocks, self.part_rows = t, n_items, n_blocks, part_rows
+
+    def attach(self, p):
+        if self.t is not None:
+            base = self.t.data_ptr()
+            p.pf_items, p.num_pf_items = base, self.n_items
+            p.pf_blocks, p.num_pf_blocks = (base + 32 * self.n_items if self.n_blocks else None), self.n_blocks
+            p.pf_part_rows = self.part_rows
+
+
+def prefill_plan(p, q_lens_host, k_lens_host, dev) -> _PrefillPlan:
+    """q_lens_host: chunk length per entry (None: p.seqlen_q for all); k_lens_host: visible keys per entry."""
+    B = p.b
+    q_of = q_lens_host if q_lens_host is not None else [p.seqlen_q] * B
+    n_blk = sum((int(q) + 255) // 256 for q in q_of) * p.h          # (entry, head, 256-row query block) triples
+    cap_i, cap_b = 17 * n_blk + 16, n_blk + 16
+    if n_blk > 4 * 256 + 64:                  # (the planner keeps the default launch for grids of several rounds: skip the tables)
+        return _PrefillPlan()
+    items, blocks = (K.PrefillItem * cap_i)(), (K.PrefillItem * cap_b)()
+    counts = (C.c_int32 * 3)()
+    ql = (C.c_int32 * B)(*[int(x) for x in q_lens_host]) if q_lens_host is not None else None
+    kl = (C.c_int32 * B)(*[int(x) for x in k_lens_host])
+    n = K.klib().vattn_prefill_plan(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, counts)
+    if n < 0:
+        raise RuntimeError("vattn_prefill_plan: bad arguments")
+    if n == 0:
+        return _PrefillPlan()
+    nb = int(counts[1])
+    flat = torch.empty(8 * (n + nb), dtype=torch.int32)
+    C.memmove(flat.data_ptr(), items, 32 * n)
+    if nb:
+        C.memmove(flat.data_ptr() + 32 * n, blocks, 32 * nb)
+    return _PrefillPlan(flat.to(dev, non_blocking=True), n, nb, int(counts[2]))
 
 
 def _decode_plan(p, lens_host, dev):
@@ -280,7 +331,7 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
 def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q_lens: torch.Tensor, max_q_len: int,
                                    cache_seqlens: torch.Tensor, cache_batch_idx: Optional[torch.Tensor] = None,
                                    softmax_scale=None, causal=True, out=None, num_splits=0, _variant=0, _max_seqlen_k: int = 0,
-                                   _rotary_cos_sin=None):
+                                   _rotary_cos_sin=None, _pf_plan=None):
     """MI355X extension (SURVEY §8f "batched multi-prefill"): ONE launch for the prefill chunks of several sequences with
     different lengths.  q / out are the flattened tokens [T, Hq, D]; entry i attends with rows [q_start[i], q_start[i] +
     q_lens[i]) over cache slot cache_batch_idx[i] (identity if None), keys [0, cache_seqlens[i]) — the chunk's own K/V must
@@ -332,5 +383,7 @@ def flash_attn_varlen_with_kvcache(q, k_cache, v_cache, q_start: torch.Tensor, q
     if _rotary_cos_sin is not None:      # q rows of entry i are rotated at positions (cache_seqlens[i] - q_lens[i]) + row
         rot = _rotary_table(None, None, _rotary_cos_sin, False, q)
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
-    _launch(p, dev, keep=(q, k_cache, v_cache, q_start, q_lens, cache_seqlens, cache_batch_idx, out, _rotary_cos_sin))
+    if isinstance(_pf_plan, _PrefillPlan) and D == 128 and num_splits == 0 and not _capture_active():
+        _pf_plan.attach(p)        # work list built from the host-side lengths of this iteration (prefill_plan)
+    _launch(p, dev, keep=(q, k_cache, v_cache, q_start, q_lens, cache_seqlens, cache_batch_idx, out, _rotary_cos_sin, _pf_plan))
     return out

@@ -28,7 +28,12 @@ class AttnParams(C.Structure):
         ("max_seqlen_k_hint", i32),
         ("rotary_cos_sin", vp), ("rotary_row_stride", i64), ("rotary_dim", i32), ("rotary_reserved", i32),
         ("split_items", vp), ("split_seq", vp), ("num_split_items", i32), ("split_reserved", i32),
+        ("pf_items", vp), ("pf_blocks", vp), ("num_pf_items", i32), ("num_pf_blocks", i32), ("pf_part_rows", i32), ("pf_reserved", i32),
     ]
+
+
+class PrefillItem(C.Structure):
+    _fields_ = [("b", i32), ("h", i32), ("qb", i32), ("tile_begin", i32), ("tile_end", i32), ("nshares", i32), ("part_row", i32), ("reserved", i32)]
 
 
 class DecodeItem(C.Structure):
@@ -38,7 +43,7 @@ class DecodeItem(C.Structure):
 _bound = False
 _lab = None
 # variant bits the PRODUCT library accepts (csrc/attn_common.h, kProductVariantMask) and the tilings among bits 1-3
-PRODUCT_VARIANT_MASK = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | (3 << 16)
+PRODUCT_VARIANT_MASK = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12)
 PRODUCT_TILINGS = (0, 1, 4, 7)
 
 
@@ -67,6 +72,9 @@ def _bind(lib):
         lib.vattn_time_attn.restype = C.c_float
         lib.vattn_time_attn.argtypes = [C.POINTER(AttnParams), vp, i32, i32]
         lib.vattn_kernels_last_error.restype = C.c_char_p
+        lib.vattn_prefill_plan.restype = i32
+        lib.vattn_prefill_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(i32), C.POINTER(PrefillItem), i32, C.POINTER(PrefillItem), i32,
+                                           C.POINTER(i32)]
         lib.vattn_decode_plan.restype = i32
         lib.vattn_decode_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(DecodeItem), i32, C.POINTER(i32)]
     return lib
