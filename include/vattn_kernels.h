@@ -137,7 +137,8 @@ int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqle
  * is_causal; pointers are not read); q_lens_host[b] are the chunk lengths (NULL: every entry has seqlen_q rows), k_lens_host[b] the
  * visible keys of each entry (cache length + new tokens).  Writes at most cap_items / cap_blocks entries and counts_out[3] =
  * {items, split blocks, partial rows}; returns the number of items, 0 when the default launch is at least as good (grids that fill
- * the chip with balanced work, head dimensions other than 128) or a table would not fit, < 0 on bad arguments.  Pure host arithmetic. */
+ * the chip with balanced work, short key walks, head dimensions other than 128) or a table would not fit, < 0 on bad arguments.
+ * p->num_splits = -T forces pieces of at most T tiles (tests, A/B measurements).  Pure host arithmetic. */
 int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
                            int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* counts_out);
 

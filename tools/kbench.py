@@ -92,7 +92,7 @@ def prefill(variant):
         tag = ""
         if WORKLIST:          # host-planned work list (vattn_prefill_plan) where the planner wants one
             from vattention_amd import flash_attn as FA
-            pl = FA.prefill_plan(p, [n], [c + n], DEV)
+            pl = FA.prefill_plan(p, [n], [c + n], DEV, force_tiles=WL_TILES)
             if pl.t is not None:
                 pl.attach(p)
                 need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
@@ -140,6 +140,7 @@ def decode(variant):
 
 ONLY = None
 WORKLIST = False
+WL_TILES = 0
 MEGA = 1
 DTYPE = torch.float16
 SPLITS = (0,)
@@ -150,6 +151,7 @@ if __name__ == "__main__":
     if "--splits" in sys.argv:
         SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
     WORKLIST = "--worklist" in sys.argv
+    WL_TILES = int(sys.argv[sys.argv.index("--wl-tiles") + 1]) if "--wl-tiles" in sys.argv else 0
     if "--mega" in sys.argv:      # decode only: K/V as one layer's view of a megacache tensor with this many layers
         MEGA = int(sys.argv[sys.argv.index("--mega") + 1])
     if "--bf16" in sys.argv:

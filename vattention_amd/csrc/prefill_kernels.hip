@@ -8,6 +8,9 @@
 // Semantics: /root/reference/pod_attn/pod_attn/flash_attn_interface.py:1146-1291, flash_api.cpp:1291-1578, mask.h:164-196
 // (bottom-right causal), softmax.h:69-157 (fp32 max/sum, exp2, P rounded to the I/O dtype before PV).
 #include <algorithm>
+#include <functional>
+#include <queue>
+#include <vector>
 
 #include "attn_common.h"
 
@@ -623,9 +626,14 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     return VATTN_K_OK;
 }
 
-// Work list of a prefill launch (include/vattn_kernels.h, vattn_prefill_plan).  W = key tiles walked by all (entry, head, query block)
-// triples; one 256-row workgroup per CU, so the launch cannot end before W / 256 tile steps.  Blocks longer than that average are cut
-// into ceil(tiles / T) equal pieces, T = max(16 tiles, the average); every piece is one workgroup, dispatched longest first.
+// Work list of a prefill launch (include/vattn_kernels.h, vattn_prefill_plan).  One 256-row prefill64 workgroup per CU; the launch
+// lasts as long as the most loaded CU.  Candidate plans cut every query block longer than T key tiles into ceil(tiles / T) equal pieces,
+// for T = longest / {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}; each candidate is priced by replaying the dispatcher (pieces longest first,
+// each to the CU that frees up first) with a per-piece cost of tiles + 3 (prologue: zeroing the V ring, Q, the first DMA round trips)
+// + 1.5 for a piece that publishes a partial, plus the merge pass's traffic; the cheapest wins.  [Measured, profiles/r03_kbench.txt: a
+// plan whose piece count lands just above a round of 256 — 280 pieces of a 2 k chunk on a 30 k prefix — costs 0.371 ms against 0.279 for
+// 256 pieces: pricing whole rounds is what the replay is for.]  Short key walks (no block of 96 tiles = 6 k keys) keep the default
+// launch: their time is prologue and merge, and the 4-wave tiling's smaller blocks do better there (2 k prompt, 32 heads: 0.071 vs 0.089).
 int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const int32_t* k_lens, vattn_prefill_item* items, int cap_items,
                      vattn_prefill_item* blocks, int cap_blocks, int32_t* counts) {
     if (!p || !k_lens || !items || !blocks || !counts || p->b <= 0 || p->h <= 0 || p->seqlen_q <= 0) return VATTN_K_ERR_INVALID;
@@ -640,28 +648,83 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
         if (n_end < 0) n_end = 0;
         return (n_end + PF_BN - 1) / PF_BN;
     };
+    std::vector<long> blk_tiles;                       // per (entry, query block); every head repeats it
     for (int e = 0; e < p->b; e++) {
         const long sq = q_lens ? q_lens[e] : p->seqlen_q;
         for (int qb = 0; qb < (sq + 255) / 256; qb++) {
             const long t = tiles_of(e, qb);
+            blk_tiles.push_back(t);
             W += t * p->h;
             nblk += p->h;
             longest = t > longest ? t : longest;
         }
     }
-    if (W <= 0 || nblk <= 0) return 0;
+    const long forced_T = p->num_splits < 0 ? -(long)p->num_splits : 0;      // num_splits = -T: pieces of at most T tiles, no questions asked
+    if (W <= 0 || nblk <= 0 || (!forced_T && longest < 96)) return 0;
     const long avg = (W + kSlots - 1) / kSlots;
     // grids of several rounds of workgroups whose longest is no longer than ~a round's share are balanced by the dispatcher's
     // longest-first order already (and keep the XCD-grouped order that lets the heads of a kv group share their K/V stream in L2)
-    if (nblk >= 4 * kSlots || (nblk >= kSlots && longest * 4 <= avg * 5)) return 0;
-    long T = avg < 16 ? 16 : avg;
-    if (longest > 16 * T) T = (longest + 15) / 16;     // the merge takes at most 16 shares per block
+    if (!forced_T && (nblk >= 4 * kSlots || (nblk >= kSlots && longest * 4 <= avg * 5))) return 0;
+    auto price = [&](long T, long* pieces_out, long* rows_out) -> double {
+        std::vector<long> cost;
+        long rows = 0;
+        for (long t : blk_tiles) {
+            long ns = (t + T - 1) / T;
+            if (ns < 1) ns = 1;
+            if (ns > 16) return 1e30;
+            const long per = (t + ns - 1) / ns;
+            for (int h = 0; h < p->h; h++) {
+                for (long s_ = 0; s_ < ns; s_++) {
+                    long tb = s_ * per, te = tb + per;
+                    if (tb > t) tb = t;
+                    if (te > t) te = t;
+                    cost.push_back(2 * (te - tb) + 6 + (ns > 1 ? 3 : 0));        // half-tile units
+                }
+                if (ns > 1) rows += 256 * ns;
+            }
+        }
+        std::sort(cost.begin(), cost.end(), std::greater<long>());
+        std::priority_queue<long, std::vector<long>, std::greater<long>> cu;   // load of every CU, least loaded on top
+        for (long i = 0; i < kSlots; i++) cu.push(0);
+        long makespan = 0;
+        for (long c : cost) {
+            const long l = cu.top() + c;
+            cu.pop();
+            cu.push(l);
+            makespan = l > makespan ? l : makespan;
+        }
+        *pieces_out = (long)cost.size();
+        *rows_out = rows;
+        // merge pass: every partial row is written once and read once (516 B each way) at ~3 TB/s, in half-tile units of ~0.9 us
+        return (double)makespan + (double)rows * 1032.0 / 3.0e12 / 0.9e-6;
+    };
+    static const long kShares[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+    double best = 1e30;
+    long T = 0, best_rows = 0;
+    if (forced_T) {
+        long pieces = 0;
+        T = forced_T;
+        if (longest > 16 * T) T = (longest + 15) / 16;
+        if (price(T, &pieces, &best_rows) >= 1e30 || pieces > cap_items) return 0;
+    }
+    for (long ns_max : kShares) {
+        if (forced_T) break;
+        const long t_c = (longest + ns_max - 1) / ns_max;
+        if (t_c < 12 && ns_max > 1) break;             // pieces shorter than ~12 tiles are all prologue
+        long pieces = 0, rows = 0;
+        const double c = price(t_c, &pieces, &rows);
+        if (pieces > cap_items) continue;
+        if (c < best - 1e-9) { best = c; T = t_c; best_rows = rows; }
+    }
+    if (T == 0 || (!forced_T && T >= longest)) return 0;      // nothing worth cutting: the default launch
+    if (best_rows > 0x7fffffffL - 4096) return 0;
     int n = 0, nb = 0;
     long part_rows = 0;
+    size_t bi = 0;
     for (int e = 0; e < p->b; e++) {
         const long sq = q_lens ? q_lens[e] : p->seqlen_q;
         for (int qb = 0; qb < (sq + 255) / 256; qb++) {
-            const long t = tiles_of(e, qb);
+            const long t = blk_tiles[bi++];
             long ns = (t + T - 1) / T;
             if (ns < 1) ns = 1;
             const long per = (t + ns - 1) / ns;
@@ -680,7 +743,6 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
                     n++;
                 }
                 if (ns > 1) part_rows += 256 * ns;
-                if (part_rows > 0x7fffffffL - 4096) return 0;
             }
         }
     }

@@ -270,19 +270,24 @@ class _PrefillPlan:
             p.pf_part_rows = self.part_rows
 
 
-def prefill_plan(p, q_lens_host, k_lens_host, dev) -> _PrefillPlan:
-    """q_lens_host: chunk length per entry (None: p.seqlen_q for all); k_lens_host: visible keys per entry."""
+def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0) -> _PrefillPlan:
+    """q_lens_host: chunk length per entry (None: p.seqlen_q for all); k_lens_host: visible keys per entry; force_tiles: pieces of at
+    most this many 64-key tiles whatever the planner's own rules say (tests, A/B)."""
     B = p.b
     q_of = q_lens_host if q_lens_host is not None else [p.seqlen_q] * B
     n_blk = sum((int(q) + 255) // 256 for q in q_of) * p.h          # (entry, head, 256-row query block) triples
     cap_i, cap_b = 17 * n_blk + 16, n_blk + 16
-    if n_blk > 4 * 256 + 64:                  # (the planner keeps the default launch for grids of several rounds: skip the tables)
+    if n_blk > 4 * 256 + 64 and not force_tiles:      # (the planner keeps the default launch for grids of several rounds)
         return _PrefillPlan()
     items, blocks = (K.PrefillItem * cap_i)(), (K.PrefillItem * cap_b)()
     counts = (C.c_int32 * 3)()
     ql = (C.c_int32 * B)(*[int(x) for x in q_lens_host]) if q_lens_host is not None else None
     kl = (C.c_int32 * B)(*[int(x) for x in k_lens_host])
+    keep_ns = p.num_splits
+    if force_tiles:
+        p.num_splits = -int(force_tiles)
     n = K.klib().vattn_prefill_plan(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, counts)
+    p.num_splits = keep_ns
     if n < 0:
         raise RuntimeError("vattn_prefill_plan: bad arguments")
     if n == 0:
