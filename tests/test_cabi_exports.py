@@ -239,7 +239,8 @@ def test_prefill_plan_lists_every_key_tile_once_and_cuts_only_long_blocks():
     n, lens, counts = check([8192], [8192], 8, 1)
     assert 256 < n < 700 and max(lens) <= 67                   # the short blocks stay whole, the long ones are cut in two or three
     check([7344], [7344], 8, 1)
-    assert plan([4096], [4096], 8, 1)[0] == 0 and plan([2048], [2048], 8, 1)[0] == 0      # no key walk of 96 tiles: default launch
+    check([4096], [4096], 8, 1)
+    assert plan([2048], [2048], 8, 1)[0] == 0                   # no key walk of 48 tiles: default launch
     check([12001, 900, 600], [12001, 900, 600], 8, 1)           # one long prompt beside short ones: its last blocks outlast the average
     assert plan([12001, 4119, 7000], [12001, 4119, 7000], 8, 1)[0] == 0      # three rounds of blocks, none longer than a CU's share
     check([2048], [32768], 8, 1)                                # a 2 k chunk on a 30 k prefix: 64 equal blocks, four shares each

@@ -660,7 +660,7 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
         }
     }
     const long forced_T = p->num_splits < 0 ? -(long)p->num_splits : 0;      // num_splits = -T: pieces of at most T tiles, no questions asked
-    if (W <= 0 || nblk <= 0 || (!forced_T && longest < 96)) return 0;
+    if (W <= 0 || nblk <= 0 || (!forced_T && longest < 48)) return 0;
     const long avg = (W + kSlots - 1) / kSlots;
     // grids of several rounds of workgroups whose longest is no longer than ~a round's share are balanced by the dispatcher's
     // longest-first order already (and keep the XCD-grouped order that lets the heads of a kv group share their K/V stream in L2)
