@@ -242,7 +242,13 @@ def test_prefill_plan_lists_every_key_tile_once_and_cuts_only_long_blocks():
     check([4096], [4096], 8, 1)
     assert plan([2048], [2048], 8, 1)[0] == 0                   # no key walk of 48 tiles: default launch
     check([12001, 900, 600], [12001, 900, 600], 8, 1)           # one long prompt beside short ones: its last blocks outlast the average
-    assert plan([12001, 4119, 7000], [12001, 4119, 7000], 8, 1)[0] == 0      # three rounds of blocks, none longer than a CU's share
+    # three rounds of blocks, none longer than a CU's share: nothing is cut, but a RAGGED batch still gets a list — the default grid's
+    # exit workgroups starve part of the chip (static striping over shader engines) — of exactly the valid blocks
+    n, lens, counts = check([12001, 4119, 7000], [12001, 4119, 7000], 8, 1)
+    assert n == (47 + 17 + 28) * 8 and counts[1] == 0 and counts[2] == 0
+    n, lens, counts = check([7344, 8347, 7339, 5353], [7344, 8347, 7339, 5353], 32, 8)      # Llama-3-8B heads: XCD-affine head order
+    assert counts[1] == 0
+    assert plan([8192, 8192], [8192, 8192], 32, 8)[0] == 0                                   # equal lengths, balanced: default grid
     check([2048], [32768], 8, 1)                                # a 2 k chunk on a 30 k prefix: 64 equal blocks, four shares each
     check([300, 1, 700], [9300, 50, 700], 4, 2)                 # ragged small chunks (incl. a one-token entry), one on a long prefix
     # keep the default launch: a grid of many balanced rounds, d = 64, the decode form

@@ -277,7 +277,8 @@ def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0) -> _Pre
     q_of = q_lens_host if q_lens_host is not None else [p.seqlen_q] * B
     n_blk = sum((int(q) + 255) // 256 for q in q_of) * p.h          # (entry, head, 256-row query block) triples
     cap_i, cap_b = 17 * n_blk + 16, n_blk + 16
-    if n_blk > 4 * 256 + 64 and not force_tiles:      # (the planner keeps the default launch for grids of several rounds)
+    ragged = q_lens_host is not None and len({(int(q) + 255) // 256 for q in q_lens_host}) > 1
+    if n_blk > 4 * 256 + 64 and not force_tiles and not ragged:      # (the planner keeps the default launch for balanced grids of several rounds)
         return _PrefillPlan()
     items, blocks = (K.PrefillItem * cap_i)(), (K.PrefillItem * cap_b)()
     counts = (C.c_int32 * 3)()
