@@ -28,7 +28,7 @@ def _check(out_gpu, ref64, ref32, dtype, what):
         "%s: kernel err %.3e vs reference-numerics err %.3e" % (what, err.max().item(), e_ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 65536, 131072], ids=["tr_read", "plain_read", "wg512", "wg1024"])
+@pytest.mark.parametrize("variant", [0, 1, 65536, 131072, 262144], ids=["tr_read", "plain_read", "wg512", "wg1024", "two_register_sets"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("B,G,Hkv,lens", [
     (1, 8, 4, [777]),                    # Yi-6B group size
@@ -203,7 +203,7 @@ def test_prefill_work_list_matches_the_oracle(Hq, Hkv, chunks, dtype):
         assert (outs[2] - outs[1]).abs().max().item() <= (2e-3 if dtype == torch.float16 else 1.6e-2)
 
 
-@pytest.mark.parametrize("variant", [0, 65536, 131072], ids=["wg256", "wg512", "wg1024"])
+@pytest.mark.parametrize("variant", [0, 65536, 131072, 262144], ids=["wg256", "wg512", "wg1024", "two_register_sets"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("Hq,Hkv,lens", [
     (8, 1, [5000, 31, 900, 2100, 64, 1, 3333, 12000, 700, 450]),          # one TP=8 rank: ragged contexts on ONE kv head

@@ -176,5 +176,5 @@ if __name__ == "__main__":
         if "--dvariants" in sys.argv:
             dvs = [int(x) for x in sys.argv[sys.argv.index("--dvariants") + 1].split(",")]
         for v in dvs:
-            print("-- decode variant %d (%s) --" % (v, "512-thread workgroups" if v & 65536 else "1024-thread workgroups" if v & 131072 else "256-thread workgroups (default)"))
+            print("-- decode variant %d (%s) --" % (v, "512-thread workgroups" if v & 65536 else "1024-thread workgroups" if v & 131072 else "256 threads, two K/V register sets per wave" if v & 262144 else "256-thread workgroups (default)"))
             decode(v)

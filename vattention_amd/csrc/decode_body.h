@@ -18,7 +18,10 @@ constexpr int DC_BN = 32;     // keys per wave tile
 // keeps the kernel inside the 168-register budget of three workgroups per CU; wider groups run as ceil(G/32) such workgroups.
 // W:  waves per workgroup (4 = 256 threads, three workgroups per CU; 8 = 512 threads, two per CU: 16 waves per CU instead of 12 and a
 //     third fewer partials for the same number of resident wave-tiles).
-template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES>
+// PF: K/V register sets per wave = tiles a wave keeps in flight (1: the product shape for chip-filling grids, three workgroups per CU; 2:
+//     a second set, requested a whole tile earlier — a lone wave then pulls twice the bytes per round trip, which is what bounds
+//     launches with FEWER workgroups than the chip has room for: batch 1-4 decode; two workgroups per CU).
+template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES, int PF = 1>
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
                                             const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0,
                                             const int item = -1, const int item_tb = 0, const int item_te = 0) {
@@ -111,7 +114,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     const float sc = p.softmax_scale * kLog2e;
     char* vsm = smem + wave * V_WAVE_BYTES;
 
-    uint4 kreg[2][KK], vreg[VPASS];
+    uint4 kreg[PF][2][KK], vreg[PF][VPASS];
     const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
     const T* kbase_u = uniform_ptr(kbase);
     const T* vbase_u = uniform_ptr(vbase);
@@ -122,7 +125,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     const unsigned voff0 = (unsigned)(lane / CPR) * v_rs_bytes + (unsigned)(lane % CPR) * 16u;
     const unsigned k_kb_step = __builtin_amdgcn_readfirstlane(16u * k_rs_bytes);
     const unsigned v_ps_step = __builtin_amdgcn_readfirstlane((unsigned)(64 / CPR) * v_rs_bytes);
-    auto load_tile = [&](int tile) {
+    auto load_tile = [&](const int u, int tile) {      // u: register set, a literal at every call site (unrolled loops)
         const int k0 = tile * DC_BN;
         int rem = Lk - k0;
         rem = rem < 0 ? 0 : (rem > DC_BN ? DC_BN : rem);
@@ -135,12 +138,12 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-            for (int kk = 0; kk < KK; kk++) kreg[kb][kk] = buf_load16(kr, ko + (unsigned)kb * k_kb_step + 64u * kk);
+            for (int kk = 0; kk < KK; kk++) kreg[u][kb][kk] = buf_load16(kr, ko + (unsigned)kb * k_kb_step + 64u * kk);
 #pragma unroll
-        for (int ps = 0; ps < VPASS; ps++) vreg[ps] = buf_load16(vr, vo + (unsigned)ps * v_ps_step);
+        for (int ps = 0; ps < VPASS; ps++) vreg[u][ps] = buf_load16(vr, vo + (unsigned)ps * v_ps_step);
     };
     // the new K/V row (fused append) replaces its row of the LAST tile in registers; the gb == 0 workgroup also stores it
-    auto substitute_new_row = [&](int k0) {
+    auto substitute_new_row = [&](int k0) {      // (register set 0: the last tile is loaded there)
         const T* kn = (const T*)p.k_new + (int64_t)b * p.knew_batch_stride + (int64_t)hk * p.knew_head_stride;
         const T* vn = (const T*)p.v_new + (int64_t)b * p.vnew_batch_stride + (int64_t)hk * p.vnew_head_stride;
         T* kc = (T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride + (int64_t)new_key * p.k_row_stride;
@@ -163,7 +166,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
                 for (int kk = 0; kk < KK; kk++) {
                     uint4 v;
                     __builtin_memcpy(&v, &kn8[kk], 16);
-                    kreg[kb][kk] = v;
+                    kreg[0][kb][kk] = v;
                     if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(kc + 32 * kk + 8 * g4) = v;
                 }
             }
@@ -172,7 +175,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             const int idx = ps * 64 + lane;
             if (k0 + idx / CPR == new_key) {
                 const uint4 v = *(const uint4*)(vn + (idx % CPR) * 8);
-                vreg[ps] = v;
+                vreg[0][ps] = v;
                 if (gb == 0 && new_key < p.seqlen_k) *(uint4*)(vc + (idx % CPR) * 8) = v;
             }
         }
@@ -180,7 +183,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     // One 32-key tile of this wave: V registers -> wave-private LDS, S^T = K.Q^T on the register-resident K fragments, request the
     // wave's next tile into the freed registers, online softmax, O^T += V^T.P^T.  RAGGED: the sequence's last tile (keys at or
     // beyond Lk are masked) — a literal at both call sites, so the steady-state loop carries no mask and no append code.
-    auto process_tile = [&](auto ragged_tag, const int tile, const int next_tile) {
+    auto process_tile = [&](auto ragged_tag, const int u, const int tile, const int next_tile) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         const int k0 = tile * DC_BN;
         // ---- V: registers -> wave-private LDS ([d/16][key][16 d]) ----
@@ -188,7 +191,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
         for (int ps = 0; ps < VPASS; ps++) {
             const int idx = ps * 64 + lane;
             const int row = idx / CPR, c = idx % CPR;
-            *(uint4*)(vsm + (c >> 1) * VSUB + row * 32 + ((c & 1) << 4)) = vreg[ps];
+            *(uint4*)(vsm + (c >> 1) * VSUB + row * 32 + ((c & 1) << 4)) = vreg[u][ps];
         }
         // ---- S^T = K.Q^T (every head block of the group uses the same K fragments) ----
         f32x4 s[NB][2];
@@ -207,11 +210,11 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             for (int kb = 0; kb < 2; kb++) {
                 s[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < KK; kk++) s[nb][kb] = X::mfma16(as_v8<V8>(kreg[kb][kk]), qt[kk], s[nb][kb]);
+                for (int kk = 0; kk < KK; kk++) s[nb][kb] = X::mfma16(as_v8<V8>(kreg[u][kb][kk]), qt[kk], s[nb][kb]);
             }
         }
         // request the wave's next tile while this one is being consumed (past the end: every lane out of range, no access)
-        if (!RAGGED) load_tile(next_tile);
+        if (!RAGGED) load_tile(u, next_tile);
 
         // s[nb][kb][r] = S^T[key = k0 + 16*kb + 4*g4 + r][head row l15 of block nb]
         V8 pf[NB];
@@ -285,16 +288,22 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     const bool own_last = special_last && last_tile >= first && last_tile < tile_end && ((last_tile - first) % W) == 0;
     const int loop_end = own_last ? last_tile : tile_end;          // wave-uniform
     if (first < loop_end) {
-        load_tile(first);
-        for (int tile = first; tile < loop_end; tile += W) {
-            const int nxt = tile + W;
-            process_tile(std::false_type{}, tile, nxt < loop_end ? nxt : ntiles_total);
+#pragma unroll
+        for (int u = 0; u < PF; u++) load_tile(u, first + u * W < loop_end ? first + u * W : ntiles_total);
+        for (int tile0 = first; tile0 < loop_end; tile0 += PF * W) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int tile = tile0 + u * W;
+                if (tile >= loop_end) break;                 // wave-uniform
+                const int nxt = tile + PF * W;
+                process_tile(std::false_type{}, u, tile, nxt < loop_end ? nxt : ntiles_total);
+            }
         }
     }
     if (own_last) {
-        load_tile(last_tile);
+        load_tile(0, last_tile);
         if (fused_append) substitute_new_row(last_tile * DC_BN);
-        process_tile(std::true_type{}, last_tile, ntiles_total);
+        process_tile(std::true_type{}, 0, last_tile, ntiles_total);
     }
 
     // ---- merge the W waves (each holds a partial softmax over its own tiles), one head block after the other ----
@@ -432,15 +441,15 @@ __device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params
 
 // gblocks = head-block GROUPS per kv head (ceil(ceil(G/16) / NB)).  `done`: NULL = partials are merged by combine_kernel in a second
 // launch; else one zero-initialised int per (sequence, kv head, group): single-launch merge.
-template <typename T, int HD, bool USE_TR, int NB, int W = DC_WAVES>
-__global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB > 1)) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done, int merge_mode) {
+template <typename T, int HD, bool USE_TR, int NB, int W = DC_WAVES, int PF = 1>
+__global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB > 1) || PF > 1) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done, int merge_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;
     int split, hk, gb, b;
     if (p.split_items != nullptr) {
         // length-balanced plan: blockIdx.x = work item (a piece of ONE sequence), blockIdx.y = (kv head, head-block group)
         const vattn_decode_item it = p.split_items[blockIdx.x];
-        decode_body<T, HD, USE_TR, NB, W>(p, 2, gblocks, fused_append, it.index_in_seq, blockIdx.y / gblocks, blockIdx.y % gblocks, it.b, smem, 0,
+        decode_body<T, HD, USE_TR, NB, W, PF>(p, 2, gblocks, fused_append, it.index_in_seq, blockIdx.y / gblocks, blockIdx.y % gblocks, it.b, smem, 0,
                                           (int)blockIdx.x, it.tile_begin, it.tile_end);
         return;
     }
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB >
         gb = blockIdx.y % gblocks;
         b = blockIdx.z;
     }
-    decode_body<T, HD, USE_TR, NB, W>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0);
+    decode_body<T, HD, USE_TR, NB, W, PF>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0);
     if (kLab && W == DC_WAVES && done != nullptr && num_splits > 1)
         decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket, merge_mode);
 }

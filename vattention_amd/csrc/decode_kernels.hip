@@ -152,17 +152,23 @@ static inline int decode_shape(const vattn_attn_params* p) {
     if (!kLab || p->d != 128 || decode_nb(p) != 1) return 0;      // the alternative shapes exist for d = 128, one head block per workgroup
     return (p->variant & 65536) ? 1 : (p->variant & 131072) ? 2 : 0;      // 1: 8 waves (512 slots), 2: 16 waves (256 slots)
 }
+// Two K/V register sets per wave (decode_body.h, PF = 2; two workgroups per CU).  Variant bit 18 forces it (A/B).
+static inline bool decode_pf2(const vattn_attn_params* p) {
+    if (p->d != 128 || decode_nb(p) != 1) return false;
+    return (p->variant & 262144) != 0;
+}
 static inline long decode_slots(const vattn_attn_params* p) {      // resident workgroups
     if (decode_shape(p) == 1) return 512;
     if (decode_shape(p) == 2) return 256;
+    if (decode_pf2(p)) return 512;
     return (p->d == 128 && decode_nb(p) == 2) ? 512 : 768;
 }
 static inline bool decode_inline_merge(const vattn_attn_params* p, int splits, int groups) {
     (void)groups;
     return splits > 1 && (p->variant & (512 | 1024)) != 0;      // bit 9: fence protocol, bit 10: device-scope accesses, no fence
 }
-template <typename T, int HD, int NB, int W = DC_WAVES> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
-    const bool use_tr = (p->variant & 1) == 0 || W != DC_WAVES;
+template <typename T, int HD, int NB, int W = DC_WAVES, int PF = 1> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
+    const bool use_tr = (p->variant & 1) == 0 || W != DC_WAVES || PF != 1;
     const int groups = decode_groups(p);
     const bool planned = p->split_items != nullptr;
     if (planned && (!p->split_seq || p->num_split_items <= 0)) return fail(VATTN_K_ERR_INVALID, "split_items needs split_seq and num_split_items");
@@ -177,7 +183,7 @@ template <typename T, int HD, int NB, int W = DC_WAVES> int launch_decode_nb(con
     const size_t smem = (size_t)W * 16 * HD * 4 + W * 16 * 4 * 2 + (W > DC_WAVES ? NB * (HD / 32) * 1024 : 0);   // merge area >= V staging (W x 8 KiB), then Q^T fragments
     if (smem > 48 * 1024) {
         static const bool once = [] {
-            (void)hipFuncSetAttribute((const void*)decode_kernel<T, HD, true, NB, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)W * 16 * HD * 4 + W * 16 * 4 * 2 + NB * (HD / 32) * 1024));
+            (void)hipFuncSetAttribute((const void*)decode_kernel<T, HD, true, NB, W, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)W * 16 * HD * 4 + W * 16 * 4 * 2 + NB * (HD / 32) * 1024));
             return true;
         }();
         (void)once;
@@ -185,11 +191,11 @@ template <typename T, int HD, int NB, int W = DC_WAVES> int launch_decode_nb(con
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
     const vattn_attn_params& q = *p;
-    int* done = (W == DC_WAVES && !planned && decode_inline_merge(p, splits, groups)) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
+    int* done = (W == DC_WAVES && PF == 1 && !planned && decode_inline_merge(p, splits, groups)) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
     const bool inline_merge = done != nullptr;
     const int mm = !inline_merge ? 0 : (p->variant & 1024) ? 2 : 1;
-    if constexpr (W != DC_WAVES) {
-        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB, W>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
+    if constexpr (W != DC_WAVES || PF != 1) {
+        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB, W, PF>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
     } else {
         bool plain = false;
         if constexpr (kLab) {      // variant bit 0: V^T fragments by plain LDS reads
@@ -215,6 +221,9 @@ template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hi
         if (shape == 2) return launch_decode_nb<T, 128, 1, 16>(p, st);
     }
 #endif
+    if constexpr (HD == 128) {
+        if (decode_pf2(p)) return launch_decode_nb<T, 128, 1, DC_WAVES, 2>(p, st);
+    }
     return decode_nb(p) == 2 ? launch_decode_nb<T, HD, 2>(p, st) : launch_decode_nb<T, HD, 1>(p, st);
 }
 
