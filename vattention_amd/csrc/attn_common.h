@@ -36,7 +36,7 @@ constexpr bool kLab = false;
 #endif
 // variant bits of vattn_attn_params a product build accepts: bits 1-3 tiling {0 plan, 1 = 8 waves x 32 rows, 4 = 4 waves x 32 rows,
 // 7 = prefill64}; bits 5-6 workgroup order; bit 7 one 16-head block per decode workgroup; bits 12-13 role policy of the fused launch
-constexpr int kProductVariantMask = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | (1 << 18);
+constexpr int kProductVariantMask = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12);
 
 template <typename T> struct Tr;
 template <> struct Tr<_Float16> {

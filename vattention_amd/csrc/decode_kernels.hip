@@ -152,9 +152,11 @@ static inline int decode_shape(const vattn_attn_params* p) {
     if (!kLab || p->d != 128 || decode_nb(p) != 1) return 0;      // the alternative shapes exist for d = 128, one head block per workgroup
     return (p->variant & 65536) ? 1 : (p->variant & 131072) ? 2 : 0;      // 1: 8 waves (512 slots), 2: 16 waves (256 slots)
 }
-// Two K/V register sets per wave (decode_body.h, PF = 2; two workgroups per CU).  Variant bit 18 forces it (A/B).
+// Two K/V register sets per wave (decode_body.h, PF = 2; two workgroups per CU).  LAB ONLY (variant bit 18): it helps the one shape
+// whose grid is smaller than the chip — B1 @ 32 k: 23.4 -> 21.4 us — and costs 1-8 % on grids that fill it (B16 @ 32 k: 0.191 -> 0.206 ms,
+// profiles/r03_kbench_decode_shapes.txt): a third of the resident waves for twice the bytes per wave is a bad trade once every CU is busy.
 static inline bool decode_pf2(const vattn_attn_params* p) {
-    if (p->d != 128 || decode_nb(p) != 1) return false;
+    if (!kLab || p->d != 128 || decode_nb(p) != 1) return false;
     return (p->variant & 262144) != 0;
 }
 static inline long decode_slots(const vattn_attn_params* p) {      // resident workgroups
@@ -221,9 +223,11 @@ template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hi
         if (shape == 2) return launch_decode_nb<T, 128, 1, 16>(p, st);
     }
 #endif
+#ifdef VATTN_LAB
     if constexpr (HD == 128) {
         if (decode_pf2(p)) return launch_decode_nb<T, 128, 1, DC_WAVES, 2>(p, st);
     }
+#endif
     return decode_nb(p) == 2 ? launch_decode_nb<T, HD, 2>(p, st) : launch_decode_nb<T, HD, 1>(p, st);
 }
 

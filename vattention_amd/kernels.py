@@ -43,7 +43,7 @@ class DecodeItem(C.Structure):
 _bound = False
 _lab = None
 # variant bits the PRODUCT library accepts (csrc/attn_common.h, kProductVariantMask) and the tilings among bits 1-3
-PRODUCT_VARIANT_MASK = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | (1 << 18)
+PRODUCT_VARIANT_MASK = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12)
 PRODUCT_TILINGS = (0, 1, 4, 7)
 
 
