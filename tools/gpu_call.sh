@@ -7,6 +7,8 @@
 #   rank:N[:ARGS]     python bench.py --rank-of N ARGS (default: --steps 1 --warmup 1)
 #   kbench[:ARGS]     python tools/kbench.py ARGS
 #   py:FILE[:ARGS]    python FILE ARGS
+#   sh:FILE[:ARGS]    bash FILE ARGS
+#   gloo2[:ARGS]      python bench.py --gpus 2 ARGS with VATTN_BENCH_BACKEND=gloo (two ranks sharing the one GPU: the N > 1 code path)
 #   prof:NAME:CMD     rocprofv3 --kernel-trace --stats of CMD, summary copied to gpurun_out/<tag>_prof_NAME/
 # TAG (environment) prefixes the log names (default "c").
 cd "$(dirname "$0")/.."
@@ -41,6 +43,12 @@ for step in "$@"; do
         py)
             f=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
             timeout 900 python $f $args > $log 2>&1; echo "py rc=$?" >> $log; tail -40 $log ;;
+        sh)
+            f=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
+            timeout 1200 bash $f $args > $log 2>&1; echo "sh rc=$?" >> $log; tail -60 $log ;;
+        gloo2)
+            VATTN_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 ${rest:---steps 1 --warmup 1} > gpurun_out/${TAG}${i}_gloo2.json 2> $log
+            echo "gloo2 rc=$?" >> $log; tail -3 $log; tail -c 1500 gpurun_out/${TAG}${i}_gloo2.json ;;
         prof)
             name=${rest%%:*}; cmd=${rest#*:}
             ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o $name -- bash -c "cd $GRAFT_REPO_ROOT && $cmd" ) > $log 2>&1

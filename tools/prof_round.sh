@@ -1,13 +1,18 @@
-set -x
-cd /root/repo
-export TMPDIR=/tmp
-mkdir -p gpurun_out/prof2
-timeout 280 python bench.py --steps 2 --warmup 1 > gpurun_out/prof2/bench_n1.json 2> gpurun_out/prof2/bench_n1.err
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof2/kt -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof2/bench_prof.json 2> gpurun_out/prof2/kt.err
-python tools/rocpd_stats.py $(find gpurun_out/prof2/kt -name "*.db" | head -1) > gpurun_out/prof2/bench_kernel_stats.md 2>> gpurun_out/prof2/kt.err
-timeout 200 python tools/kbench.py > gpurun_out/prof2/kbench.txt 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof2/pmc_fetch -- python tools/kbench.py --only "yi6b" --variants 0 > /dev/null 2> gpurun_out/prof2/pmc_fetch.err
-timeout 200 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof2/pmc_write -- python tools/kbench.py --only "yi6b" --variants 0 > /dev/null 2> gpurun_out/prof2/pmc_write.err
-(python tools/pmc_summary.py gpurun_out/prof2/pmc_fetch; python tools/pmc_summary.py gpurun_out/prof2/pmc_write) > gpurun_out/prof2/hbm_pmc_raw.txt 2>&1
-find gpurun_out/prof2 -name "*.db" -size +20M -delete
-du -sh gpurun_out/prof2
+#!/bin/bash
+# The round's profiling evidence in one go (bash tools/prof_round.sh [outdir]): rocprofv3 kernel statistics of the bench workload
+# (whose average launch durations must agree with the HIP-event timings bench.py reports), HBM traffic of the two dominant kernels
+# (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, never combined with API traces), SQ / L2 counters of both (tools/pmc_*.sh).
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+O=${1:-gpurun_out/prof3}
+mkdir -p $O
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 2 --warmup 1 --no-dynamic --no-cpu-baseline > $O/bench_prof.json 2> $O/kt.err
+python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) > $O/bench_kernel_stats.md 2>> $O/kt.err
+timeout 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -- python tools/kbench.py --only "yi6b whole,yi6b B16@32k" --variants 0 > /dev/null 2> $O/pmc_fetch.err
+timeout 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- python tools/kbench.py --only "yi6b whole,yi6b B16@32k" --variants 0 > /dev/null 2> $O/pmc_write.err
+(python tools/pmc_summary.py $O/pmc_fetch; python tools/pmc_summary.py $O/pmc_write) > $O/hbm_pmc_raw.txt 2>&1
+bash tools/pmc_decode.sh > $O/decode_pmc_raw.txt 2>&1
+bash tools/pmc_prefill.sh > $O/prefill_pmc_raw.txt 2>&1
+find $O -name "*.db" -delete
+rm -rf $O/kt $O/pmc_fetch $O/pmc_write
+tail -c 600 $O/bench_prof.json; head -30 $O/bench_kernel_stats.md; cat $O/hbm_pmc_raw.txt | tail -12
