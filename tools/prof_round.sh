@@ -10,7 +10,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) > $O/bench_kernel_stats.md 2>> $O/kt.err
 timeout 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -- python tools/kbench.py --only "yi6b whole,yi6b B16@32k" --variants 0 > /dev/null 2> $O/pmc_fetch.err
 timeout 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- python tools/kbench.py --only "yi6b whole,yi6b B16@32k" --variants 0 > /dev/null 2> $O/pmc_write.err
-(python tools/pmc_summary.py $O/pmc_fetch; python tools/pmc_summary.py $O/pmc_write) > $O/hbm_pmc_raw.txt 2>&1
+(python tools/pmc_summary.py $O/pmc_fetch vattn; python tools/pmc_summary.py $O/pmc_write vattn) > $O/hbm_pmc_raw.txt 2>&1
 bash tools/pmc_decode.sh > $O/decode_pmc_raw.txt 2>&1
 bash tools/pmc_prefill.sh > $O/prefill_pmc_raw.txt 2>&1
 find $O -name "*.db" -delete
