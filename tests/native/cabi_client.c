@@ -59,5 +59,32 @@ int main(void) {
         printf("null_params %d err '%s'\n", rc, vattn_kernels_last_error());
         printf("workspace_bytes %zu sizeof_params %zu\n", vattn_attn_workspace_bytes(&p), sizeof p);
     }
+    /* the host-side planners (pure arithmetic): a ragged decode batch cut into near-equal pieces, a tensor-parallel shard's prompt
+     * listed longest piece first with only its long query blocks cut; a lab-only variant is refused by the product library */
+    {
+        vattn_attn_params p;
+        static vattn_decode_item ditems[4096];
+        static vattn_prefill_item pitems[4096], pblocks[512];
+        int32_t dlens[64], dseq[128], qlen[1] = {8192}, klen[1] = {8192}, counts[3];
+        int32_t n, i, longest = 0;
+        memset(&p, 0, sizeof p);
+        p.b = 64; p.seqlen_q = 1; p.seqlen_k = 32768; p.seqlen_knew = 1; p.h = 8; p.h_k = 1; p.d = 128;
+        for (i = 0; i < 64; i++) dlens[i] = 500 + 450 * i;                         /* 500 .. 28 850 tokens */
+        n = vattn_decode_plan(&p, dlens, ditems, 4096, dseq);
+        for (i = 0; i < n; i++) if (ditems[i].tile_end - ditems[i].tile_begin > longest) longest = ditems[i].tile_end - ditems[i].tile_begin;
+        printf("decode_plan items %d first_seq_pieces %d last_seq_pieces %d longest_piece_tiles %d\n", n, dseq[1], dseq[127], longest);
+        memset(&p, 0, sizeof p);
+        p.b = 1; p.seqlen_q = 8192; p.h = 8; p.h_k = 1; p.d = 128; p.is_causal = 1;
+        n = vattn_prefill_plan(&p, qlen, klen, pitems, 4096, pblocks, 512, counts);
+        printf("prefill_plan items %d split_blocks %d partial_rows %d first_piece_tiles %d last_piece_tiles %d\n", n, counts[1], counts[2],
+               pitems[0].tile_end - pitems[0].tile_begin, pitems[n > 0 ? n - 1 : 0].tile_end - pitems[n > 0 ? n - 1 : 0].tile_begin);
+        p.q = p.out = p.k_cache = p.v_cache = &p;      /* (never dereferenced: validation stops at the variant) */
+        p.seqlen_k = 8192; p.dtype = VATTN_DTYPE_F16;
+        p.q_row_stride = p.q_head_stride = p.q_batch_stride = p.k_row_stride = p.k_head_stride = p.k_batch_stride = 8;
+        p.v_row_stride = p.v_head_stride = p.v_batch_stride = p.o_row_stride = p.o_head_stride = p.o_batch_stride = 8;
+        p.variant = 4 << 8;                            /* a timing ablation of the lab build */
+        rc = vattn_flash_attn_with_kvcache(&p, NULL);
+        printf("lab_variant %d err '%s'\n", rc, vattn_kernels_last_error());
+    }
     return 0;
 }

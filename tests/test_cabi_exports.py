@@ -80,6 +80,12 @@ def test_plain_c_client_drives_the_boundary(tmp_path):
     assert "step_async 0" in text and "pool_pages 52 mapped_groups 3 needed_groups 3 active_slots 1 map_calls 12" in text
     assert "bad_len -1 err 'seq_lens must have max_batch_size entries'" in text
     assert "cleanup 0" in text and "null_params" in text and "null tensor pointer" in text
+    import re
+    m = re.search(r"decode_plan items (\d+) first_seq_pieces (\d+) last_seq_pieces (\d+) longest_piece_tiles (\d+)", text)
+    assert m and 64 < int(m.group(1)) <= 768 and int(m.group(2)) == 1 and int(m.group(3)) > 4 and int(m.group(4)) < 902 // 3, text
+    m = re.search(r"prefill_plan items (\d+) split_blocks (\d+) partial_rows (\d+) first_piece_tiles (\d+) last_piece_tiles (\d+)", text)
+    assert m and int(m.group(1)) > 256 and int(m.group(2)) > 0 and int(m.group(3)) % 256 == 0 and int(m.group(4)) >= int(m.group(5)), text
+    assert "lab_variant -11" in text and "measurement build" in text
 
 
 def test_split_plans_from_the_workspace_query():
