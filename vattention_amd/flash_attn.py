@@ -312,7 +312,7 @@ def _decode_plan(p, lens_host, dev):
     lens = (C.c_int32 * B)(*[int(x) for x in lens_host])
     items = (K.DecodeItem * cap)()
     seq = (C.c_int32 * (2 * B))()
-    n = K.klib().vattn_decode_plan(C.byref(p), lens, items, cap, seq)
+    n = K.klib_for(p.variant).vattn_decode_plan(C.byref(p), lens, items, cap, seq)      # (the library that will run the call: its slot count)
     if n < 0:
         raise RuntimeError("vattn_decode_plan: bad arguments")
     if n == 0:
