@@ -209,7 +209,8 @@ def test_prefill_work_list_matches_the_oracle(Hq, Hkv, chunks, dtype):
     (8, 1, [5000, 31, 900, 2100, 64, 1, 3333, 12000, 700, 450]),          # one TP=8 rank: ragged contexts on ONE kv head
     (32, 8, [9000, 400, 2048, 6000]),                                      # Llama-3-8B heads
     (14, 2, [11000, 100, 100, 100, 100, 100, 5000]),                       # G = 7
-], ids=["tp8_rank", "llama8b", "g7"])
+    (32, 1, [4000, 333, 2500]),                                            # G = 32: two 16-head blocks per workgroup
+], ids=["tp8_rank", "llama8b", "g7", "g32"])
 def test_decode_length_balanced_plan(Hq, Hkv, lens, dtype, variant):
     """A ragged decode batch through the length-balanced plan (vattn_decode_plan: `_cache_seqlens_host` on the Python side) — pieces
     of near-equal length instead of the same number of splits for every sequence — against the oracle, fused append bit-exact, and

@@ -140,11 +140,6 @@ static inline int decode_groups(const vattn_attn_params* p) {
     const int nb = decode_nb(p);
     return (blocks + nb - 1) / nb;
 }
-// Single-launch merge (the last workgroup of a group merges its partials) instead of a second launch of combine_kernel.  MEASURED
-// SLOWER on MI355X and therefore opt-in only (variant bit 9): the release / acquire it needs are agent-scope fences, and on this
-// multi-XCD part each one writes back and invalidates the XCD's L2 — B1 @ 32 k 23.7 -> 41.5 us, B16 @ 32 k 203 -> 243 us
-// (profiles/r02_kbench_decode_merge.txt).  The group counters live in a small library-owned device buffer per (device, stream),
-// zeroed when it is created; the kernel leaves them zero.
 // Workgroup shape (decode_body.h: W waves per workgroup).  LAB ONLY — variant bit 16: 8 waves (two workgroups per CU); bit 17: 16 waves
 // (one): both measured slower than the 4-wave product shape (B16 @ 32 k: 0.192 ms vs 0.207 / 0.204, profiles/r03_kbench_decode_shapes.txt:
 // the pure-read probe's gain from wider workgroups does not carry over to a kernel whose waves each own a register-resident tile).
@@ -165,6 +160,11 @@ static inline long decode_slots(const vattn_attn_params* p) {      // resident w
     if (decode_pf2(p)) return 512;
     return (p->d == 128 && decode_nb(p) == 2) ? 512 : 768;
 }
+// Single-launch merge (the last workgroup of a group merges its partials) instead of a second launch of combine_kernel.  LAB ONLY
+// (variant bits 9 / 10): MEASURED SLOWER on MI355X — the release / acquire it needs are agent-scope fences, and on this multi-XCD part
+// each one writes back and invalidates the XCD's L2: B1 @ 32 k 23.7 -> 41.5 us, B16 @ 32 k 203 -> 243 us
+// (profiles/r02_kbench_decode_merge.txt).  The group counters live in a small library-owned device buffer per (device, stream),
+// zeroed when it is created; the kernel leaves them zero.
 static inline bool decode_inline_merge(const vattn_attn_params* p, int splits, int groups) {
     (void)groups;
     return splits > 1 && (p->variant & (512 | 1024)) != 0;      // bit 9: fence protocol, bit 10: device-scope accesses, no fence
@@ -221,10 +221,6 @@ template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hi
         const int shape = decode_shape(p);
         if (shape == 1) return launch_decode_nb<T, 128, 1, 8>(p, st);
         if (shape == 2) return launch_decode_nb<T, 128, 1, 16>(p, st);
-    }
-#endif
-#ifdef VATTN_LAB
-    if constexpr (HD == 128) {
         if (decode_pf2(p)) return launch_decode_nb<T, 128, 1, DC_WAVES, 2>(p, st);
     }
 #endif
