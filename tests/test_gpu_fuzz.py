@@ -165,3 +165,85 @@ def test_fuzz_prefill64_midsize(seed):
         torch.cuda.synchronize()
         _check(out, ref, dtype, "prefill64 seed %d case %d (Hq=%d Hkv=%d B=%d n=%d cl=%s causal=%s variant=%d splits=%d %s)" % (
             seed, case, Hq, Hkv, B, n, cls, causal, variant, splits, dtype))
+
+
+@pytest.mark.parametrize("seed", range(BASE, BASE + 4 * SCALE))
+def test_fuzz_planned_launches(seed):
+    """Round-3 launch plans under random shapes: ragged decode batches through the length-balanced split (random piece lengths,
+    d = 64 / 128, groups up to 32 heads, with and without the append) and batched prefill chunks through the work list (random piece
+    lengths, prefixes, one-token entries, causal and full) — each against the oracle."""
+    from vattention_amd import flash_attn as FA
+    from vattention_amd import kernels as K
+    from vattention_amd.flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
+    rng = random.Random(7000 + seed)
+    torch.manual_seed(700 + seed)
+    for case in range(5):
+        # ---- decode ----
+        D = rng.choice([64, 128, 128])
+        dtype = rng.choice([torch.float16, torch.bfloat16])
+        Hkv = rng.choice([1, 2, 4])
+        G = rng.choice([1, 4, 7, 8, 16, 32])
+        Hq = Hkv * G
+        B = rng.choice([2, 3, 6, 11])
+        ctx = rng.choice([300, 1500, 2600])
+        cls = [rng.randrange(0, ctx - 1) for _ in range(B)]
+        slots = rng.sample(range(B + 2), B)
+        append = rng.random() < 0.75
+        q = torch.randn(B, 1, Hq, D).to(dtype)
+        kc = torch.randn(B + 2, ctx, Hkv, D).to(dtype)
+        vc = torch.randn(B + 2, ctx, Hkv, D).to(dtype)
+        kn = torch.randn(B, 1, Hkv, D).to(dtype) if append else None
+        vn = torch.randn(B, 1, Hkv, D).to(dtype) if append else None
+        lens = cls if append else [c + 1 for c in cls]
+        cl = torch.tensor(lens, dtype=torch.int32)
+        idx = torch.tensor(slots, dtype=torch.int32)
+        kr, vr = kc.clone(), vc.clone()
+        ref = flash_attn_with_kvcache_ref(q, kr, vr, kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+        kg, vg = kc.to(DEV), vc.to(DEV)
+        cap = []
+        tiles = rng.choice([1, 2, 5, 9, 30])
+        out = flash_attn_with_kvcache(q.to(DEV), kg, vg, kn.to(DEV) if append else None, vn.to(DEV) if append else None,
+                                      cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True, _cache_seqlens_host=lens,
+                                      _plan_tiles=tiles, _params_out=cap)
+        torch.cuda.synchronize()
+        what = "planned decode seed %d case %d (D=%d Hq=%d Hkv=%d B=%d ctx=%d append=%s tiles=%d items=%d)" % (
+            seed, case, D, Hq, Hkv, B, ctx, append, tiles, cap[0].num_split_items)
+        if G <= 32:
+            assert cap[0].num_split_items >= B, what
+        _check(out, ref, dtype, what)
+        assert torch.equal(kg.cpu(), kr) and torch.equal(vg.cpu(), vr), what
+        # ---- prefill work list (d = 128) ----
+        Hkv = rng.choice([1, 2, 4])
+        Hq = Hkv * rng.choice([1, 2, 4, 8])
+        P = rng.choice([1, 2, 3, 4])
+        causal = rng.random() < 0.8
+        chunks = [(rng.choice([0, 0, 40, 700, 1500]), rng.choice([1, 2, 60, 256, 257, 600, 1100])) for _ in range(P)]
+        if all(n == 1 for _, n in chunks):
+            chunks[0] = (chunks[0][0], 300)
+        ctx = max(c + n for c, n in chunks) + 3
+        kc = torch.randn(P + 1, ctx, Hkv, 128).to(dtype)
+        vc = torch.randn(P + 1, ctx, Hkv, 128).to(dtype)
+        T = sum(n for _, n in chunks)
+        q = torch.randn(T, Hq, 128).to(dtype)
+        sl = torch.tensor(rng.sample(range(P + 1), P), dtype=torch.int32)
+        q_lens, k_lens = [n for _, n in chunks], [c + n for c, n in chunks]
+        p = K.AttnParams()
+        p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal = P, max(q_lens), Hq, Hkv, 128, int(causal)
+        tiles = rng.choice([1, 3, 8, 40])
+        plan = FA.prefill_plan(p, q_lens, k_lens, torch.device(DEV), force_tiles=tiles)
+        out = torch.full((T, Hq, 128), float("nan"), dtype=dtype, device=DEV)
+        starts = torch.tensor([sum(q_lens[:i]) for i in range(P)], dtype=torch.int32, device=DEV)
+        flash_attn_varlen_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), starts, torch.tensor(q_lens, dtype=torch.int32, device=DEV), max(q_lens),
+                                       torch.tensor(k_lens, dtype=torch.int32, device=DEV), sl.to(DEV), causal=causal, out=out,
+                                       _max_seqlen_k=max(k_lens), _pf_plan=plan)
+        torch.cuda.synchronize()
+        what = "work-list prefill seed %d case %d (Hq=%d Hkv=%d chunks=%s causal=%s tiles=%d pieces=%d split blocks=%d %s)" % (
+            seed, case, Hq, Hkv, chunks, causal, tiles, plan.n_items, plan.n_blocks, dtype)
+        assert plan.t is not None and not torch.isnan(out.float()).any(), what
+        tok = 0
+        for i, (c, n) in enumerate(chunks):
+            s_ = int(sl[i])
+            ref = flash_attn_with_kvcache_ref(q[tok:tok + n].unsqueeze(0), kc[s_:s_ + 1].clone(), vc[s_:s_ + 1].clone(),
+                                              cache_seqlens=torch.tensor([c + n], dtype=torch.int32), causal=causal)
+            _check(out[tok:tok + n].unsqueeze(0), ref, dtype, what + " entry %d" % i)
+            tok += n
