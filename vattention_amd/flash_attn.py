@@ -240,7 +240,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
             plan = prefill_plan(p, None, _cache_seqlens_host, dev)
         if plan is not None:
             plan.attach(p)
-    if _cache_seqlens_host is not None and Sq == 1 and B > 1 and num_splits == 0:
+    if _cache_seqlens_host is not None and Sq == 1 and B > 1 and num_splits == 0 and not torch.cuda.is_current_stream_capturing():
+        # (the plan's tables travel by a host-to-device copy: not while the stream is being captured into a graph — the uniform split then)
         if _plan_tiles:                                        # (tests / A-B: pieces of exactly this many 32-key tiles)
             p.num_splits = -int(_plan_tiles)
         plan = _decode_plan(p, _cache_seqlens_host, dev)      # ragged batch: work items of near-equal length (None: uniform split)
