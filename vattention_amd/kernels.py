@@ -52,31 +52,30 @@ def needs_lab(variant: int) -> bool:
 
 
 def _bind(lib):
-    if True:
-        lib.vattn_attn_workspace_bytes.restype = C.c_size_t
-        lib.vattn_attn_workspace_bytes.argtypes = [C.POINTER(AttnParams)]
-        lib.vattn_flash_attn_with_kvcache.restype = i32
-        lib.vattn_flash_attn_with_kvcache.argtypes = [C.POINTER(AttnParams), vp]
-        lib.vattn_hybrid_workspace_bytes.restype = C.c_size_t
-        lib.vattn_hybrid_workspace_bytes.argtypes = [C.POINTER(AttnParams), C.POINTER(AttnParams)]
-        lib.vattn_hybrid_attn.restype = i32
-        lib.vattn_hybrid_attn.argtypes = [C.POINTER(AttnParams), C.POINTER(AttnParams), vp, vp]
-        lib.vattn_cache_flat.restype = i32
-        lib.vattn_cache_flat.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp]
-        lib.vattn_cache_flat_rope.restype = i32
-        lib.vattn_cache_flat_rope.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp, i64, i64, vp]
-        lib.vattn_rotary_embedding.restype = i32
-        lib.vattn_rotary_embedding.argtypes = [vp, vp, vp, i64, i32, i32, i32, i64, i64, i32, vp, i64, i32, i32, vp]
-        lib.vattn_selftest_layouts.restype = i32
-        lib.vattn_selftest_layouts.argtypes = [vp, C.POINTER(i32)]
-        lib.vattn_time_attn.restype = C.c_float
-        lib.vattn_time_attn.argtypes = [C.POINTER(AttnParams), vp, i32, i32]
-        lib.vattn_kernels_last_error.restype = C.c_char_p
-        lib.vattn_prefill_plan.restype = i32
-        lib.vattn_prefill_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(i32), C.POINTER(PrefillItem), i32, C.POINTER(PrefillItem), i32,
-                                           C.POINTER(i32)]
-        lib.vattn_decode_plan.restype = i32
-        lib.vattn_decode_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(DecodeItem), i32, C.POINTER(i32)]
+    lib.vattn_attn_workspace_bytes.restype = C.c_size_t
+    lib.vattn_attn_workspace_bytes.argtypes = [C.POINTER(AttnParams)]
+    lib.vattn_flash_attn_with_kvcache.restype = i32
+    lib.vattn_flash_attn_with_kvcache.argtypes = [C.POINTER(AttnParams), vp]
+    lib.vattn_hybrid_workspace_bytes.restype = C.c_size_t
+    lib.vattn_hybrid_workspace_bytes.argtypes = [C.POINTER(AttnParams), C.POINTER(AttnParams)]
+    lib.vattn_hybrid_attn.restype = i32
+    lib.vattn_hybrid_attn.argtypes = [C.POINTER(AttnParams), C.POINTER(AttnParams), vp, vp]
+    lib.vattn_cache_flat.restype = i32
+    lib.vattn_cache_flat.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp]
+    lib.vattn_cache_flat_rope.restype = i32
+    lib.vattn_cache_flat_rope.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i64, i64, i64, i32, vp, i64, i64, vp]
+    lib.vattn_rotary_embedding.restype = i32
+    lib.vattn_rotary_embedding.argtypes = [vp, vp, vp, i64, i32, i32, i32, i64, i64, i32, vp, i64, i32, i32, vp]
+    lib.vattn_selftest_layouts.restype = i32
+    lib.vattn_selftest_layouts.argtypes = [vp, C.POINTER(i32)]
+    lib.vattn_time_attn.restype = C.c_float
+    lib.vattn_time_attn.argtypes = [C.POINTER(AttnParams), vp, i32, i32]
+    lib.vattn_kernels_last_error.restype = C.c_char_p
+    lib.vattn_prefill_plan.restype = i32
+    lib.vattn_prefill_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(i32), C.POINTER(PrefillItem), i32, C.POINTER(PrefillItem), i32,
+                                       C.POINTER(i32)]
+    lib.vattn_decode_plan.restype = i32
+    lib.vattn_decode_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(DecodeItem), i32, C.POINTER(i32)]
     return lib
 
 
