@@ -34,15 +34,17 @@ def test_params_struct_matches_header_size():
     import subprocess
     import tempfile
     from vattention_amd import kernels as K
-    src = '#include "%s/include/vattn_kernels.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu %%zu %%zu", sizeof(vattn_attn_params), offsetof(vattn_attn_params, b), offsetof(vattn_attn_params, softmax_scale));return 0;}\n' % ROOT
+    src = '#include "%s/include/vattn_kernels.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu", sizeof(vattn_attn_params), offsetof(vattn_attn_params, b), offsetof(vattn_attn_params, softmax_scale), offsetof(vattn_attn_params, split_items), offsetof(vattn_attn_params, pf_items), offsetof(vattn_attn_params, pf_part_rows), sizeof(vattn_decode_item), sizeof(vattn_prefill_item));return 0;}\n' % ROOT
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", c, "-o", exe])
-        size, off_b, off_sc = [int(x) for x in subprocess.check_output([exe]).decode().split()]
+        size, off_b, off_sc, off_si, off_pf, off_pr, sz_di, sz_pi = [int(x) for x in subprocess.check_output([exe]).decode().split()]
     assert ctypes.sizeof(K.AttnParams) == size
     assert K.AttnParams.b.offset == off_b and K.AttnParams.softmax_scale.offset == off_sc
+    assert K.AttnParams.split_items.offset == off_si and K.AttnParams.pf_items.offset == off_pf and K.AttnParams.pf_part_rows.offset == off_pr
+    assert ctypes.sizeof(K.DecodeItem) == sz_di == 16 and ctypes.sizeof(K.PrefillItem) == sz_pi == 32
 
 
 def test_no_gpu_calls_fail_loudly():
