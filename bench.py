@@ -350,22 +350,42 @@ def main():
     extras = {}
     if world == 1 and valid and not a.no_dynamic:
         torch.cuda.synchronize()
-        runner.stats.__init__()
-        t1 = time.perf_counter()
-        runner.run_static_trace(50, w["ctx"], w["pd"], None)        # the whole 50-request trace: 16 + 16 + 16 + 2
-        torch.cuda.synchronize()
-        dt_f = time.perf_counter() - t1
-        tk_f = runner.stats.prefill_tokens + runner.stats.decode_tokens
-        extras["full_trace_50req"] = {"requests": 50, "tokens": tk_f, "seconds": round(dt_f, 3), "tokens_per_s": round(tk_f / dt_f, 1)}
-        runner.close()
+        try:
+            runner.stats.__init__()
+            t1 = time.perf_counter()
+            runner.run_static_trace(50, w["ctx"], w["pd"], None)        # the whole 50-request trace: 16 + 16 + 16 + 2
+            torch.cuda.synchronize()
+            dt_f = time.perf_counter() - t1
+            tk_f = runner.stats.prefill_tokens + runner.stats.decode_tokens
+            extras["full_trace_50req"] = {"requests": 50, "tokens": tk_f, "seconds": round(dt_f, 3), "tokens_per_s": round(tk_f / dt_f, 1)}
+        except Exception as e:      # noqa: BLE001
+            extras["full_trace_50req"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            runner.close()
+        except Exception:      # noqa: BLE001
+            pass
         runner = None
-        extras["dynamic"] = dynamic_leg(make_runner, mem_for_kv, lengths256, "llama-3-8b", 1, "configs[2] shape: llama-3-8b TP=1, 32 layers",
-                                        None, dtype, not a.no_cpu_baseline)
-        extras["dynamic_tp8_rank"] = dynamic_leg(make_runner, mem_for_kv, cap(lengths256, 768), "llama-3-70b", 8,
-                                                 "one TP=8 rank of configs[4]: llama-3-70b, 8/1 heads, 80 layers (40 KB of KV per token: 256 sequences "
-                                                 "fit at full depth); decode lengths capped at 768", True, dtype, False)
-        extras["open_loop"] = open_loop_leg(make_runner, mem_for_kv, lengths256, 6.0, 256)
-        extras["capacity"] = capacity_leg(dev, mem_for_kv)
+        # every leg on its own: a failure in one of them is reported in its place and never costs the bench line
+        def leg(name, fn, *args):
+            try:
+                extras[name] = fn(*args)
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                try:
+                    vattention.cleanup()
+                except Exception:      # noqa: BLE001
+                    pass
+                torch.cuda.synchronize()
+
+        leg("dynamic", dynamic_leg, make_runner, mem_for_kv, lengths256, "llama-3-8b", 1, "configs[2] shape: llama-3-8b TP=1, 32 layers",
+            None, dtype, not a.no_cpu_baseline)
+        leg("dynamic_tp8_rank", dynamic_leg, make_runner, mem_for_kv, cap(lengths256, 768), "llama-3-70b", 8,
+            "one TP=8 rank of configs[4]: llama-3-70b, 8/1 heads, 80 layers (40 KB of KV per token: 256 sequences fit at full depth); decode "
+            "lengths capped at 768", True, dtype, False)
+        leg("open_loop", open_loop_leg, make_runner, mem_for_kv, lengths256, 6.0, 256)
+        leg("capacity", capacity_leg, dev, mem_for_kv)
 
     if rank == 0:
         out = {
@@ -412,8 +432,11 @@ def main():
         if not a.no_cpu_baseline:
             # after the timed region and after the ranks have parted: the oracle on this workload's per-rank shape, host cores only
             keys = min(w["ctx"], 32768) if w["mode"] == "dynamic" else w["ctx"] - math.ceil(w["ctx"] / (1 + w["pd"]))
-            out["cpu_baseline"] = cpu_baseline(dtype, L, Hq, Hkv, D, keys, shard_of, tokens, pairs["pf"], pairs["dc"],
-                                               "configs[%d]" % {1: 1, 2: 3, 4: 3, 8: 4}[shard_of])
+            try:
+                out["cpu_baseline"] = cpu_baseline(dtype, L, Hq, Hkv, D, keys, shard_of, tokens, pairs["pf"], pairs["dc"],
+                                                   "configs[%d]" % {1: 1, 2: 3, 4: 3, 8: 4}[shard_of])
+            except Exception as e:      # noqa: BLE001  (the line is printed either way)
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
 
 

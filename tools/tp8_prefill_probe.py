@@ -14,6 +14,8 @@ from vattention_amd.flash_attn import flash_attn_varlen_with_kvcache, flash_attn
 
 DEV = torch.device("cuda:0")
 Hq, Hkv, D = 8, 1, 128
+if len(sys.argv) > 2:        # other head shapes: python tools/tp8_prefill_probe.py 32 8  (Llama-3-8B)
+    Hq, Hkv = int(sys.argv[1]), int(sys.argv[2])
 
 
 def timeit(fn, iters=10):
@@ -47,7 +49,7 @@ def main():
     v = torch.randn(1, n, Hkv, D, device=DEV, dtype=torch.float16)
     cl = torch.tensor([n], dtype=torch.int32, device=DEV)
     t_big = timeit(lambda: flash_attn_with_kvcache(q, k, v, cache_seqlens=cl, causal=True, _max_seqlen_k=n), 5)
-    steps_big = 8 * sum(4 * (qb + 1) for qb in range((n + 255) // 256)) / 256.0
+    steps_big = Hq * sum(4 * (qb + 1) for qb in range((n + 255) // 256)) / 256.0
     us_per_step = t_big * 1e3 / steps_big
     print("29092-token prompt alone: %.3f ms = %.0f TFLOP/s; %.1f tile steps per CU -> %.2f us per step" % (
         t_big, 4.0 * Hq * D * n * (n + 1) / 2 / t_big / 1e9, steps_big, us_per_step))
@@ -84,7 +86,7 @@ def main():
             singles.append(timeit(lambda: flash_attn_with_kvcache(qi, kc[i:i + 1], vc[i:i + 1], cache_seqlens=cli, causal=True, out=oi, _max_seqlen_k=nn)))
             t_single += singles[-1]
             tok += nn
-        W = sum(8 * sum(4 * (qb + 1) for qb in range((x + 255) // 256)) for x in lens)
+        W = sum(Hq * sum(4 * (qb + 1) for qb in range((x + 255) // 256)) for x in lens)
         longest = max(4 * ((x + 255) // 256) for x in lens)
         model = max(W / 256.0, longest) * us_per_step / 1e3
         fl = sum(4.0 * Hq * D * x * (x + 1) / 2 for x in lens)
