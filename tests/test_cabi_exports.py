@@ -294,7 +294,7 @@ def test_product_library_holds_no_measurement_scaffolding():
     assert "VATTN_PREFILL64_BUILD" not in strings
     # which variants need the lab library
     assert not K.needs_lab(0) and not K.needs_lab(14) and not K.needs_lab(8) and not K.needs_lab(2 | 64)
-    for v in (1, 4, 12, 16, 270, 526, 2574, 512, 1024, 16384, 32768, 65536, 131072, 262144):
+    for v in (1, 4, 12, 16, 782, 526, 512, 1024, 16384, 32768, 65536, 131072, 262144):
         assert K.needs_lab(v), v
 
 

@@ -33,7 +33,7 @@ def test_standalone_rotary_kernel_is_bit_exact(dtype):
         assert torch.equal(qg.cpu(), q) and torch.equal(kg.cpu(), k), "neox=%s" % neox
 
 
-@pytest.mark.parametrize("variant", [0, 14, 2574], ids=["w8", "dma64", "dma64_dot2_kpad"])
+@pytest.mark.parametrize("variant", [0, 14, 782], ids=["w8", "dma64", "dma64_xor_image"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 def test_fused_rope_prefill_chunks_and_decode(dtype, variant):
     """Chunked prefill (cache_flat_rope + in-kernel q rotation) then decode steps (q and the appended k rotated in-kernel), slot

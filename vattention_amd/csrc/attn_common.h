@@ -75,6 +75,16 @@ __device__ __forceinline__ float swap_halves(float v) {
     return __builtin_bit_cast(float, other);
 }
 
+// max over the two half-waves, in every lane: both outputs of the swap already hold (lo, lo) and (hi, hi) — no select, and an asm
+// v_max so that the compiler does not canonicalise the operands first (two extra v_max x, x per call on MFMA outputs)
+__device__ __forceinline__ float max_halves(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    return m;
+}
+
 // Bounds-checked 16-byte loads through a buffer descriptor: a lane whose byte offset lies at or beyond
 // `bytes` gets zeros WITHOUT touching memory, so rows past the sequence's visible length (possibly on
 // unmapped virtual pages) are never accessed, and the load stream is branch-free (counted vmcnt waits).

@@ -39,17 +39,24 @@ __device__ __forceinline__ void dma_piece(unsigned lds_addr, u32x4 rsrc, unsigne
 __device__ __forceinline__ void dma_piece_first(unsigned lds_addr, u32x4 rsrc, unsigned voff) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(lds_addr), "s"(rsrc), "v"(voff) : "memory", "m0");
 }
-// descriptor from a running (wave-uniform) base pointer and remaining-row count: scalar min/max (the compiler's own clamp is a VALU
-// v_med3 + readfirstlane round trip)
-__device__ __forceinline__ u32x4 running_rsrc(unsigned long long ptr, int rem_rows, unsigned row_bytes) {
-    int r;
-    asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, 64" : "=s"(r) : "s"(rem_rows) : "scc");
-    u32x4 d;
-    d[0] = (unsigned)ptr;
-    d[1] = (unsigned)(ptr >> 32) & 0xffffu;
-    d[2] = (unsigned)r * row_bytes;
-    d[3] = 0x00020000u;
-    return d;
+// the same with the piece's LDS address formed in M0 by one SALU add (base register + literal): steady-state form, the descriptor's
+// SGPRs are SALU-written (no VALU -> SGPR -> VMEM hazard, no s_nop 4)
+template <int OFF> __device__ __forceinline__ void dma_piece_at(unsigned lds_base, u32x4 rsrc, unsigned voff) {
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(lds_base), "s"(rsrc), "v"(voff), "i"(OFF) : "memory", "m0", "scc");
+}
+// The two running buffer descriptors of the steady state live in FIXED scalar registers — K(t+3)'s in s[92:95], V(t+2)'s in s[96:99] —
+// so that moving one a tile forward is four SALU instructions on its own words (base += tile bytes with carry; bytes left -= tile
+// bytes, saturating at 0: s_sub_u32 sets SCC on borrow) and the DMA reads the quad where it is: no copies into an aligned tuple, no
+// second set of registers (the kernel sits at the SGPR limit; an SGPR spill costs a scratch access whose wait count the hand-counted
+// DMA waits do not know).  Past the sequence's end nothing is fetched; a lane only addresses rows 0..63 behind the base, so the bound
+// need not be capped at the tile's end.  The caller places the call inside an MFMA gap.
+__device__ __forceinline__ void k_rsrc_advance(u32x4& r, unsigned tile_bytes) {
+    asm volatile("s_add_u32 s92, s92, %2\n\ts_addc_u32 s93, s93, 0\n\ts_sub_u32 s94, s94, %2\n\ts_cselect_b32 s94, 0, s94"
+                 : "={s[92:95]}"(r) : "0"(r), "s"(tile_bytes) : "scc");
+}
+__device__ __forceinline__ void v_rsrc_advance(u32x4& r, unsigned tile_bytes) {
+    asm volatile("s_add_u32 s96, s96, %2\n\ts_addc_u32 s97, s97, 0\n\ts_sub_u32 s98, s98, %2\n\ts_cselect_b32 s98, 0, s98"
+                 : "={s[96:99]}"(r) : "0"(r), "s"(tile_bytes) : "scc");
 }
 __device__ __forceinline__ u32x4 tile_rsrc(const void* base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -78,6 +85,14 @@ template <typename T> struct Mfma;
         static __device__ __forceinline__ void qk_acc(f32x16& d, V8 a, V8 b) {                                                     \
             asm volatile(MNEM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));                                                       \
         }                                                                                                                          \
+        /* the same with the A fragment in the accumulator half (fragments carried from one tile step to the next are read from LDS  \
+           straight into accumulator registers: no v_accvgpr_read at the seam) */                                                   \
+        static __device__ __forceinline__ void qk_first_a(f32x16& d, V8 a, V8 b) {                                                 \
+            asm volatile(MNEM " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));                                                       \
+        }                                                                                                                          \
+        static __device__ __forceinline__ void qk_acc_a(f32x16& d, V8 a, V8 b) {                                                   \
+            asm volatile(MNEM " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));                                                       \
+        }                                                                                                                          \
         /* O(agpr) += A(vgpr) x B(vgpr) */                                                                                         \
         static __device__ __forceinline__ void pv(f32x16& o, V8 a, V8 b) {                                                         \
             asm volatile(MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                                       \
@@ -85,21 +100,9 @@ template <typename T> struct Mfma;
         static __device__ __forceinline__ void pv_nop(f32x16& o, V8 a, V8 b) {                                                     \
             asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                         \
         }                                                                                                                          \
-        /* l += p.lo + p.hi for a packed pair of probabilities (f32 accumulate) */                                                 \
-        static __device__ __forceinline__ void dot2_ones(float& l, unsigned packed) {                                              \
-            asm("v_dot2c_f32_" SUFFIX " %0, %1, %2" : "+v"(l) : "s"(ONES), "v"(packed));                                           \
-        }                                                                                                                          \
     };
-#define SUFFIX "f16"
-#define ONES 0x3c003c00u
 VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16")
-#undef SUFFIX
-#undef ONES
-#define SUFFIX "bf16"
-#define ONES 0x3f803f80u
 VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16")
-#undef SUFFIX
-#undef ONES
 #undef VATTN_MFMA_STRUCT
 // one scalar f32 add that the SLP vectoriser cannot pack into v_pk_add_f32 (packed f32 VALU beside MFMAs costs more than two
 // plain adds, MI355X_MICROARCH "price of one filler")
@@ -114,8 +117,9 @@ __device__ __forceinline__ float add1(float a, float b) {
 
 // ABL bits 0-5: timing ablations for tools/kbench.py (results are WRONG when any is set): bit 0 no LDS-DMA in the steady state,
 // bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the first MFMAs of
-// a phase, bit 5 no f16 packing.  Bits 6-7 select correct alternatives: bit 6 row sums by v_dot2c over the packed P, bit 7 the
-// padded K image (the product instantiates ABL = 128).
+// a phase, bit 5 no f16 packing.  Bit 7 selects the padded K image (the product instantiates ABL = 128; 0 = round 2's XOR-swizzled
+// image, lab).  [Round 2's bit 6 — row sums by v_dot2c over the packed P — measured +-0 (the dot instructions serialise with the
+// MFMA pipe, profiles/r02_issue_probe.txt, r02_prefill64_ablations.md) and was removed in round 3.]
 // NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
 // (RING - 1 fragments ahead of their MFMA).
 template <typename T, int ABL, int NA, int RING>
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     constexpr int KPIECE = KP ? 1088 : 1024;
     constexpr int KSLOT = KP ? 16 * 1088 : S::kTileBytes;
     constexpr int VBASE = KP ? 36864 : 2 * S::kTileBytes;
+    constexpr int MS = 4;              // first phase-B group of the row-max chain of S'(t+1)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     };
     auto dma_v_all = [&](int t) {
         const u32x4 r = v_rsrc(t);
-        const unsigned l0 = v_lds_wave + (unsigned)((t % 3) * S::kTileBytes);
+        const unsigned l0 = v_lds_wave + (unsigned)(((t - tb) % 3) * S::kTileBytes);      // prologue only: V(tb) -> slot 0, V(tb+1) -> slot 1
         dma_piece_first(l0, r, voff[0]);
         dma_piece(l0 + 1024, r, voff[1]);
         dma_piece(l0 + 2048, r, voff[2]);
@@ -329,10 +334,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 }
         }
     };
-    auto needs_mask = [&](int tt) -> bool {
-        const int n0 = tt * PF_BN;
-        return (n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off));
-    };
+    // tile tt needs masking (ragged end of the sequence / causal diagonal of this wave's rows) iff tt >= t_mask:
+    // 64 tt + 64 > Lk  <=>  tt >= Lk >> 6;   64 tt + 63 > qw0 + off  <=>  tt >= ((qw0 + off - 63) >> 6) + 1 (arithmetic shift)
+    const int t_mask = min(Lk >> 6, causal ? ((qw0 + off - 63) >> 6) + 1 : 0x7fffffff);
+    auto needs_mask = [&](int tt) -> bool { return tt >= t_mask; };
     auto row_max = [&](const f32x16 (&s)[2][2], int qc) -> float {
         float m0 = fmaxf(s[0][qc][0], s[1][qc][0]);
 #pragma unroll
@@ -344,7 +349,6 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     auto raise_max = [&](int qc, float delta) {
         const float alpha = fast_exp2(-delta);
         nmsub[qc] -= delta;
-        if (ABL & 64) asm volatile("s_nop 3" ::: "memory");      // v_dot2c result -> a different VALU opcode: 3 wait states, not interlocked
 #pragma unroll
         for (int i = 0; i < DB; i++)
 #pragma unroll
@@ -357,13 +361,6 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         V8 r;
 #pragma unroll
         for (int j = 0; j < 8; j++) r[j] = X::cvt(pt[ks >> 1][qc][8 * (ks & 1) + j]);
-        if (ABL & 64) {
-            // row sums from the PACKED probabilities: one v_dot2c (p.lo * 1 + p.hi * 1 + l, f32 accumulate) per two scores
-            // instead of two v_add — the sum then is over exactly the values the P.V product uses
-            const u32x4 w = __builtin_bit_cast(u32x4, r);
-#pragma unroll
-            for (int j = 0; j < 4; j++) M::dot2_ones(l_acc[qc][j & 1], w[j]);
-        }
         return r;
     };
 
@@ -409,15 +406,26 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             if (GE(e) - 1 == G)
                 asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale), "v"(nmsub[qc]));
             if (GE(e) == G) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
-            if (GE(e) + 1 == G && !(ABL & 64))      // (v_pk_add_f32 was tried: forming the register pairs costs more moves than the adds it saves)
+            if (GE(e) + 1 == G)      // (v_pk_add_f32 was tried: forming the register pairs costs more moves than the adds it saves)
                 asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][0]), "+v"(l_acc[qc][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
         }
     };
 
-    const unsigned long long k_tile_bytes = (unsigned long long)PF_BN * k_rs_bytes, v_tile_bytes = (unsigned long long)PF_BN * v_rs_bytes;
-    unsigned long long k_next_ptr = (unsigned long long)kbase + (unsigned long long)(tb + 3) * k_tile_bytes;
-    unsigned long long v_next_ptr = (unsigned long long)vbase + (unsigned long long)(tb + 2) * v_tile_bytes;
-    int k_next_rem = Lk - (tb + 3) * PF_BN, v_next_rem = Lk - (tb + 2) * PF_BN;
+    // ---- the DMA stream's scalars, carried across the tile steps and advanced INSIDE MFMA gaps: a lone wave pays an issue slot for
+    // every SALU instruction, and whatever sits between the last MFMA of a step and the first of the next is not hidden at all ----
+    // rk / rv: descriptors of K(t+2) / V(t+1) at step entry (base, bytes left from the base on); phase B moves them one tile on and
+    // fetches K(t+3) / V(t+2) through them
+    const unsigned k_tile_b = (unsigned)PF_BN * k_rs_bytes, v_tile_b = (unsigned)PF_BN * v_rs_bytes;
+    auto bytes_left = [&](int tile, unsigned rs) -> unsigned {
+        const int rem = Lk - tile * PF_BN;
+        return rem <= 0 ? 0u : (unsigned)rem * rs;      // seqlen_k x row bytes < 2^32: checked on the host (attn_api.hip)
+    };
+    const unsigned long long kp0 = (unsigned long long)kbase + (unsigned long long)(tb + 2) * k_tile_b;
+    const unsigned long long vp0 = (unsigned long long)vbase + (unsigned long long)(tb + 1) * v_tile_b;
+    u32x4 rk = {(unsigned)kp0, (unsigned)(kp0 >> 32) & 0xffffu, bytes_left(tb + 2, k_rs_bytes), 0x00020000u};
+    u32x4 rv = {(unsigned)vp0, (unsigned)(vp0 >> 32) & 0xffffu, bytes_left(tb + 1, v_rs_bytes), 0x00020000u};
+    // byte offsets inside the V ring of V(t)'s slot and of the slot V(t+2) goes to (= the one V(t-1) left): slots go by (t - tb) % 3
+    unsigned vs_cur = 0, vs_dma = 2 * S::kTileBytes;
     // One tile step of the wave.  cur holds S(t) on entry and P(t) afterwards, nxt receives S(t+1); kf0 / kf1 hold the first two
     // K(t+1) fragments on entry (read before the previous step ended) and the first two of K(t+2) on exit.
     // Invariants at entry: K(t+1) and V(t) have landed and every wave knows it (the barrier of step t-1); K(t+2) and V(t+1) are
@@ -429,17 +437,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         const int s_cur = KP ? par : (t & 1);                                   // slot of K(t), K(t+2)
         const char* ksm = smem + (s_cur ^ 1) * KSLOT;                           // K(t+1)
         const char* ksm_next = smem + s_cur * KSLOT;                            // K(t+2)
-        const char* vsm = smem + VBASE + (t % 3) * S::kTileBytes;
-        // descriptors of K(t+3) and V(t+2): running base pointers and remaining-row counts, advanced one tile per step with a handful
-        // of SALU instructions (past the last tile the row count clamps to 0: nothing is fetched)
-        const u32x4 rk = running_rsrc(k_next_ptr, k_next_rem, k_rs_bytes);
-        const u32x4 rv = running_rsrc(v_next_ptr, v_next_rem, v_rs_bytes);
-        k_next_ptr += k_tile_bytes;
-        v_next_ptr += v_tile_bytes;
-        k_next_rem -= PF_BN;
-        v_next_rem -= PF_BN;
+        const char* vsm = smem + VBASE + vs_cur;                                // V(t)
         const unsigned lk0 = k_lds_wave + (unsigned)((s_cur ^ 1) * KSLOT);      // K(t+3) -> the slot K(t+1) leaves
-        const unsigned lv0 = v_lds_wave + (unsigned)(((t + 2) % 3) * S::kTileBytes);
+        unsigned lv0 = 0;                                                       // V(t+2)'s pieces of this wave (set in phase B)
+        const bool mask_next = needs_mask(t + 1);                               // ragged end / causal diagonal: wave-uniform, the last tiles only
         // Every wave runs the SAME straight-line body for every tile of the workgroup (the barrier makes the waves wait for each other
         // anyway): a tile that lies wholly beyond a wave's causal limit is masked to -inf, contributes P = 0, and leaves the running
         // maximum alone; past the last tile S'(t+1) is computed from a zero-filled K slot and never used.
@@ -447,14 +448,16 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         // phase A: S'(t+1) = K(t+1).Q^T - m   (32 MFMAs: k-step kk = i>>2, key block (i>>1)&1, query block i&1)
         V8 pf[2][2];         // P(t) fragments of the key slice being multiplied and of the next one
         V8 kf[RING];         // RING - 1 fragments (twice as many MFMAs) ahead of their use
-        kf[0] = kf0;
-        kf[1] = kf1;
-        if (RING > 3) kf[2] = kf2;
         SCHED_FENCE();
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const int f = i >> 1, qc = i & 1;
-            if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
+            if (f < RING - 1) {
+                // the fragments read before the previous step ended sit in accumulator registers
+                const V8 a = f == 0 ? kf0 : (f == 1 ? kf1 : kf2);
+                if (i < 4) M::qk_first_a(nxt[f & 1][qc], a, qf[qc][f >> 1]);
+                else M::qk_acc_a(nxt[f & 1][qc], a, qf[qc][f >> 1]);
+            } else if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
             else M::qk_acc(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
             if ((i & 1) == 0 && f + RING - 1 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + RING - 1) % RING] = kfrag(ksm, f + RING - 1);
             softmax_stages(i, cur);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             pf[0][0] = pack_p(cur, 0, 0);
             pf[0][1] = pack_p(cur, 0, 1);
         }
-        float mx0 = -INFINITY, mx1 = -INFINITY;
+        float mx0 = -INFINITY, mx1 = -INFINITY, g0 = -INFINITY, g1 = -INFINITY, grow = -INFINITY;
         SCHED_FENCE();
 #pragma unroll
         for (int j = 0; j < 32; j++) {
@@ -486,7 +489,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if ((j & 7) < 2) M::pv_nop(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);      // first use of a freshly packed P fragment
+            // (a P fragment is packed at least one MFMA group before its first use: no VALU -> MFMA operand hazard to pad)
+            if (NA < 16 && j < 2) M::pv_nop(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
             else M::pv(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
             if ((j & 1) == 0 && f + RING - 1 < 16 && !((ABL & 16) && f >= 1)) vf[(f + RING - 1) % RING] = vfrag(vsm, f + RING - 1);
             softmax_stages(32 + j, cur);
@@ -495,37 +499,51 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
                 if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
             }
-            // row max of S'(t+1): 2 chains x 16 v_max3, groups 8..23 (>= 8 MFMAs after the last S^T MFMA was issued)
-            if (!(ABL & 4) && j >= 8 && j < 24) {
-                const int r = j - 8;
-                mx0 = fmaxf(fmaxf(mx0, nxt[0][0][r]), nxt[1][0][r]);
-                mx1 = fmaxf(fmaxf(mx1, nxt[0][1][r]), nxt[1][1][r]);
+            // row max of S'(t+1): 2 chains x 16 v_max3, groups MS .. MS+15 (>= 4 MFMAs after the last S^T MFMA was issued); the
+            // half-wave exchange and the growth test follow in the next gaps, so that only the branch itself is left behind the
+            // step's last MFMA
+            if (!(ABL & 4) && j >= MS && j < MS + 16) {
+                const int r = j - MS;
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx0) : "v"(nxt[0][0][r]), "v"(nxt[1][0][r]));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx1) : "v"(nxt[0][1][r]), "v"(nxt[1][1][r]));
             }
+            if (j == MS + 16) mx0 = max_halves(mx0);
+            if (j == MS + 17) mx1 = max_halves(mx1);
+            if (j == MS + 18) {
+                // growth of the row maxima over the running maxima, log2 units (nmsub = -m*scale*log2e; -inf for rows that see nothing here)
+                asm("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(g0), "=&v"(g1) : "v"(mx0), "v"(mx1), "s"(escale), "v"(nmsub[0]), "v"(nmsub[1]));
+            }
+            if (j == MS + 19) asm("v_max_f32 %0, %1, %2" : "=v"(grow) : "v"(g0), "v"(g1));
+            // the DMA stream's scalars move one tile on (SALU work, inside gaps)
+            if (j == 9) lv0 = v_lds_wave + vs_dma;
+            if (j == 11) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
+                                      : "+s"(vs_cur), "=&s"(vs_dma) : "i"(S::kTileBytes), "i"(3 * S::kTileBytes) : "scc");
+            if (j == 13) k_rsrc_advance(rk, k_tile_b);
+            if (j == 15) v_rsrc_advance(rv, v_tile_b);
             if (!(ABL & 1)) {
-                if (j == 24) dma_piece_first(lk0, rk, koff[0]);
-                if (j == 25) dma_piece(lk0 + KPIECE, rk, koff[1]);
-                if (j == 26) dma_piece(lk0 + 2 * KPIECE, rk, koff[2]);
-                if (j == 27) dma_piece(lk0 + 3 * KPIECE, rk, koff[3]);
-                if (j == 28) dma_piece_first(lv0, rv, voff[0]);
-                if (j == 29) dma_piece(lv0 + 1024, rv, voff[1]);
-                if (j == 30) dma_piece(lv0 + 2048, rv, voff[2]);
-                if (j == 31) dma_piece(lv0 + 3072, rv, voff[3]);
+                if (j == 24) dma_piece_at<0>(lk0, rk, koff[0]);
+                if (j == 25) dma_piece_at<KPIECE>(lk0, rk, koff[1]);
+                if (j == 26) dma_piece_at<2 * KPIECE>(lk0, rk, koff[2]);
+                if (j == 27) dma_piece_at<3 * KPIECE>(lk0, rk, koff[3]);
+                if (j == 28) dma_piece_at<0>(lv0, rv, voff[0]);
+                if (j == 29) dma_piece_at<1024>(lv0, rv, voff[1]);
+                if (j == 30) dma_piece_at<2048>(lv0, rv, voff[2]);
+                if (j == 31) dma_piece_at<3072>(lv0, rv, voff[3]);
             }
             if (j == 27) kf0 = kfrag(ksm_next, 0);          // the next step's first K fragments: K(t+2) is behind the barrier
             if (j == 28) kf1 = kfrag(ksm_next, 1);
             if (j == 29 && RING > 3) kf2 = kfrag(ksm_next, 2);
             SCHED_FENCE();
         }
-        mx0 = fmaxf(mx0, swap_halves(mx0));
-        mx1 = fmaxf(mx1, swap_halves(mx1));
-        if (needs_mask(t + 1)) {                     // ragged end / causal diagonal: wave-uniform, the last tiles only
+        if (mask_next) {
             mask_tile(t + 1, nxt);
             mx0 = row_max(nxt, 0);
             mx1 = row_max(nxt, 1);
+            g0 = __builtin_fmaf(mx0, escale, nmsub[0]);
+            g1 = __builtin_fmaf(mx1, escale, nmsub[1]);
+            grow = fmaxf(g0, g1);
         }
-        // growth of the row maxima over the running maxima, log2 units (nmsub = -m*scale*log2e; -inf for rows that see nothing here)
-        const float g0 = __builtin_fmaf(mx0, escale, nmsub[0]), g1 = __builtin_fmaf(mx1, escale, nmsub[1]);
-        if (__builtin_amdgcn_ballot_w64(fmaxf(g0, g1) > kDeferLog2) != 0) {          // rare: a row's maximum grew by > 2^6
+        if (__builtin_amdgcn_ballot_w64(grow > kDeferLog2) != 0) {          // rare: a row's maximum grew by > 2^6
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");                        // every PV result has landed in O
             SCHED_FENCE();
             raise_max(0, fmaxf(g0, 0.f));
@@ -654,18 +672,15 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
 }
 
 // Product: ONE build per dtype (padded K image, 24 exp2 pairs in phase A, fragment ring of 4).  The lab library (-DVATTN_LAB) adds the
-// schedule variants and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 1, 3, 10 = correct alternatives;
+// K-image alternative and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 3 = correct alternative;
 // 4-9 = ablations whose RESULTS ARE WRONG).
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
 #ifdef VATTN_LAB
     const int sel = (p->variant >> 8) & 15;
     if (p->dtype == VATTN_DTYPE_BF16) {
-        if (sel == 1) return launch64_t<__bf16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode);
         if (sel == 3) return launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done, merge_mode);
     } else {
         switch (sel) {
-            case 1: case 10: return launch64_t<_Float16, 64 | 128, 24, 4>(p, st, nsplit, done, merge_mode);   // row sums by v_dot2c over the packed P (no
-                                                                     // gain: the dot instructions serialise with the MFMA pipe, profiles/r02_issue_probe.txt)
             case 3: return launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done, merge_mode);                    // XOR-swizzled K image (round 2's first layout)
             case 4: return launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no LDS-DMA in the steady state
             case 5: return launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no fma / exp2 / row sums
