@@ -44,6 +44,12 @@ __device__ __forceinline__ void dma_piece_first(unsigned lds_addr, u32x4 rsrc, u
 template <int OFF> __device__ __forceinline__ void dma_piece_at(unsigned lds_base, u32x4 rsrc, unsigned voff) {
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(lds_base), "s"(rsrc), "v"(voff), "i"(OFF) : "memory", "m0", "scc");
 }
+// base + ROWS x row_bytes per lane (row strides are far below 2^24 bytes)
+template <int ROWS> __device__ __forceinline__ unsigned piece_off(unsigned base, unsigned row_bytes) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %3, %2" : "=v"(r) : "s"(row_bytes), "v"(base), "n"(ROWS));
+    return r;
+}
 // The two running buffer descriptors of the steady state live in FIXED scalar registers — K(t+3)'s in s[92:95], V(t+2)'s in s[96:99] —
 // so that moving one a tile forward is four SALU instructions on its own words (base += tile bytes with carry; bytes left -= tile
 // bytes, saturating at 0: s_sub_u32 sets SCC on borrow) and the DMA reads the quad where it is: no copies into an aligned tuple, no
@@ -122,7 +128,7 @@ __device__ __forceinline__ float add1(float a, float b) {
 // MFMA pipe, profiles/r02_issue_probe.txt, r02_prefill64_ablations.md) and was removed in round 3.]
 // NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
 // (RING - 1 fragments ahead of their MFMA).
-template <typename T, int ABL, int NA, int RING>
+template <typename T, int ABL, int NA, int RING, int MS = 4, int BJ = 8, int D0 = 9, int DS = 3>
 __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done, int merge_mode) {
     using X = Tr<T>;
     using V8 = typename X::v8;
@@ -143,7 +149,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     constexpr int KPIECE = KP ? 1088 : 1024;
     constexpr int KSLOT = KP ? 16 * 1088 : S::kTileBytes;
     constexpr int VBASE = KP ? 36864 : 2 * S::kTileBytes;
-    constexpr int MS = 4;              // first phase-B group of the row-max chain of S'(t+1)
+    // MS: first phase-B group of the row-max chain of S'(t+1).  BJ: the phase-B group that opens with the per-tile wait + barrier; the
+    // eight DMA pieces go out in groups D0, D0 + DS, ... (all >= BJ).
+    static_assert(D0 >= BJ && D0 + 7 * DS < 32, "DMA pieces behind the barrier, inside phase B");
+    auto dma_gap = [](int k) { return D0 + DS * k; };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -429,9 +438,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // One tile step of the wave.  cur holds S(t) on entry and P(t) afterwards, nxt receives S(t+1); kf0 / kf1 hold the first two
     // K(t+1) fragments on entry (read before the previous step ended) and the first two of K(t+2) on exit.
     // Invariants at entry: K(t+1) and V(t) have landed and every wave knows it (the barrier of step t-1); K(t+2) and V(t+1) are
-    // in flight.  The barrier of this step sits in phase B after group 23: by then every wave has finished reading K(t+1)
-    // (phase A) and V(t-1) (step t-1), so K(t+3) -> slot of K(t+1) and V(t+2) -> slot of V(t-1) are issued right behind it, one
-    // piece per group in the eight groups that carry no softmax work.
+    // in flight.  The barrier of this step opens phase-B group BJ: by then every wave has finished reading K(t+1) (phase A) and V(t-1)
+    // (step t-1), so K(t+3) -> slot of K(t+1) and V(t+2) -> slot of V(t-1) may be issued behind it — one piece every DS-th group from
+    // group D0 on (back-to-back pieces in the barrier's own group and the seven after it, round 2's placement, measured 1-2 % slower on
+    // boxes that are not pinned at their power limit: profiles/r03_p64_schedules.txt).
     auto step = [&](int t, const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2) {
         // par = (t - tb) & 1, a literal at both call sites: with the padded K layout every K fragment address folds to lane + immediate
         const int s_cur = KP ? par : (t & 1);                                   // slot of K(t), K(t+2)
@@ -467,6 +477,12 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 if (i == 13) pf[0][0] = pack_p(cur, 0, 0);
                 if (i == 15) pf[0][1] = pack_p(cur, 0, 1);
             }
+            // the DMA stream's scalars move one tile on (SALU work, inside gaps)
+            if (i == 17) lv0 = v_lds_wave + vs_dma;
+            if (i == 19) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
+                                      : "+s"(vs_cur), "=&s"(vs_dma) : "i"(S::kTileBytes), "i"(3 * S::kTileBytes) : "scc");
+            if (i == 21) k_rsrc_advance(rk, k_tile_b);
+            if (i == 23) v_rsrc_advance(rv, v_tile_b);
             SCHED_FENCE();
         }
         // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 #pragma unroll
         for (int j = 0; j < 32; j++) {
             const int f = j >> 1, ks = j >> 3, qc = j & 1;
-            if (j == 24 && !(ABL & 8)) {
+            if (j == BJ && !(ABL & 8)) {
                 // this wave's pieces of K(t+2) and V(t+1) (issued one step ago) have landed; behind the barrier everyone's have, and
                 // every wave is past its reads of K(t+1) and V(t-1)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -514,21 +530,17 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 asm("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(g0), "=&v"(g1) : "v"(mx0), "v"(mx1), "s"(escale), "v"(nmsub[0]), "v"(nmsub[1]));
             }
             if (j == MS + 19) asm("v_max_f32 %0, %1, %2" : "=v"(grow) : "v"(g0), "v"(g1));
-            // the DMA stream's scalars move one tile on (SALU work, inside gaps)
-            if (j == 9) lv0 = v_lds_wave + vs_dma;
-            if (j == 11) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
-                                      : "+s"(vs_cur), "=&s"(vs_dma) : "i"(S::kTileBytes), "i"(3 * S::kTileBytes) : "scc");
-            if (j == 13) k_rsrc_advance(rk, k_tile_b);
-            if (j == 15) v_rsrc_advance(rv, v_tile_b);
             if (!(ABL & 1)) {
-                if (j == 24) dma_piece_at<0>(lk0, rk, koff[0]);
-                if (j == 25) dma_piece_at<KPIECE>(lk0, rk, koff[1]);
-                if (j == 26) dma_piece_at<2 * KPIECE>(lk0, rk, koff[2]);
-                if (j == 27) dma_piece_at<3 * KPIECE>(lk0, rk, koff[3]);
-                if (j == 28) dma_piece_at<0>(lv0, rv, voff[0]);
-                if (j == 29) dma_piece_at<1024>(lv0, rv, voff[1]);
-                if (j == 30) dma_piece_at<2048>(lv0, rv, voff[2]);
-                if (j == 31) dma_piece_at<3072>(lv0, rv, voff[3]);
+                if (j == dma_gap(0)) dma_piece_at<0>(lk0, rk, koff[0]);
+                // piece j's per-lane offset = piece 0's + j x (4 K rows | 16 V keys): one v_mad beside the DMA instead of six more
+                // loop-invariant registers that the allocator parks in the accumulator file and reads back every tile
+                if (j == dma_gap(1)) dma_piece_at<KPIECE>(lk0, rk, KP ? piece_off<4>(koff[0], k_rs_bytes) : koff[1]);
+                if (j == dma_gap(2)) dma_piece_at<2 * KPIECE>(lk0, rk, KP ? piece_off<8>(koff[0], k_rs_bytes) : koff[2]);
+                if (j == dma_gap(3)) dma_piece_at<3 * KPIECE>(lk0, rk, KP ? piece_off<12>(koff[0], k_rs_bytes) : koff[3]);
+                if (j == dma_gap(4)) dma_piece_at<0>(lv0, rv, voff[0]);
+                if (j == dma_gap(5)) dma_piece_at<1024>(lv0, rv, piece_off<16>(voff[0], v_rs_bytes));
+                if (j == dma_gap(6)) dma_piece_at<2048>(lv0, rv, piece_off<32>(voff[0], v_rs_bytes));
+                if (j == dma_gap(7)) dma_piece_at<3072>(lv0, rv, piece_off<48>(voff[0], v_rs_bytes));
             }
             if (j == 27) kf0 = kfrag(ksm_next, 0);          // the next step's first K fragments: K(t+2) is behind the barrier
             if (j == 28) kf1 = kfrag(ksm_next, 1);
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
 constexpr int kSmem64 = 36864 + 3 * PfSmem<128>::kTileBytes;      // K ring (padded layout: 2 x 17 408, rounded up) + V ring
-template <typename T, int ABL, int NA, int RING> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
+template <typename T, int ABL, int NA, int RING, int MS = 4, int BJ = 8, int D0 = 9, int DS = 3> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -664,15 +676,15 @@ template <typename T, int ABL, int NA, int RING> static void launch64_t(const va
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64 + 16);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING, MS, BJ, D0, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64 + 16);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit, done, merge_mode);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING, MS, BJ, D0, DS>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit, done, merge_mode);
 }
 
-// Product: ONE build per dtype (padded K image, 24 exp2 pairs in phase A, fragment ring of 4).  The lab library (-DVATTN_LAB) adds the
-// K-image alternative and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 3 = correct alternative;
+// Product: ONE build per dtype (padded K image, 24 exp2 pairs in phase A, fragment ring of 4, barrier at group 8, DMA in groups 9, 12, .. 30).  The lab library (-DVATTN_LAB) adds the
+// K-image alternative and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 1-3, 11, 12 = correct alternatives;
 // 4-9 = ablations whose RESULTS ARE WRONG).
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
 #ifdef VATTN_LAB
@@ -682,6 +694,11 @@ void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, in
     } else {
         switch (sel) {
             case 3: return launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done, merge_mode);                    // XOR-swizzled K image (round 2's first layout)
+            // schedule alternatives (correct, bit-identical results; tools/p64_variants.py, profiles/r03_p64_schedules.txt)
+            case 1: return launch64_t<_Float16, 128, 20, 4, 4, 8, 9, 3>(p, st, nsplit, done, merge_mode);   // 20 exp2 pairs in phase A
+            case 2: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3>(p, st, nsplit, done, merge_mode);   // row-max chain from group 8
+            case 11: return launch64_t<_Float16, 128, 24, 4, 4, 12, 13, 2>(p, st, nsplit, done, merge_mode);  // barrier after group 11, DMA every second group
+            case 12: return launch64_t<_Float16, 128, 24, 4, 4, 24, 24, 1>(p, st, nsplit, done, merge_mode);  // round 2's placement: barrier after 23, DMA 24-31
             case 4: return launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no LDS-DMA in the steady state
             case 5: return launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no fma / exp2 / row sums
             case 6: return launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no per-tile wait + barrier
