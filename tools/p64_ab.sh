@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the prefill kernels on ONE box (clocks and boxes differ by a few percent, so both libraries are timed back to back):
 #   bash tools/p64_ab.sh [tests|notests] — parity tests with the working-tree library, then tools/kbench.py prefill with it (A), with
-#   build/base/libvattn_amd.so (B: the library of the last commit, built by hand), and A again.
+#   build/base/libvattn_amd.so (B: the library of a commit, tools/build_base.py), and A again.
 cd "$(dirname "$0")/.."
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 O=gpurun_out/ab
@@ -13,7 +13,10 @@ if [ "${1:-tests}" = "tests" ]; then
     echo "tests rc=$?" >> $O/tests.log
     tail -4 $O/tests.log
 fi
-run() { timeout 300 python tools/kbench.py prefill --variant 0 --only "$ONLY" 2>&1 | grep -v "^--\|^==\|amdgpu.ids"; }
+run() {
+    timeout 300 python tools/kbench.py prefill --variant 0 --only "$ONLY" 2>&1 | grep -v "^--\|^==\|amdgpu.ids"
+    timeout 300 python tools/kbench.py prefill --variant 14 --worklist --only "llama70b/tp8 8k,llama70b/tp8 4k,chunk512@16k,chunk2k@30k,llama70b/tp8 2k" 2>&1 | grep -v "^--\|^==\|amdgpu.ids"
+}
 echo "A (working tree)"; run | tee $O/a1.txt
 cp vattention_amd/libvattn_amd.so /tmp/new.so
 if [ -f build/base/libvattn_amd.so ]; then

@@ -247,14 +247,20 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     };
 
     // ---- prologue ----
-    // the V ring starts zeroed: a key row past the sequence's end that the DMA leaves untouched must hold finite data (its
-    // probability is exactly 0, and 0 x NaN would poison O)
-    {
+    // A key row past the sequence's end must hold FINITE data in the V image (its probability is exactly 0, and 0 x NaN would poison
+    // O).  On gfx950 the DMA writes zeros for a lane beyond the descriptor's bound (vattn_selftest_layouts [6]); the kernel does not
+    // lean on that: a workgroup whose key range reaches the sequence's ragged last tile zero-fills the V ring first.  Every other
+    // workgroup only ever multiplies rows that the DMA fetched (tiles past `nt` are computed into S' and never used) and skips the
+    // 48 KiB of LDS writes and the barrier that used to sit in front of its first fetch (1.5 % of a 32 k prompt, 2-13 % of the
+    // short pieces of tensor-parallel prompts: profiles/r03_p64_prologue_epilogue.txt).
+    if (!(ABL & 512) && nt * PF_BN > Lk) {
         const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < (3 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + VBASE + (i * 256 + tid) * 16) = z;
+        __syncthreads();
     }
-    __syncthreads();
+    // (asking for V(tb) and K(tb+1) only once Q sits in its registers — so that the wait for Q does not also wait for them — was measured:
+    // short pieces lose more on the later K(tb+1) than the first S' gains)
     dma_k_all(tb);
     dma_v_all(tb);
     dma_k_all(tb + 1);
@@ -580,6 +586,9 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 #undef P64_X1
 
     // ---- epilogue: O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
+    // (Staging the fp32 partials of a key-range piece through LDS so that every store instruction writes whole 512-byte rows instead of
+    // 32 bytes of 32 rows was built and measured in round 3: no gain — the cost of the partials (no-store ablation: 5-19 % of the
+    // tensor-parallel launches, profiles/r03_p64_prologue_epilogue.txt) is their volume, not their coalescing.)
     const float sc_ln = p.softmax_scale;
 #pragma unroll
     for (int qc = 0; qc < 2; qc++) {
@@ -588,12 +597,16 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         const float l_tot = l_loc + swap_halves(l_loc);
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
         const float m_log2 = -nmsub[qc];                      // running max of softmax_scale*log2e*q.k
-        if (my_q < Sq && partial) {
-            // KV-split: normalised fp32 partial + its log2-domain LSE; combine_rows_kernel (work list: combine_blocks_kernel) merges the
-            // partials of a row
-            const int64_t row = listed ? (int64_t)it_row + (my_q - q_wg0) : (((int64_t)split * p.b + b) * p.seqlen_q + my_q) * p.h + h;
+        // row of the partial buffer that query row q of this block goes to
+        auto part_row = [&](int q) -> int64_t {
+            return listed ? (int64_t)it_row + (q - q_wg0) : (((int64_t)split * p.b + b) * p.seqlen_q + q) * p.h + h;
+        };
+        float* lpart = (float*)p.workspace + (listed ? (int64_t)p.pf_part_rows : (int64_t)nsplit * p.b * p.seqlen_q * p.h) * HD;
+        if (ABL & 256) {
+            if (l_tot == 12345.f) ((float*)p.workspace)[lane] = o[0][qc][0] * inv;      // ablation: no epilogue stores
+        } else if (my_q < Sq && partial) {
+            const int64_t row = part_row(my_q);
             float* opart = (float*)p.workspace + row * HD;
-            float* lpart = (float*)p.workspace + (listed ? (int64_t)p.pf_part_rows : (int64_t)nsplit * p.b * p.seqlen_q * p.h) * HD;
 #pragma unroll
             for (int db = 0; db < DB; db++)
 #pragma unroll
@@ -699,6 +712,8 @@ void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, in
             case 2: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3>(p, st, nsplit, done, merge_mode);   // row-max chain from group 8
             case 11: return launch64_t<_Float16, 128, 24, 4, 4, 12, 13, 2>(p, st, nsplit, done, merge_mode);  // barrier after group 11, DMA every second group
             case 12: return launch64_t<_Float16, 128, 24, 4, 4, 24, 24, 1>(p, st, nsplit, done, merge_mode);  // round 2's placement: barrier after 23, DMA 24-31
+            case 10: return launch64_t<_Float16, 256 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no epilogue stores
+            case 13: return launch64_t<_Float16, 512 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no zero-fill of the V ring
             case 4: return launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no LDS-DMA in the steady state
             case 5: return launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no fma / exp2 / row sums
             case 6: return launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no per-tile wait + barrier
