@@ -243,3 +243,29 @@ def test_llama8b_varlen_prefill_4_prompts_over_megacache_views_vs_oracle():
             tok += n
     finally:
         va.cleanup()
+
+
+def test_prefill_chunk_over_a_layer_view_that_spans_more_than_4_gib_vs_oracle():
+    """A layer's view k[:, :, l] of a megacache tensor [slots, tokens, layers, heads, d] has rows of layers x heads x 256 bytes: at
+    64 KiB per row 70 000 tokens span 4.3 GiB, more than a 32-bit buffer bound holds.  The prefill kernel's running descriptors count
+    ROWS (prefill64_kernels.hip, k_rsrc_advance); this drives a 256-row chunk on a 69 744-token prefix through them, and the last
+    rows of the sequence lie beyond the 4 GiB mark."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(41)
+    L, Hkv, Hq, n, c = 32, 8, 8, 256, 69744
+    Lk = n + c
+    kmega = torch.empty(1, Lk, L, Hkv, D, dtype=torch.float16, device=DEV)
+    vmega = torch.empty(1, Lk, L, Hkv, D, dtype=torch.float16, device=DEV)
+    assert kmega.stride(1) * 2 == 64 << 10 and Lk * kmega.stride(1) * 2 > (1 << 32)
+    layer = 17
+    kmega[:, :, layer].normal_()
+    vmega[:, :, layer].normal_()
+    kv, vv = kmega[:, :, layer], vmega[:, :, layer]                      # [1, Lk, Hkv, D], row stride 64 KiB
+    q = torch.randn(1, n, Hq, D).half()
+    cl = torch.tensor([Lk], dtype=torch.int32)
+    out = flash_attn_with_kvcache(q.to(DEV), kv, vv, cache_seqlens=cl.to(DEV), causal=True)
+    torch.cuda.synchronize()
+    kc, vc = kv.cpu().contiguous(), vv.cpu().contiguous()
+    ref64 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, causal=True)
+    ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, causal=True, math="f32")
+    _check(out, ref64, ref32, "256-row chunk on a 69 744-token prefix over a 64 KiB-row view")

@@ -8,8 +8,8 @@ O=gpurun_out/ab
 mkdir -p $O
 ONLY="yi6b whole,yi6b chunk4k@28k,llama8b 16k,llama70b/tp8 8k,llama70b/tp8 chunk2k@30k"
 if [ "${1:-tests}" = "tests" ]; then
-    timeout 600 python -m pytest tests/test_gpu_attention.py tests/test_gpu_fuzz.py -m gpu -q --timeout 300 \
-        -k "prefill_chunk_parity or kv_split or variable_length or rescale or work_list or prefill64_midsize or virtual" > $O/tests.log 2>&1
+    timeout 600 python -m pytest tests/test_gpu_attention.py tests/test_gpu_fuzz.py tests/test_gpu_full_size_parity.py -m gpu -q --timeout 300 \
+        -k "prefill_chunk_parity or kv_split or variable_length or rescale or work_list or prefill64_midsize or virtual or 4_gib or sampled_blocks or megacache_views" > $O/tests.log 2>&1
     echo "tests rc=$?" >> $O/tests.log
     tail -4 $O/tests.log
 fi

@@ -233,9 +233,6 @@ int validate(const vattn_attn_params* p) {
     }
     if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
         return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
-    // the kernels bound every K/V access by a 32-bit buffer descriptor over one sequence's rows of one cache view
-    if ((uint64_t)p->seqlen_k * (uint64_t)p->k_row_stride * 2u >= (1ull << 32) || (uint64_t)p->seqlen_k * (uint64_t)p->v_row_stride * 2u >= (1ull << 32))
-        return fail(VATTN_K_ERR_UNSUPPORTED, "one sequence's rows of a cache view must span less than 4 GiB (seqlen_k x row stride)");
     if (p->pf_items && (p->seqlen_q == 1 || p->d != 128)) return fail(VATTN_K_ERR_INVALID, "pf_items (prefill work list) applies to the prefill form with head dimension 128");
     if (p->split_items && p->seqlen_q != 1) return fail(VATTN_K_ERR_INVALID, "split_items (length-balanced plan) applies to the decode form only");
     if (!kLab) {

@@ -51,18 +51,19 @@ template <int ROWS> __device__ __forceinline__ unsigned piece_off(unsigned base,
     return r;
 }
 // The two running buffer descriptors of the steady state live in FIXED scalar registers — K(t+3)'s in s[92:95], V(t+2)'s in s[96:99] —
-// so that moving one a tile forward is four SALU instructions on its own words (base += tile bytes with carry; bytes left -= tile
-// bytes, saturating at 0: s_sub_u32 sets SCC on borrow) and the DMA reads the quad where it is: no copies into an aligned tuple, no
-// second set of registers (the kernel sits at the SGPR limit; an SGPR spill costs a scratch access whose wait count the hand-counted
-// DMA waits do not know).  Past the sequence's end nothing is fetched; a lane only addresses rows 0..63 behind the base, so the bound
-// need not be capped at the tile's end.  The caller places the call inside an MFMA gap.
-__device__ __forceinline__ void k_rsrc_advance(u32x4& r, unsigned tile_bytes) {
-    asm volatile("s_add_u32 s92, s92, %2\n\ts_addc_u32 s93, s93, 0\n\ts_sub_u32 s94, s94, %2\n\ts_cselect_b32 s94, 0, s94"
-                 : "={s[92:95]}"(r) : "0"(r), "s"(tile_bytes) : "scc");
+// so that moving one a tile forward is a handful of SALU instructions on its own words and the DMA reads the quad where it is: no
+// copies into an aligned tuple, no second set of registers (the kernel sits at the SGPR limit; an SGPR spill costs a scratch access
+// whose wait count the hand-counted DMA waits do not know).  base += tile bytes (with carry); rows left behind the new base -= 64;
+// bound = clamp(rows left, 0, 64) x row bytes: past the sequence's end nothing is fetched.  Counting ROWS keeps every quantity far
+// from 32 bits whatever the row stride (a layer's view of a megacache tensor has rows of 64 KiB and spans > 4 GiB at 128 k tokens).
+// The caller places the call inside an MFMA gap.
+__device__ __forceinline__ void k_rsrc_advance(u32x4& r, int& rows_left, unsigned tile_bytes, unsigned row_bytes) {
+    asm volatile("s_add_u32 s92, s92, %3\n\ts_addc_u32 s93, s93, 0\n\ts_sub_i32 %1, %1, 64\n\ts_min_i32 s94, %1, 64\n\ts_max_i32 s94, s94, 0\n\ts_mul_i32 s94, s94, %4"
+                 : "={s[92:95]}"(r), "+s"(rows_left) : "0"(r), "s"(tile_bytes), "s"(row_bytes) : "scc");
 }
-__device__ __forceinline__ void v_rsrc_advance(u32x4& r, unsigned tile_bytes) {
-    asm volatile("s_add_u32 s96, s96, %2\n\ts_addc_u32 s97, s97, 0\n\ts_sub_u32 s98, s98, %2\n\ts_cselect_b32 s98, 0, s98"
-                 : "={s[96:99]}"(r) : "0"(r), "s"(tile_bytes) : "scc");
+__device__ __forceinline__ void v_rsrc_advance(u32x4& r, int& rows_left, unsigned tile_bytes, unsigned row_bytes) {
+    asm volatile("s_add_u32 s96, s96, %3\n\ts_addc_u32 s97, s97, 0\n\ts_sub_i32 %1, %1, 64\n\ts_min_i32 s98, %1, 64\n\ts_max_i32 s98, s98, 0\n\ts_mul_i32 s98, s98, %4"
+                 : "={s[96:99]}"(r), "+s"(rows_left) : "0"(r), "s"(tile_bytes), "s"(row_bytes) : "scc");
 }
 __device__ __forceinline__ u32x4 tile_rsrc(const void* base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -431,14 +432,16 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // rk / rv: descriptors of K(t+2) / V(t+1) at step entry (base, bytes left from the base on); phase B moves them one tile on and
     // fetches K(t+3) / V(t+2) through them
     const unsigned k_tile_b = (unsigned)PF_BN * k_rs_bytes, v_tile_b = (unsigned)PF_BN * v_rs_bytes;
-    auto bytes_left = [&](int tile, unsigned rs) -> unsigned {
-        const int rem = Lk - tile * PF_BN;
-        return rem <= 0 ? 0u : (unsigned)rem * rs;      // seqlen_k x row bytes < 2^32: checked on the host (attn_api.hip)
+    int k_rows_left = Lk - (tb + 2) * PF_BN, v_rows_left = Lk - (tb + 1) * PF_BN;      // rows of the sequence behind the descriptor's base
+    auto bound = [](int rows, unsigned rs) -> unsigned {      // scalar min / max: the compiler's own clamp is a VALU v_med3 (+ a copy back that it cannot do)
+        int r;
+        asm("s_min_i32 %0, %1, 64\n\ts_max_i32 %0, %0, 0" : "=s"(r) : "s"(rows) : "scc");
+        return (unsigned)r * rs;
     };
     const unsigned long long kp0 = (unsigned long long)kbase + (unsigned long long)(tb + 2) * k_tile_b;
     const unsigned long long vp0 = (unsigned long long)vbase + (unsigned long long)(tb + 1) * v_tile_b;
-    u32x4 rk = {(unsigned)kp0, (unsigned)(kp0 >> 32) & 0xffffu, bytes_left(tb + 2, k_rs_bytes), 0x00020000u};
-    u32x4 rv = {(unsigned)vp0, (unsigned)(vp0 >> 32) & 0xffffu, bytes_left(tb + 1, v_rs_bytes), 0x00020000u};
+    u32x4 rk = {(unsigned)kp0, (unsigned)(kp0 >> 32) & 0xffffu, bound(k_rows_left, k_rs_bytes), 0x00020000u};
+    u32x4 rv = {(unsigned)vp0, (unsigned)(vp0 >> 32) & 0xffffu, bound(v_rows_left, v_rs_bytes), 0x00020000u};
     // byte offsets inside the V ring of V(t)'s slot and of the slot V(t+2) goes to (= the one V(t-1) left): slots go by (t - tb) % 3
     unsigned vs_cur = 0, vs_dma = 2 * S::kTileBytes;
     // One tile step of the wave.  cur holds S(t) on entry and P(t) afterwards, nxt receives S(t+1); kf0 / kf1 hold the first two
@@ -487,8 +490,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             if (i == 17) lv0 = v_lds_wave + vs_dma;
             if (i == 19) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
                                       : "+s"(vs_cur), "=&s"(vs_dma) : "i"(S::kTileBytes), "i"(3 * S::kTileBytes) : "scc");
-            if (i == 21) k_rsrc_advance(rk, k_tile_b);
-            if (i == 23) v_rsrc_advance(rv, v_tile_b);
+            if (i == 21) k_rsrc_advance(rk, k_rows_left, k_tile_b, k_rs_bytes);
+            if (i == 23) v_rsrc_advance(rv, v_rows_left, v_tile_b, v_rs_bytes);
             SCHED_FENCE();
         }
         // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
