@@ -33,6 +33,37 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+# prefill64_kernel counts its own `vmcnt` around LDS-DMA issued by inline asm: a register spill (scratch access, compiler-inserted
+# waits the hand-placed ones do not know about) silently breaks it, and the kernel sits at the SGPR / VGPR limits.  Its translation unit
+# is therefore compiled with the resource-usage remarks on, and the build FAILS when any instantiation of a guarded kernel spills.
+NO_SPILL_KERNELS = {"prefill64_kernels.hip": "prefill64_kernel"}
+
+
+def _compile(hipcc, flags, src, obj):
+    guard = NO_SPILL_KERNELS.get(os.path.basename(src))
+    if not guard:
+        return _run([hipcc, *flags, "-c", src, "-o", obj])
+    cmd = [hipcc, *flags, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
+    print("[build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr)
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    name, bad, seen = None, [], 0
+    for line in r.stderr.splitlines():
+        if "remark: Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+            seen += guard in name
+        elif name and guard in name and ("ScratchSize" in line or "SGPRs Spill" in line or "VGPRs Spill" in line):
+            value = int(line.split("]:")[-1].split("[")[0].strip() if "ScratchSize" in line else line.split("Spill:")[1].split()[0])
+            if value:
+                bad.append("%s: %s" % (name, line.split("remark:")[1].split("[-R")[0].strip()))
+    if not seen:
+        raise RuntimeError("no resource remarks for %s in %s: the spill guard saw nothing" % (guard, src))
+    if bad:
+        raise RuntimeError("register spills in a kernel that counts its own vmcnt:\n  " + "\n  ".join(bad))
+
+
 def build_lib(force=False):
     out = os.path.join(PKG, "libvattn_amd.so")
     srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
@@ -48,7 +79,7 @@ def build_lib(force=False):
         # one hipcc per translation unit, in parallel (the prefill kernels dominate: ~40 s)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
-            list(ex.map(lambda so: _run([hipcc, *flags, "-c", so[0], "-o", so[1]]), zip(srcs, objs)))
+            list(ex.map(lambda so: _compile(hipcc, flags, so[0], so[1]), zip(srcs, objs)))
         _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-pthread", "-Wl,-Bsymbolic", *objs, "-o", out])
     return out
 

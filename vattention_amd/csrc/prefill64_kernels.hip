@@ -252,8 +252,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // O).  On gfx950 the DMA writes zeros for a lane beyond the descriptor's bound (vattn_selftest_layouts [6]); the kernel does not
     // lean on that: a workgroup whose key range reaches the sequence's ragged last tile zero-fills the V ring first.  Every other
     // workgroup only ever multiplies rows that the DMA fetched (tiles past `nt` are computed into S' and never used) and skips the
-    // 48 KiB of LDS writes and the barrier that used to sit in front of its first fetch (1.5 % of a 32 k prompt, 2-13 % of the
-    // short pieces of tensor-parallel prompts: profiles/r03_p64_prologue_epilogue.txt).
+    // 48 KiB of LDS writes and the barrier in front of its first fetch (below the noise in time: profiles/r03_p64_prologue_epilogue.txt).
     if (!(ABL & 512) && nt * PF_BN > Lk) {
         const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
