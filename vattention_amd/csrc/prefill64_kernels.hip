@@ -129,7 +129,7 @@ __device__ __forceinline__ float add1(float a, float b) {
 // MFMA pipe, profiles/r02_issue_probe.txt, r02_prefill64_ablations.md) and was removed in round 3.]
 // NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
 // (RING - 1 fragments ahead of their MFMA).
-template <typename T, int ABL, int NA, int RING, int MS = 4, int BJ = 8, int D0 = 9, int DS = 3>
+template <typename T, int ABL, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3>
 __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done, int merge_mode) {
     using X = Tr<T>;
     using V8 = typename X::v8;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
 constexpr int kSmem64 = 36864 + 3 * PfSmem<128>::kTileBytes;      // K ring (padded layout: 2 x 17 408, rounded up) + V ring
-template <typename T, int ABL, int NA, int RING, int MS = 4, int BJ = 8, int D0 = 9, int DS = 3> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
+template <typename T, int ABL, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -698,8 +698,8 @@ template <typename T, int ABL, int NA, int RING, int MS = 4, int BJ = 8, int D0 
     hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING, MS, BJ, D0, DS>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit, done, merge_mode);
 }
 
-// Product: ONE build per dtype (padded K image, 24 exp2 pairs in phase A, fragment ring of 4, barrier at group 8, DMA in groups 9, 12, .. 30).  The lab library (-DVATTN_LAB) adds the
-// K-image alternative and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 1-3, 11, 12 = correct alternatives;
+// Product: ONE build per dtype (padded K image, 24 exp2 pairs in phase A, fragment ring of 4, row-max chain in groups 8-23, barrier at group 8, DMA in groups 9, 12, .. 30).  The lab library (-DVATTN_LAB) adds the
+// K-image alternative and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 1-3, 11, 12, 14 = correct alternatives;
 // 4-9 = ablations whose RESULTS ARE WRONG).
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
 #ifdef VATTN_LAB
@@ -710,10 +710,12 @@ void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, in
         switch (sel) {
             case 3: return launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done, merge_mode);                    // XOR-swizzled K image (round 2's first layout)
             // schedule alternatives (correct, bit-identical results; tools/p64_variants.py, profiles/r03_p64_schedules.txt)
-            case 1: return launch64_t<_Float16, 128, 20, 4, 4, 8, 9, 3>(p, st, nsplit, done, merge_mode);   // 20 exp2 pairs in phase A
-            case 2: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3>(p, st, nsplit, done, merge_mode);   // row-max chain from group 8
-            case 11: return launch64_t<_Float16, 128, 24, 4, 4, 12, 13, 2>(p, st, nsplit, done, merge_mode);  // barrier after group 11, DMA every second group
-            case 12: return launch64_t<_Float16, 128, 24, 4, 4, 24, 24, 1>(p, st, nsplit, done, merge_mode);  // round 2's placement: barrier after 23, DMA 24-31
+            case 14: return launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode);               // the product build inside the lab library (lab vs
+                                                                                                              // product binaries of one source differ by up to 1 %)
+            case 1: return launch64_t<_Float16, 128, 20, 4, 8, 8, 9, 3>(p, st, nsplit, done, merge_mode);    // 20 exp2 pairs in phase A
+            case 2: return launch64_t<_Float16, 128, 24, 4, 4, 8, 9, 3>(p, st, nsplit, done, merge_mode);    // row-max chain from group 4
+            case 11: return launch64_t<_Float16, 128, 24, 4, 8, 12, 13, 2>(p, st, nsplit, done, merge_mode); // barrier after group 11, DMA every second group
+            case 12: return launch64_t<_Float16, 128, 24, 4, 8, 24, 24, 1>(p, st, nsplit, done, merge_mode); // round 2's placement: barrier after 23, DMA 24-31
             case 10: return launch64_t<_Float16, 256 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no epilogue stores
             case 13: return launch64_t<_Float16, 512 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no zero-fill of the V ring
             case 4: return launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no LDS-DMA in the steady state
