@@ -18,8 +18,13 @@ in-tree FlashAttention-2.6.1 fork that documents the same operator:
 
 and anchors on the reference's own call sites
 (/root/reference/sarathi-lean/sarathi/model_executor/attention/vattention_flashattention_wrapper.py:151-205).
-It is cross-checked against torch's independent CPU scaled_dot_product_attention in
-tests/test_attn_oracle.py.
+It is cross-checked against torch's independent CPU scaled_dot_product_attention and — the one pure-PyTorch
+attention statement that does live under /root/reference — against outputs + LSEs of `ref_mha_bmhk` of the vendored
+CUTLASS example (pod_attn/csrc/cutlass/examples/41_fused_multi_head_attention/fmha_backward_test.py:78-105), run here
+from the reference's own file by oracle/gen_golden_attn_intree.py and committed as tests/golden/attn_intree_ref_mha.npz
+(tests/test_attn_oracle.py).  That function is not the operator's test (it has no KV cache, no GQA, no bottom-right
+mask of its own): it pins softmax(q.k^T/sqrt(d) + mask).v and the LSE, not the operator's semantics — hence still
+"unpinned" in the task's sense.
 
 Two precisions:
   * ``math="f64"``  — exact-arithmetic ground truth on the fp16/bf16 inputs (what tests compare to);

@@ -163,3 +163,35 @@ def test_rotary_oracle_matches_scalar_half_arithmetic_and_is_a_rotation():
                         assert arr[t, h * hs + xi] == x * c - y * s and arr[t, h * hs + yi] == y * c + x * s
         assert torch.equal(q[0], q0[0])
         assert torch.allclose(q.float().view(T, 3, hs).norm(dim=-1), q0.float().view(T, 3, hs).norm(dim=-1), rtol=3e-3)
+
+
+def _intree_cases():
+    import os
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "attn_intree_ref_mha.npz")
+    z = np.load(path)
+    return z, sorted({k.split("/")[0] for k in z.files})
+
+
+@pytest.mark.parametrize("name", _intree_cases()[1])
+def test_matches_the_in_tree_pytorch_mha_reference_vectors(name):
+    """tests/golden/attn_intree_ref_mha.npz: outputs and LSEs of `ref_mha_bmhk` of the CUTLASS example vendored inside the reference
+    tree (…/41_fused_multi_head_attention/fmha_backward_test.py:78-105), produced in this container by
+    oracle/gen_golden_attn_intree.py from the reference's own file.  fp32 arithmetic on the fp16 / bf16 inputs there, fp64 here."""
+    z, _ = _intree_cases()
+    seed, B, Sq, Sk, Hq, Hkv, D, causal, dt = [int(x) for x in z[name + "/meta"]]
+    g = torch.Generator().manual_seed(seed)
+    dtype = torch.bfloat16 if dt else torch.float16
+    q = torch.randn(B, Sq, Hq, D, generator=g).to(dtype)          # the generating script's recipe (inputs())
+    k = torch.randn(B, Sk, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(B, Sk, Hkv, D, generator=g).to(dtype)
+    got, lse = flash_attn_with_kvcache_ref(q, k, v, cache_seqlens=torch.full((B,), Sk, dtype=torch.int32), causal=bool(causal),
+                                           math="f64", return_lse=True)
+    ref = torch.from_numpy(z[name + "/out"]).double()
+    assert torch.allclose(got, ref, atol=2e-5, rtol=2e-5), (got - ref).abs().max().item()
+    ref_lse = torch.from_numpy(z[name + "/lse"]).double()            # [B, Hq, Sq], natural log of sum exp(scaled scores)
+    assert torch.allclose(lse, ref_lse, atol=2e-5, rtol=2e-6), (lse - ref_lse).abs().max().item()
+    # and the reference-numerics mode (fp32 accumulate, P rounded to the I/O dtype) stays within the I/O dtype's rounding of them
+    got32 = flash_attn_with_kvcache_ref(q, k, v, cache_seqlens=torch.full((B,), Sk, dtype=torch.int32), causal=bool(causal), math="f32")
+    tol = 8e-3 if dt else 2e-3
+    assert torch.allclose(got32.double(), ref, atol=tol, rtol=tol)
