@@ -104,9 +104,6 @@ template <typename T> struct Mfma;
         static __device__ __forceinline__ void pv(f32x16& o, V8 a, V8 b) {                                                         \
             asm volatile(MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                                       \
         }                                                                                                                          \
-        static __device__ __forceinline__ void pv_nop(f32x16& o, V8 a, V8 b) {                                                     \
-            asm volatile("s_nop 1\n\t" MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                         \
-        }                                                                                                                          \
     };
 VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16")
 VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16")
@@ -153,6 +150,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // MS: first phase-B group of the row-max chain of S'(t+1).  BJ: the phase-B group that opens with the per-tile wait + barrier; the
     // eight DMA pieces go out in groups D0, D0 + DS, ... (all >= BJ).
     static_assert(D0 >= BJ && D0 + 7 * DS < 32, "DMA pieces behind the barrier, inside phase B");
+    static_assert(NA >= 16 && NA < 32, "key slice 0 of P is packed in phase-A groups 13 / 15: its eight pairs must be exponentiated by group 12");
+    static_assert(MS >= 4 && MS + 19 < 32, "row-max chain >= 4 MFMAs behind the last S^T MFMA, its reduction inside phase B");
     auto dma_gap = [](int k) { return D0 + DS * k; };
 
     const int tid = threadIdx.x;
@@ -481,10 +480,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             softmax_stages(i, cur);
             // key slice 0 of P(t) (pairs 0-7: exponentiated by group GE(7) <= 12 for NA >= 16) is packed HERE, so the first P.V MFMA
             // of phase B does not wait for eight conversions issued right in front of it
-            if (NA >= 16) {
-                if (i == 13) pf[0][0] = pack_p(cur, 0, 0);
-                if (i == 15) pf[0][1] = pack_p(cur, 0, 1);
-            }
+            if (i == 13) pf[0][0] = pack_p(cur, 0, 0);
+            if (i == 15) pf[0][1] = pack_p(cur, 0, 1);
             // the DMA stream's scalars move one tile on (SALU work, inside gaps)
             if (i == 17) lv0 = v_lds_wave + vs_dma;
             if (i == 19) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
@@ -498,10 +495,6 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         vf[0] = vfrag(vsm, 0);
         vf[1] = vfrag(vsm, 1);
         if (RING > 3) vf[2] = vfrag(vsm, 2);
-        if (NA < 16) {
-            pf[0][0] = pack_p(cur, 0, 0);
-            pf[0][1] = pack_p(cur, 0, 1);
-        }
         float mx0 = -INFINITY, mx1 = -INFINITY, g0 = -INFINITY, g1 = -INFINITY, grow = -INFINITY;
         SCHED_FENCE();
 #pragma unroll
@@ -514,8 +507,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 __builtin_amdgcn_s_barrier();
             }
             // (a P fragment is packed at least one MFMA group before its first use: no VALU -> MFMA operand hazard to pad)
-            if (NA < 16 && j < 2) M::pv_nop(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
-            else M::pv(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
+            M::pv(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
             if ((j & 1) == 0 && f + RING - 1 < 16 && !((ABL & 16) && f >= 1)) vf[(f + RING - 1) % RING] = vfrag(vsm, f + RING - 1);
             softmax_stages(32 + j, cur);
             // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
