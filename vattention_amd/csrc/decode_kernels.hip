@@ -34,6 +34,16 @@ __global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int n
     const int64_t sstride = (int64_t)p.b * sq * p.h;
     const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
     const float my = (tid < num_splits) ? lacc[(int64_t)tid * sstride + row] : -INFINITY;    // num_splits <= 128
+    // up to kEarly partials per thread are asked for BEFORE the weights exist: their loads fly together with the LSE loads instead of
+    // behind the two reductions (the kernel is two dependent memory latencies long, nothing else)
+    constexpr int kEarly = 16;
+    const bool early = num_splits <= kEarly;
+    const float* src = oacc + row * HD + (tid < HD ? tid : 0);
+    float part[kEarly];
+    if (early) {
+#pragma unroll
+        for (int s = 0; s < kEarly; s++) part[s] = (s < num_splits && tid < HD) ? src[(int64_t)s * sstride * HD] : 0.f;
+    }
     float mx = my;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, xor_shuffle(mx, o));
@@ -51,10 +61,14 @@ __global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int n
     const float wsum = red[2] + red[3];
     const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
     if (tid < HD) {
-        const float* src = oacc + row * HD + tid;
         float acc = 0.f;
+        if (early) {
+#pragma unroll
+            for (int s = 0; s < kEarly; s++) acc += wsm[s] * part[s];      // wsm[s] = 0 and part[s] = 0 beyond num_splits: the same sum, the same order
+        } else {
 #pragma unroll 8
-        for (int s = 0; s < num_splits; s++) acc += wsm[s] * src[(int64_t)s * sstride * HD];
+            for (int s = 0; s < num_splits; s++) acc += wsm[s] * src[(int64_t)s * sstride * HD];
+        }
         ((T*)p.out)[(int64_t)b * p.o_batch_stride + (int64_t)q * p.o_row_stride + (int64_t)hh * p.o_head_stride + tid] = Tr<T>::cvt(acc * inv);
     }
     if (p.softmax_lse && tid == 0)
