@@ -10,7 +10,9 @@
 //     tile, counted `vmcnt` (the DMA is issued by inline asm, the compiler's wait-count pass never sees it);
 //   * software pipeline inside the wave: phase A  S(t+1) = K(t+1).Q^T  ||  P(t) = exp2(S(t)), row sums;
 //                                        phase B  O += V(t)^T.P(t)^T   ||  row max of S(t+1), f16 packing of P(t);
-//     so the softmax VALU work of a tile is issued between the MFMAs of its neighbours by the same wave;
+//     so the softmax VALU work of a tile is issued between the MFMAs of its neighbours by the same wave; the scalar bookkeeping of
+//     the DMA stream (running descriptors in fixed SGPR quads, slot rotation) and the row-max reduction sit inside MFMA gaps as
+//     well — one instruction before a step's first MFMA, two behind its last (round 3);
 //   * softmax exactly as the reference states it (softmax.h:69-94): P = exp2(s*scale*log2e - m*scale*log2e) in fp32, one v_fma
 //     + one v_exp per score; the running maximum is only moved when a tile's maximum exceeds it by more than 2^kDeferLog2
 //     (deferred rescale, cdna guide T13) — O and l are rescaled exactly once in that (rare) branch, the pending S(t+1) is still
