@@ -629,7 +629,7 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
 // Work list of a prefill launch (include/vattn_kernels.h, vattn_prefill_plan).  One 256-row prefill64 workgroup per CU; the launch
 // lasts as long as the most loaded CU.  Candidate plans cut every query block longer than T key tiles into ceil(tiles / T) equal pieces,
 // for T = longest / {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}; each candidate is priced by replaying the dispatcher (pieces longest first,
-// each to the CU that frees up first) with a per-piece cost of tiles + 3 (prologue: zeroing the V ring, Q, the first DMA round trips)
+// each to the CU that frees up first) with a per-piece cost of tiles + 3 (prologue: Q, the first DMA round trips, the first S')
 // + 1.5 for a piece that publishes a partial, plus the merge pass's traffic; the cheapest wins.  [Measured, profiles/r03_kbench.txt: a
 // plan whose piece count lands just above a round of 256 — 280 pieces of a 2 k chunk on a 30 k prefix — costs 0.371 ms against 0.279 for
 // 256 pieces: pricing whole rounds is what the replay is for.]  Short key walks (no block of 96 tiles = 6 k keys) keep the default
