@@ -281,8 +281,11 @@ def test_product_library_holds_no_measurement_scaffolding():
         import os
         so = os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libvattn_amd.so")
     syms = subprocess.run(["nm", "--defined-only", so], capture_output=True, text=True, check=True).stdout      # (mangled names)
-    p64 = set(re.findall(r"prefill64_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E", syms))
-    assert p64 == {("DF16_", "128", "24", "4"), ("DF16b", "128", "24", "4")}, p64
+    # prefill64_kernel<T, ABL, NA, RING, MS, BJ, D0, DS>: padded K image, 24 exp2 pairs in phase A, ring of 4, row-max chain from group 8,
+    # barrier at group 8, DMA pieces in groups 9, 12, ...
+    p64 = set(re.findall(r"prefill64_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EE", syms))
+    assert p64 == {("DF16_", "128", "24", "4", "8", "8", "9", "3"), ("DF16b", "128", "24", "4", "8", "8", "9", "3")}, p64
+    assert len(set(re.findall(r"prefill64_kernelI\w+?EEv", syms))) == 2
     assert "prefill_ilv_kernel" not in syms
     # prefill_kernel<T, HD, USE_TR, WAVES, QC, MSUM> / decode_kernel<T, HD, USE_TR, NB, W>: plain-read (USE_TR = false) operand paths
     # and the row-sums-by-MFMA build are lab-only
