@@ -1,7 +1,7 @@
 """Gate on the prefill launch plan (csrc/prefill_kernels.hip, plan_prefill): on the short / underfilled shapes where the plan has to
 choose a tiling and a KV split, the DEFAULT plan must not lose to any explicit tiling of the product library by more than 3 %
 (+ a 3 us allowance for launch jitter on these 40-200 us kernels).  Timed through the C ABI (vattn_time_attn, HIP events on the launch
-stream), best of three repetitions of 20 launches each."""
+stream), best of three repetitions of 20 launches each (the plan: of six, three before and three after the explicit tilings)."""
 import ctypes as C
 
 import pytest
@@ -26,11 +26,13 @@ def test_default_plan_is_not_beaten_by_an_explicit_tiling(name, Hq, Hkv, n, c):
     cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     times = {}
-    for variant in (0, 2, 8, 14):                       # plan, 8 waves x 32 rows, 4 waves x 32 rows, prefill64
+    # plan, 8 waves x 32 rows, 4 waves x 32 rows, prefill64 — and the plan once more at the end: whatever is timed first on these
+    # 40-200 us launches reads a few percent slow (the plan and the explicit tiling it chose are the SAME launch, and differed by 5 %)
+    for variant in (0, 2, 8, 14, 0):
         p, keep = params(q, kc, vc, cl, variant=variant)
         best = min(K.klib().vattn_time_attn(C.byref(p), st, 3, 20) for _ in range(3))
         assert best > 0, K.last_error()
-        times[variant] = best
+        times[variant] = min(best, times.get(variant, best))
         del keep
     explicit = min(times[v] for v in (2, 8, 14))
     print("%s: plan %.4f ms, explicit tilings %s" % (name, times[0], {v: round(times[v], 4) for v in (2, 8, 14)}))
