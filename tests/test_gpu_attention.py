@@ -28,7 +28,8 @@ def _check(out_gpu, ref64, ref32, dtype, what):
         "%s: kernel err %.3e vs reference-numerics err %.3e" % (what, err.max().item(), e_ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 65536, 131072, 262144], ids=["tr_read", "plain_read", "wg512", "wg1024", "two_register_sets"])
+@pytest.mark.parametrize("variant", [0, 1 << 20, 1 << 19, 1, 65536, 131072, 262144],
+                         ids=["stream", "stream_in_launch_merge", "grid_heuristics", "plain_read", "wg512", "wg1024", "two_register_sets"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("B,G,Hkv,lens", [
     (1, 8, 4, [777]),                    # Yi-6B group size
@@ -37,6 +38,9 @@ def _check(out_gpu, ref64, ref32, dtype, what):
     (4, 1, 2, [300, 2, 4095, 64]),       # MHA
 ])
 def test_decode_parity(B, G, Hkv, lens, dtype, variant):
+    """variant 0 = the product path: the device-planned stream decomposition (merged by a second launch); bit 20 (lab): merged inside the
+    launch; bit 19: the grid heuristics of rounds 1-3; the rest are lab shapes.  num_splits < 0 forces that many workgroups per kv head on the
+    stream path (pieces that cross sequence boundaries, ranges that end inside a tile space smaller than the grid, ...)."""
     from vattention_amd.flash_attn import flash_attn_with_kvcache
     torch.manual_seed(1234)
     Hq, D, ctx, slots = G * Hkv, 128, 6000, 7
@@ -53,13 +57,15 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
     kc2, vc2 = kc.clone(), vc.clone()
     ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :max_len], vc2[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     kg, vg = kc.to(DEV), vc.to(DEV)
-    for splits in (0, 1, 3):
+    stream = variant in (0, 1 << 20)
+    for splits in (0, 1, 3) + ((-1, -2, -5, -37, -300) if stream else ()):
         kgi, vgi = kg.clone(), vg.clone()
-        out = flash_attn_with_kvcache(q.to(DEV), kgi[:, :max_len], vgi[:, :max_len], kn.to(DEV), vn.to(DEV),
-                                      cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True,
-                                      num_splits=splits, _variant=variant)
-        torch.cuda.synchronize()
-        _check(out, ref64, ref32, dtype, "decode splits=%d" % splits)
+        for rep in range(2 if stream else 1):          # (the in-launch merge's tickets reset themselves: a second call must work too)
+            out = flash_attn_with_kvcache(q.to(DEV), kgi[:, :max_len], vgi[:, :max_len], kn.to(DEV), vn.to(DEV),
+                                          cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True,
+                                          num_splits=splits, _variant=variant)
+            torch.cuda.synchronize()
+            _check(out, ref64, ref32, dtype, "decode splits=%d call %d" % (splits, rep))
         assert torch.equal(kgi.cpu(), kc1) and torch.equal(vgi.cpu(), vc1)     # in-place append, bit-exact, nothing else touched
 
 
@@ -254,6 +260,73 @@ def test_decode_length_balanced_plan(Hq, Hkv, lens, dtype, variant):
         outs.append(out.float().cpu())
     for o in outs[:2]:
         assert (o - outs[2]).abs().max().item() <= (2e-3 if dtype == torch.float16 else 1.6e-2)
+
+
+@pytest.mark.parametrize("append", [True, False], ids=["append", "no_append"])
+@pytest.mark.parametrize("Hq,Hkv,B,lo,hi,nwg", [
+    (8, 1, 250, 0, 900, 0),            # four sequences per lane of the planning wave, some EMPTY
+    (8, 1, 250, 0, 900, -700),         # ... and far more workgroups than the tile space has tiles
+    (8, 1, 100, 0, 900, -50),          # two sequences per lane
+    (32, 8, 40, 1, 3000, 0),           # Llama-3-8B heads
+    (32, 8, 40, 1, 3000, -7),          # every workgroup's range spans several sequences
+    (28, 4, 1, 9000, 9000, -64),       # ONE sequence (forced onto the stream path: the product takes the uniform grid for B = 1): 64 pieces
+    (32, 1, 9, 10, 2500, -11),         # G = 32: two 16-head blocks per workgroup
+    (8, 2, 256, 0, 70, 0),             # the largest batch the plan prologue takes
+    (8, 2, 300, 0, 70, 0),             # ... and one beyond it (the launch falls back to the grid heuristics)
+], ids=["b250", "b250_sparse", "b100", "llama8b", "llama8b_spanning", "one_sequence", "g32", "b256", "b300_fallback"])
+def test_decode_stream_plan(Hq, Hkv, B, lo, hi, nwg, append):
+    """The device-planned stream decomposition (csrc/decode_body.h, decode_stream_kernel) on batches that stress the PLAN: every sequence
+    against the oracle (f64 and reference numerics), the appended rows bit-exact, the lab build's in-launch merge against the product's
+    two-launch form (the same arithmetic up to the chunking of the sum), repeated calls on one stream (the tickets reset themselves).  No host-side lengths anywhere."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(B * 7 + Hq)
+    dtype, D = torch.float16, 128
+    g = torch.Generator().manual_seed(B + hi)
+    lens = torch.randint(lo, hi + 1, (B,), generator=g).tolist()
+    if B >= 100:
+        lens[0] = lens[17] = lens[B - 1] = 0            # empty sequences (first, middle, last)
+    ctx = max(lens) + 8
+    slots = B + 3
+    kc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    vc = torch.randn(slots, ctx, Hkv, D).to(dtype)
+    q = torch.randn(B, 1, Hq, D).to(dtype)
+    kn = torch.randn(B, 1, Hkv, D).to(dtype) if append else None
+    vn = torch.randn(B, 1, Hkv, D).to(dtype) if append else None
+    idx = torch.randperm(slots, generator=g)[:B].to(torch.int32)
+    cl = torch.tensor(lens, dtype=torch.int32)
+    ml = max(lens) + (1 if append else 0)
+    kc1, vc1 = kc.clone(), vc.clone()
+    ref64 = flash_attn_with_kvcache_ref(q, kc1[:, :ml], vc1[:, :ml], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
+    kc2, vc2 = kc.clone(), vc.clone()
+    ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :ml], vc2[:, :ml], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
+    dev = lambda t: t.to(DEV) if t is not None else None
+    outs = {}
+    for variant in (0, 1 << 20):
+        kg, vg = kc.to(DEV), vc.to(DEV)
+        for rep in range(2):
+            out, lse = flash_attn_with_kvcache(dev(q), kg[:, :ml], vg[:, :ml], dev(kn), dev(vn), cache_seqlens=dev(cl), cache_batch_idx=dev(idx),
+                                               causal=True, num_splits=nwg, _variant=variant, return_softmax_lse=True)
+            torch.cuda.synchronize()
+            _check(out, ref64, ref32, dtype, "stream decode, variant %d, call %d" % (variant, rep))
+        assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)
+        outs[variant] = (out.cpu(), lse.cpu())
+    # (the two merges fold the records in chunks of 16 / 8: the same sum up to the order of a few fp32 multiply-adds)
+    assert (outs[0][0].float() - outs[1 << 20][0].float()).abs().max().item() <= 1e-3 and torch.allclose(outs[0][1], outs[1 << 20][1], atol=1e-4, rtol=1e-5)
+    if not append:      # an empty sequence attends to nothing: zeros, LSE = +inf as FlashAttention reports it
+        for b, l in enumerate(lens):
+            if l == 0:
+                assert float(outs[0][0][b].abs().max()) == 0.0 and bool(torch.isinf(outs[0][1][b]).all())
+    # natural-log LSE against the oracle's scores
+    got = outs[0][1][:, :, 0].double()
+    for b in (1, B // 2, B - 2) if B > 3 else (0,):
+        Lk = lens[b] + (1 if append else 0)
+        if Lk == 0:
+            continue
+        keys = kc1[idx[b].item(), :Lk].double()                       # [Lk, Hkv, D] (after the oracle's append)
+        qq = q[b, 0].double().view(Hkv, Hq // Hkv, D)
+        sc = torch.einsum("kgd,lkd->kgl", qq, keys) * D ** -0.5
+        want = torch.logsumexp(sc, dim=-1).reshape(-1)
+        assert torch.allclose(got[b], want, atol=2e-3, rtol=2e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])

@@ -212,6 +212,14 @@ def test_fuzz_planned_launches(seed):
             assert cap[0].num_split_items >= B, what
         _check(out, ref, dtype, what)
         assert torch.equal(kg.cpu(), kr) and torch.equal(vg.cpu(), vr), what
+        # the product path (round 4): the decomposition derived ON THE DEVICE from cache_seqlens — default workgroup count and a random one
+        for nwg in (0, -rng.choice([1, 2, 3, 7, 19, 64, 200])):
+            kg2, vg2 = kc.to(DEV), vc.to(DEV)
+            out2 = flash_attn_with_kvcache(q.to(DEV), kg2, vg2, kn.to(DEV) if append else None, vn.to(DEV) if append else None,
+                                           cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True, num_splits=nwg)
+            torch.cuda.synchronize()
+            _check(out2, ref, dtype, what + " device-planned stream, num_splits=%d" % nwg)
+            assert torch.equal(kg2.cpu(), kr) and torch.equal(vg2.cpu(), vr), what
         # ---- prefill work list (d = 128) ----
         Hkv = rng.choice([1, 2, 4])
         Hq = Hkv * rng.choice([1, 2, 4, 8])

@@ -34,6 +34,7 @@ def params(q, kc, vc, cl, idx=None, kn=None, vn=None, causal=True, splits=0, var
     p.seqlen_k, p.h_k = kc.shape[1], kc.shape[2]
     p.is_causal, p.dtype, p.num_splits, p.softmax_scale, p.variant = int(causal), (1 if q.dtype == torch.bfloat16 else 0), splits, q.shape[3] ** -0.5, variant
     p.max_seqlen_k_hint = kc.shape[1]        # the benchmark caches are exactly as long as the sequences
+    p.split_reserved = int(os.environ.get("KBENCH_SWITCH_TILES", "-1")) + 1      # stream decode: switch allowance override (tuning)
     keep = [out, q, kc, vc, cl, idx, kn, vn]
     need = K.klib_for(p.variant).vattn_attn_workspace_bytes(C.byref(p))
     if need:
@@ -109,7 +110,8 @@ def prefill(variant):
 def decode(variant):
     print("== decode (Sq=1, append + split-KV + combine), %s, D=128 ==" % ("bf16" if DTYPE == torch.bfloat16 else "fp16"))
     for name, Hq, Hkv, B, ctx, slots in [("yi6b B16@32k", 32, 4, 16, 32768, 16), ("yi6b B1@32k", 32, 4, 1, 32768, 4), ("yi6b B4@32k", 32, 4, 4, 32768, 4),
-                                         ("yi6b B1@8k", 32, 4, 1, 8192, 4), ("yi6b B1@2k", 32, 4, 1, 2048, 4),
+                                         ("yi6b B2@32k", 32, 4, 2, 32768, 4), ("yi6b B8@32k", 32, 4, 8, 32768, 8),
+                                         ("yi6b B1@8k", 32, 4, 1, 8192, 4), ("yi6b B1@2k", 32, 4, 1, 2048, 4), ("yi6b B16@2k", 32, 4, 16, 2048, 16),
                                          ("llama8b B64@8k", 32, 8, 64, 8192, 64), ("llama8b B256@2k", 32, 8, 256, 2048, 256),
                                          ("llama70b/tp8 B64@32k", 8, 1, 64, 32768, 64), ("yi34b/tp2 B8@128k", 28, 4, 8, 131072, 8),
                                          ("yi34b/tp2 B1@128k", 28, 4, 1, 131072, 2), ("yi34b/tp4 B1@128k", 14, 2, 1, 131072, 2),
@@ -176,5 +178,6 @@ if __name__ == "__main__":
         if "--dvariants" in sys.argv:
             dvs = [int(x) for x in sys.argv[sys.argv.index("--dvariants") + 1].split(",")]
         for v in dvs:
-            print("-- decode variant %d (%s) --" % (v, "512-thread workgroups" if v & 65536 else "1024-thread workgroups" if v & 131072 else "256 threads, two K/V register sets per wave" if v & 262144 else "256-thread workgroups (default)"))
+            print("-- decode variant %d (%s%s) --" % (v, "512-thread workgroups" if v & 65536 else "1024-thread workgroups" if v & 131072 else "256 threads, two K/V register sets per wave" if v & 262144 else "256-thread workgroups (default)",
+                                                   ", grid heuristics of rounds 1-3" if v & (1 << 19) else ", device-planned stream, in-launch merge (lab)" if v & (1 << 20) else ", device-planned stream"))
             decode(v)

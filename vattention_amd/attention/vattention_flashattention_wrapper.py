@@ -233,8 +233,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                     cache_seqlens=self.decode_cache_lens, block_table=None,
                                     softmax_scale=softmax_scale, causal=True,
                                     cache_batch_idx=self.batch_index_gen,
-                                    out=output[tok:tok + nb].view(nb, 1, Hq, D), _rotary_cos_sin=self._rotary, _params_out=capture,
-                                    _cache_seqlens_host=self._decode_lens_host)
+                                    out=output[tok:tok + nb].view(nb, 1, Hq, D), _rotary_cos_sin=self._rotary, _params_out=capture)
+            # (no host-side lengths: the launch balances a ragged batch from `cache_seqlens` on the device, csrc/decode_body.h)
         if capture:
             es = query.element_size()
             self._dec_plan = {"sig": sig, "p": capture[0], "q_off": tok * query.stride(0) * es, "k_off": tok * key.stride(0) * es,

@@ -35,8 +35,11 @@ constexpr bool kLab = true;
 constexpr bool kLab = false;
 #endif
 // variant bits of vattn_attn_params a product build accepts: bits 1-3 tiling {0 plan, 1 = 8 waves x 32 rows, 4 = 4 waves x 32 rows,
-// 7 = prefill64}; bits 5-6 workgroup order; bit 7 one 16-head block per decode workgroup; bits 12-13 role policy of the fused launch
-constexpr int kProductVariantMask = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12);
+// 7 = prefill64}; bits 5-6 workgroup order; bit 7 one 16-head block per decode workgroup; bits 12-13 role policy of the fused launch;
+// bit 19: decode keeps the grid heuristics of rounds 1-3 (uniform split / host plan) instead of the device-planned stream decomposition
+// (an A/B selector).  LAB ONLY, bit 20: the stream decomposition merges inside the decode launch (tickets) instead of in a second launch.
+constexpr int kVariantLegacyDecodePlan = 1 << 19, kVariantInLaunchMerge = 1 << 20;
+constexpr int kProductVariantMask = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | kVariantLegacyDecodePlan;
 
 template <typename T> struct Tr;
 template <> struct Tr<_Float16> {
@@ -183,6 +186,9 @@ __device__ __forceinline__ bool wg_to_work(const vattn_attn_params& p, int order
 // ---- device-scope (cache-bypassing) accesses for data handed from one workgroup to another inside a launch ----
 // Relaxed atomics at agent scope compile to global_store/load ... sc1: the store is written through to the device's coherence
 // point and the load does not hit a stale line of this XCD's L2 — no fence (= no L2 write-back + invalidate) needed around them.
+// The same for buffer accesses: cache-policy operand of the raw buffer intrinsics with the SC1 bit (device scope on gfx940+): a store is
+// written through, a load is not served from this CU's L1.  16-byte device-scope stores cost what plain ones do.
+constexpr int kDevScope = 16;
 __device__ __forceinline__ void store_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float load_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

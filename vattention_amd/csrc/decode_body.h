@@ -24,7 +24,13 @@ constexpr int DC_BN = 32;     // keys per wave tile
 template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES, int PF = 1>
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
                                             const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0,
-                                            const int item = -1, const int item_tb = 0, const int item_te = 0) {
+                                            const int item = -1, const int item_tb = 0, const int item_te = 0,
+                                            const int st_mode = 0, const int st_slot = 0, const int st_lk = 0, const unsigned st_block = 0) {
+    // st_mode != 0: a piece [item_tb, item_te) of the device-planned stream decomposition (decode_stream_kernel below).  Slot and visible
+    // length come from the workgroup's plan (LDS) instead of two dependent global loads; st_mode 1 = the piece is the whole sequence: the
+    // final rows are written; st_mode 2 = a partial, published as one record block at byte offset st_block of the workspace (16-byte
+    // stores; merged by the next launch); st_mode 3 (lab) = the same with write-through stores (device scope: merged INSIDE the launch by
+    // a workgroup that may sit on another XCD, whose L2 is not coherent with this one).
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
@@ -40,14 +46,21 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     const int g4 = lane >> 4;
 
     const int G = p.h / p.h_k;
-    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
-    int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
-    // never beyond the rows of the cache VIEW: the append skips such rows, and the rows behind them may be another slot's or sit on
-    // unmapped virtual pages (the wrapper asserts cache_len + new <= rows on the host, where it knows the lengths)
-    Lk = Lk > p.seqlen_k ? p.seqlen_k : Lk;
+    int slot, Lk;
+    if (st_mode) {
+        slot = st_slot;
+        Lk = st_lk;
+    } else {
+        slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+        Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
+        // never beyond the rows of the cache VIEW: the append skips such rows, and the rows behind them may be another slot's or sit on
+        // unmapped virtual pages (the wrapper asserts cache_len + new <= rows on the host, where it knows the lengths)
+        Lk = Lk > p.seqlen_k ? p.seqlen_k : Lk;
+    }
 
     // each sequence divides ITS OWN length evenly over the splits (balanced for ragged batches)
-    const int ntiles_total = (Lk + DC_BN - 1) / DC_BN;
+    // (stream mode: an EMPTY sequence still owns one tile of the plan's tile space — fully masked, so that its rows get written)
+    const int ntiles_total = (st_mode && Lk <= 0) ? 1 : (Lk + DC_BN - 1) / DC_BN;
     const int tiles_per_split = (ntiles_total + num_splits - 1) / num_splits;
     // item >= 0: a piece [item_tb, item_te) of a length-balanced plan (vattn_decode_plan) instead of split `split` of num_splits
     const int tile_begin = item >= 0 ? item_tb : split * tiles_per_split;
@@ -283,7 +296,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     // the one that holds the appended row) is always the last tile of whichever wave owns it: it is taken out of the steady-state
     // loop and processed after it.
     const int last_tile = ntiles_total - 1;
-    const bool special_last = fused_append || (Lk % DC_BN) != 0;
+    const bool special_last = fused_append || (Lk % DC_BN) != 0 || Lk <= 0;
     const int first = __builtin_amdgcn_readfirstlane(tile_begin + wave);
     const bool own_last = special_last && last_tile >= first && last_tile < tile_end && ((last_tile - first) % W) == 0;
     const int loop_end = own_last ? last_tile : tile_end;          // wave-uniform
@@ -326,6 +339,56 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             lsm[wave * 16 + l15] = lr;
         }
         __syncthreads();
+        if (st_mode) {
+            // stream decomposition: four columns per thread — 16-byte LDS reads and 16-byte stores (a device-scope store of one dword
+            // costs ~6x its share of a 16-byte one: MI355X_MICROARCH, inter-workgroup visibility)
+            const __amdgpu_buffer_rsrc_t wsr = make_rsrc(p.workspace, 0x7fffffffu);
+            for (int i4 = tid; i4 < 16 * (HD / 4); i4 += 64 * W) {
+                const int row = i4 / (HD / 4), d0 = (i4 % (HD / 4)) * 4;
+                const int rh = (gb * NB + nb) * 16 + row;
+                if (rh >= G) continue;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < W; w++) mx = fmaxf(mx, msm[w * 16 + row]);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                float lsum = 0.f;
+                const float mxs = (mx == -INFINITY) ? 0.f : mx * sc;
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    const float f = fast_exp2(msm[w * 16 + row] * sc - mxs);
+                    const f32x4 a = *(const f32x4*)&osm[(w * 16 + row) * HD + d0];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] += f * a[e];
+                    lsum += f * lsm[w * 16 + row];
+                }
+                const int hh = hk * G + rh;
+                const float inv = (lsum == 0.f || lsum != lsum) ? 1.f : 1.f / lsum;
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] *= inv;
+                if (st_mode == 1) {
+                    typename X::v4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o4[e] = X::cvt(acc[e]);
+                    *(typename X::v4*)((T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d0) = o4;
+                    if (p.softmax_lse && d0 == 0)
+                        p.softmax_lse[(int64_t)b * p.h + hh] = (lsum == 0.f) ? INFINITY : (mx * p.softmax_scale + __logf(lsum));
+                } else {
+                    // record block: float o[16 * NB][HD], then float lse[16 * NB] (log2 domain) — see decode_stream_kernel
+                    const unsigned r16 = (unsigned)(nb * 16 + row);
+                    u32x4 bits;
+                    __builtin_memcpy(&bits, &acc, 16);
+                    const float lv = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));
+                    if (kLab && st_mode == 3) {      // handed over inside the launch: device scope (write-through)
+                        __builtin_amdgcn_raw_buffer_store_b128(bits, wsr, (int)(st_block + (r16 * HD + d0) * 4u), 0, kDevScope);
+                        if (d0 == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lv), wsr, (int)(st_block + (16u * NB * HD + r16) * 4u), 0, kDevScope);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(bits, wsr, (int)(st_block + (r16 * HD + d0) * 4u), 0, 0);
+                        if (d0 == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lv), wsr, (int)(st_block + (16u * NB * HD + r16) * 4u), 0, 0);
+                    }
+                }
+            }
+            continue;
+        }
         for (int idx = tid; idx < 16 * HD; idx += 64 * W) {
             const int row = idx / HD, d = idx % HD;
             const int rh = (gb * NB + nb) * 16 + row;
@@ -437,6 +500,318 @@ __device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params
         decode_group_combine<T, HD, NB>(p, num_splits, hk, gb, b, mode == 2);
         if (tid == 0) *done_counter = 0;
     }
+}
+
+// ============================================================================================
+// Device-planned stream decomposition of a decode batch (round 4)
+// ============================================================================================
+// The reference's split heuristic (flash_api.cpp:258-323) and rounds 1-3 of this kernel give every sequence of a batch the same number
+// of splits; a ragged batch then lasts as long as its longest sequence's share.  Round 3 balanced it with a HOST-built plan — which needs
+// the lengths on the host, and the reference's wrapper only has them on the device (vattention_flashattention_wrapper.py:194-205 passes
+// `cache_seqlens` / `cache_batch_idx` tensors).  Here the plan is derived ON THE DEVICE, by every workgroup for itself, from those two
+// arrays: the 32-key tiles of all sequences of one (kv head, head-block group) form ONE tile space in batch order; workgroup w of the
+// nwg workgroups of that group streams tiles [w T, (w + 1) T), T = ceil(total / nwg) — every workgroup reads the same number of bytes
+// whatever the lengths are.  A range that crosses sequence boundaries is processed piece by piece (one softmax state per sequence).
+//   plan prologue: lane i of every wave loads cache_seqlens[i] and cache_batch_idx[i] (ONE memory latency for both), a wave-wide inclusive
+//     scan of the tile counts, a compare + ballot for the first sequence of the range — registers only, no LDS, no barrier, no dependent
+//     second load before the K/V stream starts;
+//   pieces of sequence b come from the consecutive workgroups first_w .. last_w (closed form from the scan), piece (w, b) publishes
+//     its partial as record (w + b) — unique, and consecutive within a sequence;
+//   a sequence that lies inside ONE workgroup's range is written directly; the others are merged by decode_stream_combine_kernel (a
+//     second launch that re-derives the plan the same way) — no host plan, no upload.  LAB: the workgroup that completes a sequence's
+//     last piece merges inside the launch (device-scope ticket per (sequence, kv head)): measured equal or slower, see decode_kernels.hip.
+// Partials travel as 16-byte device-scope (write-through) stores — nothing is left dirty in the L2s for the kernel boundary to write
+// back — one 128-byte-aligned record block per (record, kv head, group) that exactly one workgroup writes and exactly one reads.
+constexpr int DC_MAXB = 256;                         // sequences per launch the plan prologue handles (4 per lane of a wave)
+// A workgroup whose range crosses into another sequence pays a second prologue / epilogue (partial stores drained, Q fetched, the K/V
+// stream restarted): a few microseconds during which its neighbours on the CU keep streaming but IT falls behind — and a one-round
+// launch ends with its slowest workgroup.  Every sequence therefore occupies `switch allowance` extra positions of the tile space ahead
+// of its first tile: ranges stay equal in POSITIONS, a range that crosses a boundary holds that many fewer real tiles.
+constexpr int DC_SWITCH_TILES = 4;
+constexpr int DC_MIN_WG_TILES = 8;                   // a workgroup streams at least this many positions (two tiles per wave)
+__device__ __forceinline__ int stream_switch_tiles(const vattn_attn_params& p) { return (p.split_reserved & 255) > 0 ? (p.split_reserved & 255) - 1 : DC_SWITCH_TILES; }
+__device__ __forceinline__ int stream_tiles_per_wg(int total, int nwg) {
+    const int t = (total + nwg - 1) / nwg;
+    return t < DC_MIN_WG_TILES ? DC_MIN_WG_TILES : t;
+}
+
+// workspace: int2 table[b] = (first record, record count) of every sequence — written by the workgroup that owns the sequence's first
+// piece on kv head 0, read by the merge launch (ONE scalar load instead of re-deriving the plan) — then the records, 128-byte aligned
+__host__ __device__ __forceinline__ constexpr unsigned stream_table_bytes(int b) { return ((unsigned)b * 8u + 127u) & ~127u; }
+template <int NB, int HD> struct StreamRec {
+    static constexpr int kFloats = 16 * NB * HD + 32;        // o[16 NB][HD], lse[16 NB] padded to a 128-byte line
+};
+
+// What every workgroup of the launch (and of the merge launch) derives from the lengths: the decomposition and, per sequence, which
+// records hold its pieces.
+//   STREAM (above): workgroup w owns positions [w T, (w + 1) T).
+//   UNIFORM: when cutting EVERY sequence into the same number S = nwg / B of pieces of its own length is at least as balanced — the
+//   longest piece, ceil(longest sequence / S), is no longer than a stream range — the pieces are taken aligned to the sequences
+//   (workgroup w = piece w % S of sequence w / S): equal-length batches (the static trace) then have no workgroup that crosses a
+//   sequence boundary, and the decomposition IS the one the reference's heuristic (flash_api.cpp:258-323) would launch.
+// Both are pure functions of (lengths, nwg): the decode launch and the merge launch agree without exchanging anything.
+struct StreamGeom {
+    int T;            // stream: positions per workgroup
+    int S;            // uniform: pieces per sequence
+    bool uniform;
+};
+__device__ __forceinline__ StreamGeom stream_geom(const int total, const int maxt, const int B, const int nwg) {
+    StreamGeom g;
+    g.T = stream_tiles_per_wg(total, nwg);
+    g.S = nwg / B;
+    g.uniform = g.S >= 1 && (maxt + g.S - 1) / g.S <= g.T;
+    return g;
+}
+// records of sequence b (tiles at positions [excl + X, incl)): first record and count
+__device__ __forceinline__ void stream_seq_records(const StreamGeom& g, const int excl, const int incl, const int X, const int b, int& first_rec, int& cnt) {
+    if (g.uniform) {
+        const int t = incl - excl - X, per = (t + g.S - 1) / g.S;
+        first_rec = b * g.S + b;
+        cnt = (t + per - 1) / per;
+    } else {
+        const int first_w = (excl + X) / g.T, last_w = (incl - 1) / g.T;
+        first_rec = first_w + b;
+        cnt = last_w - first_w + 1;
+    }
+}
+
+// Plan prologue, per WAVE and in registers (no LDS, no barrier: the four waves of a workgroup derive the same plan side by side and each
+// starts its K/V stream as soon as ITS copy is done).  Lane l holds sequences [l << sh, (l + 1) << sh), sh = 0 / 1 / 2 for batches up
+// to 64 / 128 / 256: incl = positions of sequences 0..i (inclusive scan of tiles + switch allowance), slot, lk = cache slot and visible
+// length.  ONE memory latency (lengths and slots are fetched together), six shuffle steps.
+struct StreamPlan {
+    int incl[4], slot[4], lk[4];
+    int sh, total, maxt;
+};
+__device__ __forceinline__ void stream_plan_load(const vattn_attn_params& p, const int X, StreamPlan& pl) {
+    const int lane = threadIdx.x & 63;
+    const int B = p.b;
+    pl.sh = B <= 64 ? 0 : B <= 128 ? 1 : 2;
+    int sum = 0, mx = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int i = (lane << pl.sh) + e;
+        int t = 0;
+        pl.lk[e] = 0;
+        pl.slot[e] = 0;
+        if (e < (1 << pl.sh) && i < B) {
+            int lk = (p.cache_seqlens ? p.cache_seqlens[i] : p.seqlen_k);
+            lk = (lk < 0 ? 0 : lk) + p.seqlen_knew;
+            lk = lk > p.seqlen_k ? p.seqlen_k : lk;                  // never beyond the rows of the cache view (decode_body)
+            pl.lk[e] = lk;
+            pl.slot[e] = p.cache_batch_idx ? p.cache_batch_idx[i] : i;
+            t = (lk > 0 ? (lk + DC_BN - 1) / DC_BN : 1);            // an empty sequence owns one (masked) tile: its rows get written
+            mx = max(mx, t);
+            t += X;
+        }
+        sum += t;
+        pl.incl[e] = sum;
+    }
+    int v = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    const int excl = v - sum;
+#pragma unroll
+    for (int e = 0; e < 4; e++) pl.incl[e] += excl;
+    pl.total = __builtin_amdgcn_readlane(v, 63);
+    pl.maxt = __builtin_amdgcn_readfirstlane(mx);
+}
+// element b of a per-lane array (b wave-uniform)
+__device__ __forceinline__ int stream_plan_get(const int (&a)[4], const int sh, const int b) {
+    const int e = b & ((1 << sh) - 1), l = b >> sh;
+    const int v = e == 0 ? a[0] : e == 1 ? a[1] : e == 2 ? a[2] : a[3];
+    return __builtin_amdgcn_readlane(v, l);
+}
+// the sequence whose positions [excl, incl) hold position g (g < total)
+__device__ __forceinline__ int stream_plan_find(const StreamPlan& pl, const int g) {
+    const int lane = threadIdx.x & 63;
+    int lo = __shfl_up(pl.incl[3], 1, 64);
+    if (lane == 0) lo = 0;
+    int hit = -1;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (lo <= g && g < pl.incl[e]) hit = e;
+        lo = pl.incl[e];
+    }
+    const unsigned long long m = __ballot(hit >= 0);
+    const int l = __builtin_ctzll(m);
+    return (l << pl.sh) + __builtin_amdgcn_readlane(hit, l);
+}
+
+__device__ __forceinline__ void stream_publish_seq(const vattn_attn_params& p, const int b, const int first_rec, const int cnt) {
+    int* t = (int*)p.workspace + 2 * b;
+    t[0] = first_rec;
+    t[1] = cnt;
+}
+
+// LSE-weighted merge of records [first_rec, first_rec + cnt) of (kv head hk, group gb) into the output rows of sequence b, by one
+// 256-thread workgroup: a thread owns four columns of one head row, walks the records in chunks of CH with every load of a chunk
+// in flight at once (device-scope loads: the records were written by other workgroups of this launch) and folds the chunks together
+// like an online softmax (running maximum, running weight sum) — any number of records, one pass.
+template <typename T, int HD, int NB, int CH = 8, int SCOPE = kDevScope>
+__device__ __forceinline__ void decode_stream_merge(const vattn_attn_params& p, const int first_rec, const int cnt, const int hk, const int gb,
+                                                    const int gblocks, const int b) {
+    using X = Tr<T>;
+    constexpr int RF = StreamRec<NB, HD>::kFloats;
+    const int tid = threadIdx.x;
+    const int G = p.h / p.h_k;
+    const __amdgpu_buffer_rsrc_t wsr = make_rsrc(p.workspace, 0x7fffffffu);
+    const unsigned blk_stride = (unsigned)p.h_k * (unsigned)gblocks * RF * 4u;                 // bytes between consecutive records
+    const unsigned blk0 = stream_table_bytes(p.b) + ((unsigned)first_rec * p.h_k * gblocks + (unsigned)hk * gblocks + gb) * RF * 4u;
+    for (int i4 = tid; i4 < 16 * NB * (HD / 4); i4 += 256) {
+        const int r16 = i4 / (HD / 4), d0 = (i4 % (HD / 4)) * 4;
+        const int rh = gb * NB * 16 + r16;
+        if (rh >= G) continue;
+        const unsigned o_off = blk0 + (unsigned)(r16 * HD + d0) * 4u, l_off = blk0 + (unsigned)(16 * NB * HD + r16) * 4u;
+        float m = -INFINITY, wsum = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < cnt; s0 += CH) {
+            float l[CH];
+            u32x4 v[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const int s = s0 + j < cnt ? s0 + j : cnt - 1;      // (the tail of the last chunk re-reads the last record, weight 0)
+                l[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wsr, (int)(l_off + (unsigned)s * blk_stride), 0, SCOPE));
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(wsr, (int)(o_off + (unsigned)s * blk_stride), 0, SCOPE);
+            }
+            float cm = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                if (s0 + j >= cnt) l[j] = -INFINITY;
+                cm = fmaxf(cm, l[j]);
+            }
+            const float m_new = fmaxf(m, cm);
+            const float mns = (m_new == -INFINITY) ? 0.f : m_new;
+            const float r = fast_exp2(m - mns);
+            wsum *= r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[e] *= r;
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const float w = fast_exp2(l[j] - mns);
+                f32x4 a;
+                __builtin_memcpy(&a, &v[j], 16);
+                wsum += w;
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] += w * a[e];
+            }
+            m = m_new;
+        }
+        const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+        const int hh = hk * G + rh;
+        typename X::v4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o4[e] = X::cvt(acc[e] * inv);
+        *(typename X::v4*)((T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d0) = o4;
+        if (p.softmax_lse && d0 == 0)
+            p.softmax_lse[(int64_t)b * p.h + hh] = (wsum == 0.f) ? INFINITY : (((m == -INFINITY) ? 0.f : m) + __log2f(wsum)) * 0.6931471805599453f;
+    }
+}
+
+// nwg: workgroups per (kv head, group) = gridDim.x.  counters: NULL (product): the partials are merged by decode_stream_combine_kernel in a
+// second launch; LAB: one zero-initialised int per (sequence, kv head, group), left zero by the launch (the merging workgroup resets its
+// counter): merge inside the launch.
+template <typename T, int HD, bool USE_TR, int NB>
+__global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_kernel(vattn_attn_params p, int gblocks, int fused_append, int* counters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_ticket;                           // (lab: in-launch merge)
+    __shared__ int s_plan[3 * DC_MAXB];                // stream mode: the plan, for the pieces after the first
+    const int tid = threadIdx.x;
+    // grid (workgroups per head, kv heads): consecutive workgroup ids — consecutive XCDs — stream consecutive ranges of ONE kv head.  [The
+    // kv head as the fastest index (the heads of one range dispatched together) measured 5-7 % slower on every shape, profiles/r04_decode_stream.txt.]
+    const int hk = blockIdx.y / gblocks, gb = blockIdx.y % gblocks;
+    const int nwg = gridDim.x, w = blockIdx.x;
+    const int X = stream_switch_tiles(p);
+    constexpr unsigned RB = StreamRec<NB, HD>::kFloats * 4u;
+    StreamPlan pl;
+    stream_plan_load(p, X, pl);
+    const StreamGeom geo = stream_geom(pl.total, pl.maxt, p.b, nwg);
+    auto publish_and_merge = [&](const int b, const int first_rec, const int cnt) {      // LAB: in-launch merge
+        // publish: this workgroup's record stores have left the CU (write-through), then ONE device-scope ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(counters + ((int64_t)b * p.h_k + hk) * gblocks + gb, 1);
+        __syncthreads();
+        if (s_ticket == cnt - 1) {
+            decode_stream_merge<T, HD, NB>(p, first_rec, cnt, hk, gb, gblocks, b);
+            if (tid == 0) __hip_atomic_store(counters + ((int64_t)b * p.h_k + hk) * gblocks + gb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // the current piece (all wave-uniform): sequence, its slot and visible length, tiles [tb, te), the sequence's records
+    int b, slot, lk, tb, te, first_rec, cnt;
+    int g0 = 0, g1 = 0;
+    // stream mode: the first piece at or after sequence `from` that holds real tiles of this workgroup's range (plan read from LDS)
+    auto next_piece = [&](const int from) -> bool {
+        for (b = from; b < p.b; b++) {
+            const int excl = __builtin_amdgcn_readfirstlane(b ? s_plan[b - 1] : 0);
+            if (excl >= g1) return false;
+            const int incl = __builtin_amdgcn_readfirstlane(s_plan[b]);
+            const int real0 = excl + X;                  // the sequence's tile r sits at position real0 + r
+            tb = max(g0, real0) - real0;
+            te = min(g1, incl) - real0;
+            if (te <= tb) continue;                      // this range only holds (part of) the sequence's switch allowance
+            stream_seq_records(geo, excl, incl, X, b, first_rec, cnt);
+            slot = __builtin_amdgcn_readfirstlane(s_plan[DC_MAXB + b]);
+            lk = __builtin_amdgcn_readfirstlane(s_plan[2 * DC_MAXB + b]);
+            return true;
+        }
+        return false;
+    };
+    if (geo.uniform) {
+        // piece w % S of sequence w / S: each sequence divides ITS OWN tiles into S pieces; everything from the plan's registers
+        b = w / geo.S;
+        const int sidx = w - b * geo.S;
+        if (b >= p.b) return;
+        const int excl = b ? stream_plan_get(pl.incl, pl.sh, b - 1) : 0, incl = stream_plan_get(pl.incl, pl.sh, b);
+        const int t = incl - excl - X, per = (t + geo.S - 1) / geo.S;
+        tb = sidx * per;
+        te = min(t, tb + per);
+        if (te <= tb) return;
+        cnt = (t + per - 1) / per;
+        first_rec = b * geo.S + b;
+        slot = stream_plan_get(pl.slot, pl.sh, b);
+        lk = stream_plan_get(pl.lk, pl.sh, b);
+    } else {
+        g0 = w * geo.T;
+        if (g0 >= pl.total) return;
+        g1 = min(pl.total, g0 + geo.T);
+        // the range may hold several sequences: the plan moves to LDS (every wave stores the SAME values and reads only after its own
+        // stores: no barrier), so that its twelve registers are not carried through the key loops
+        const int b0 = stream_plan_find(pl, g0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = ((tid & 63) << pl.sh) + e;
+            if (e < (1 << pl.sh) && i < p.b) {
+                s_plan[i] = pl.incl[e];
+                s_plan[DC_MAXB + i] = pl.slot[e];
+                s_plan[2 * DC_MAXB + i] = pl.lk[e];
+            }
+        }
+        if (!next_piece(b0)) return;
+    }
+    for (;;) {
+        const unsigned blk = stream_table_bytes(p.b) + (((unsigned)(w + b) * p.h_k + hk) * gblocks + gb) * RB;
+        if (tb == 0 && hk == 0 && gb == 0 && tid == 0) stream_publish_seq(p, b, first_rec, cnt);      // (the owner of the sequence's first piece)
+        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, 0, tb, te, cnt == 1 ? 1 : (kLab && counters) ? 3 : 2, slot, lk, blk);
+        if (kLab && cnt > 1 && counters != nullptr) publish_and_merge(b, first_rec, cnt);      // product: the records are merged by decode_stream_combine_kernel
+        if (geo.uniform || !next_piece(b + 1)) return;
+        __syncthreads();                                 // the previous piece's in-workgroup merge is done with the LDS
+    }
+}
+
+// The merge as a second launch: one workgroup per (sequence, kv head x group) merges the sequence's records (nothing to do for sequences
+// that one workgroup wrote directly).
+template <typename T, int HD, int NB>
+__global__ __launch_bounds__(256) void decode_stream_combine_kernel(vattn_attn_params p, int gblocks) {
+    const int b = blockIdx.x, hk = blockIdx.y / gblocks, gb = blockIdx.y % gblocks;
+    const int* t = (const int*)p.workspace + 2 * b;
+    const int first_rec = __builtin_amdgcn_readfirstlane(t[0]), cnt = __builtin_amdgcn_readfirstlane(t[1]);
+    if (cnt <= 1) return;
+    decode_stream_merge<T, HD, NB, 16, 0>(p, first_rec, cnt, hk, gb, gblocks, b);      // (up to 16 records in ONE round trip)
 }
 
 // gblocks = head-block GROUPS per kv head (ceil(ceil(G/16) / NB)).  `done`: NULL = partials are merged by combine_kernel in a second

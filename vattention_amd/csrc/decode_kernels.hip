@@ -3,6 +3,9 @@
 // stage, fp32 online softmax, in-workgroup merge of the 4 waves, new K/V row appended in-kernel, LSE-weighted combine across
 // splits (combine_kernel; flash_fwd_kernel.h:1116-1297).  Call-site semantics: flash_api.cpp:1367-1378,1451-1454,1558-1560.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "attn_common.h"
 
@@ -183,7 +186,78 @@ static inline bool decode_inline_merge(const vattn_attn_params* p, int splits, i
     (void)groups;
     return splits > 1 && (p->variant & (512 | 1024)) != 0;      // bit 9: fence protocol, bit 10: device-scope accesses, no fence
 }
+// Device-planned stream decomposition (decode_body.h, decode_stream_kernel): the host only picks the number of workgroups per (kv head,
+// head-block group) — from the batch size and the cache VIEW's row count, which the reference's wrapper makes the batch's longest
+// context (vattention_flashattention_wrapper.py:196-197: `kv_cache[0][:, :self.max_cache_len]`) — the lengths stay on the device.
+// One round of the resident workgroups; fewer when the batch is small or its contexts short (see per_seq below).  0 = take the grid
+// heuristics of rounds 1-3: ONE sequence (nothing to balance: its uniform split is the optimum and needs no plan prologue), GQA groups
+// wider than 16 heads, batches beyond DC_MAXB, explicit num_splits > 0, variant bit 19.  num_splits = -N forces N workgroups per group (tests, A/B).
+int stream_nwg(const vattn_attn_params* p) {
+    if (p->seqlen_q != 1 || p->split_items || p->num_splits > 0 || (p->variant & kVariantLegacyDecodePlan)) return 0;
+    if (p->b > DC_MAXB || decode_groups(p) != 1) return 0;
+    if (kLab && (decode_shape(p) || decode_pf2(p) || (p->variant & (1 | 256)) || decode_inline_merge(p, 2, 1))) return 0;      // lab shapes / protocols keep the old grid
+    const long slots = decode_nb(p) == 2 ? 512 : 768;      // resident workgroups of decode_stream_kernel (its launch bounds)
+    const long gps = p->h_k;
+    if (p->num_splits < 0) return (int)std::min<long>(-(long)p->num_splits, 65535);
+    // ONE sequence has nothing to balance, and the two-block workgroups of wide GQA groups (16 < G <= 32) measure 16 % slower on this path
+    // (mqa G32 B16 @ 16 k: 42.5 vs 36.5 us): both keep the grid heuristics
+    if (p->b < 2 || decode_nb(p) == 2) return 0;
+    const long max_tiles = std::max(1L, ((long)p->seqlen_k + DC_BN - 1) / DC_BN);      // (seqlen_k rows already hold the appended token)
+    // pieces per sequence, on average: at least one tile per wave and piece, at most 48 (pick_splits' measurements: a piece shorter than
+    // ~700 keys costs more in prologue and merge than it returns once the chip is full, short contexts still want every CU busy)
+    const long per_seq = std::min(48L, std::max(1L, max_tiles / 4));
+    return (int)std::min(std::max(1L, slots / gps), (long)p->b * per_seq);
+}
+static size_t stream_workspace_bytes(const vattn_attn_params* p, int nwg) {
+    const size_t rf = decode_nb(p) == 2 ? (size_t)(32 * p->d + 32) : (size_t)(16 * p->d + 32);
+    return stream_table_bytes(p->b) + (size_t)(nwg + p->b) * p->h_k * rf * sizeof(float);      // (first record, count) per sequence, then the records
+}
+
+// LAB ONLY (variant bit 20; measured equal or slower than the second launch on every shape: ragged 256 sequences 0.223 vs 0.219 ms,
+// B16 @ 32 k 0.200 vs 0.198, B1 @ 32 k 24.3 vs 22.4 us — profiles/r04_decode_stream.txt: the publishing side drains its write-through
+// stores and waits for a device-scope ticket, one workgroup reads all pieces of a sequence).
+// Tickets of the in-launch merge: one int per (sequence, kv head), zero between launches (the merging workgroup resets its own).  One
+// buffer per (device, stream), created — and zeroed, stream-ordered — on first use; never while the stream is being captured into a
+// graph (the launch then takes the two-launch merge; a warm-up call before the capture creates the buffer).
+static int* stream_counters(hipStream_t st, size_t n_ints) {
+    struct Buf { int* p; size_t n; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    Buf& b = bufs[std::make_pair(dev, st)];
+    if (b.p && b.n >= n_ints) return b.p;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    const size_t n = std::max<size_t>(n_ints, 1 << 16);
+    int* np = nullptr;
+    if (hipMalloc((void**)&np, n * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemsetAsync(np, 0, n * sizeof(int), st) != hipSuccess) { (void)hipFree(np); return nullptr; }
+    b.p = np;      // (an older, smaller buffer may still be in use by queued launches: leaked on purpose, at most once per growth step)
+    b.n = n;
+    return np;
+}
+
+template <typename T, int HD, int NB> int launch_decode_stream(const vattn_attn_params* p, hipStream_t st, int nwg) {
+    if (!p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
+    if (stream_workspace_bytes(p, nwg) >= 0x7fffffffull) return fail(VATTN_K_ERR_UNSUPPORTED, "decode batch too large for the 32-bit record offsets");
+    const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;
+    const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
+    if (p->k_new && !fused_append) launch_append(p, st);
+    int* counters = (kLab && (p->variant & kVariantInLaunchMerge)) ? stream_counters(st, (size_t)p->b * p->h_k) : nullptr;
+    hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB>), dim3((unsigned)nwg, (unsigned)p->h_k), dim3(64 * DC_WAVES), smem, st, *p, 1, fused_append, counters);
+    if (!counters) hipLaunchKernelGGL((decode_stream_combine_kernel<T, HD, NB>), dim3((unsigned)p->b, (unsigned)p->h_k), dim3(256), 0, st, *p, 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
+    return VATTN_K_OK;
+}
+
 template <typename T, int HD, int NB, int W = DC_WAVES, int PF = 1> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
+    if constexpr (W == DC_WAVES && PF == 1) {
+        const int nwg = stream_nwg(p);
+        if (nwg > 0) return launch_decode_stream<T, HD, NB>(p, st, nwg);
+    }
     const bool use_tr = (p->variant & 1) == 0 || W != DC_WAVES || PF != 1;
     const int groups = decode_groups(p);
     const bool planned = p->split_items != nullptr;
@@ -327,6 +401,7 @@ int decode_plan(const vattn_attn_params* p, const int32_t* lens, vattn_decode_it
 }
 
 size_t decode_workspace_bytes(const vattn_attn_params* p) {
+    if (const int nwg = stream_nwg(p)) return stream_workspace_bytes(p, nwg);
     if (p->split_items) return (size_t)(p->num_split_items > 0 ? p->num_split_items : 0) * p->h * (p->d + 1) * sizeof(float);
     const int groups = decode_groups(p);
     const int splits = pick_splits(p, groups, decode_slots(p));

@@ -30,6 +30,7 @@ from . import kernels as K
 
 APPEND_ERR = "If key is supplied, it must have seqlen <= the seqlen of the KV cache"
 _workspaces = {}
+_STREAM_SWITCH = 0      # tuning hook of tools/: 1 + switch allowance of the stream decode plan (0: the library's default)
 _rotary_cat = {}      # (id(cos), id(sin), versions, dtype) -> (cos, sin, the [S, rotary_dim] cat(cos, sin) tensor the kernels read)
 
 
@@ -227,6 +228,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.num_splits = int(num_splits)
     p.softmax_scale = float(softmax_scale)
     p.variant = int(_variant)
+    p.split_reserved = _STREAM_SWITCH
     p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
     if rot is not None:
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]

@@ -43,7 +43,8 @@ class DecodeItem(C.Structure):
 _bound = False
 _lab = None
 # variant bits the PRODUCT library accepts (csrc/attn_common.h, kProductVariantMask) and the tilings among bits 1-3
-PRODUCT_VARIANT_MASK = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12)
+LEGACY_DECODE_PLAN, IN_LAUNCH_MERGE = 1 << 19, 1 << 20      # decode A/B selectors (csrc/attn_common.h); the second is lab-only
+PRODUCT_VARIANT_MASK = (7 << 1) | (3 << 5) | (1 << 7) | (3 << 12) | LEGACY_DECODE_PLAN
 PRODUCT_TILINGS = (0, 1, 4, 7)
 
 
