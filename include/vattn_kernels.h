@@ -106,17 +106,19 @@ typedef struct vattn_attn_params {
 typedef struct vattn_prefill_item {
     int32_t b, h, qb;     /* batch entry, query head, 256-row query block                                                    */
     int32_t tile_begin;   /* first 64-key tile of the piece (pf_blocks: unused)                                              */
-    int32_t tile_end;     /* one past its last tile                                                                          */
+    int32_t tile_end;     /* one past its last tile; INT32_MAX for the block's last share: "to the last tile the block sees" —
+                             the kernel clamps every range to what the DEVICE-side lengths give, so a list built from stale
+                             host lengths costs balance, never keys                                                          */
     int32_t nshares;      /* pieces the query block was cut into; 1 = this piece writes the output rows itself               */
     int32_t part_row;     /* nshares > 1: first of this piece's 256 partial rows (pf_blocks: of the block's share 0; share s
                              sits 256 * s rows further)                                                                      */
-    int32_t reserved;
+    int32_t reserved;     /* 1 on the block's last share                                                                     */
 } vattn_prefill_item;
 
 typedef struct vattn_decode_item {
     int32_t b;            /* batch entry                                            */
     int32_t tile_begin;   /* first 32-key tile of the piece                         */
-    int32_t tile_end;     /* one past its last tile                                 */
+    int32_t tile_end;     /* one past its last tile; INT32_MAX on the sequence's last piece (open-ended, see vattn_prefill_item) */
     int32_t index_in_seq; /* 0 .. count-1 within the sequence                       */
 } vattn_decode_item;
 
@@ -141,6 +143,22 @@ int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqle
  * p->num_splits = -T forces pieces of at most T tiles (tests, A/B measurements).  Pure host arithmetic. */
 int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
                            int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* counts_out);
+
+/* What vattn_flash_attn_with_kvcache will launch for `p` — pure host arithmetic on the shapes (pointers are only tested for NULL), so a
+ * test can pin the launch plans without a GPU and without a stopwatch (tests/test_plan_table.py; the reference's equivalents are the
+ * launch heuristics of flash_api.cpp:258-323 and flash_fwd_launch_template.h:100-162).  Returns 0, or VATTN_K_ERR_INVALID. */
+typedef struct vattn_plan_desc {
+    int32_t form;          /* 0 = prefill (seqlen_q > 1), 1 = decode                                                              */
+    int32_t path;          /* prefill: 0 = grid order, 1 = work list (pf_items).  decode: 0 = uniform split of every sequence (grid
+                              heuristics), 1 = host item plan (split_items), 2 = device-planned stream decomposition               */
+    int32_t tiling;        /* prefill: 1 = 8 waves x 32 rows, 4 = 4 waves x 32 rows, 7 = prefill64 (4 waves x 64 rows).
+                              decode: 16-head blocks per workgroup (1 or 2)                                                        */
+    int32_t nsplit;        /* key-range shares per work item of the grid paths (1 = none); 0 on the list / item / stream paths      */
+    int32_t workgroups;    /* workgroups of the main launch that hold work (grid padding excluded)                                 */
+    int32_t merge_launch;  /* 1 = a second launch merges fp32 partials                                                             */
+    int64_t workspace_bytes;
+} vattn_plan_desc;
+int vattn_attn_plan_describe(const vattn_attn_params* p, vattn_plan_desc* out);
 
 /* flash_attn_with_kvcache: appends k_new/v_new (if given) and attends; prefill form (seqlen_q > 1,
  * causal chunk against the growing cache) and decode form (seqlen_q == 1, split-KV + combine). */

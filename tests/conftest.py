@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock comparisons on a real MI355X (run with -m perf; never part of -m gpu: a slow box must not fail the correctness suite)")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -23,5 +24,5 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="no GPU in this environment")
     for item in items:
-        if "gpu" in item.keywords:
+        if "gpu" in item.keywords or "perf" in item.keywords:
             item.add_marker(skip)

@@ -71,13 +71,19 @@ int main(void) {
         p.b = 64; p.seqlen_q = 1; p.seqlen_k = 32768; p.seqlen_knew = 1; p.h = 8; p.h_k = 1; p.d = 128;
         for (i = 0; i < 64; i++) dlens[i] = 500 + 450 * i;                         /* 500 .. 28 850 tokens */
         n = vattn_decode_plan(&p, dlens, ditems, 4096, dseq);
-        for (i = 0; i < n; i++) if (ditems[i].tile_end - ditems[i].tile_begin > longest) longest = ditems[i].tile_end - ditems[i].tile_begin;
+        for (i = 0; i < n; i++) {      /* (a sequence's last piece is open-ended, INT32_MAX: it runs to the sequence's last tile) */
+            const int32_t tiles = (dlens[ditems[i].b] + 1 + 31) / 32;
+            const int32_t te = ditems[i].tile_end < tiles ? ditems[i].tile_end : tiles;
+            if (te - ditems[i].tile_begin > longest) longest = te - ditems[i].tile_begin;
+        }
         printf("decode_plan items %d first_seq_pieces %d last_seq_pieces %d longest_piece_tiles %d\n", n, dseq[1], dseq[127], longest);
         memset(&p, 0, sizeof p);
         p.b = 1; p.seqlen_q = 8192; p.h = 8; p.h_k = 1; p.d = 128; p.is_causal = 1;
         n = vattn_prefill_plan(&p, qlen, klen, pitems, 4096, pblocks, 512, counts);
         printf("prefill_plan items %d split_blocks %d partial_rows %d first_piece_tiles %d last_piece_tiles %d\n", n, counts[1], counts[2],
-               pitems[0].tile_end - pitems[0].tile_begin, pitems[n > 0 ? n - 1 : 0].tile_end - pitems[n > 0 ? n - 1 : 0].tile_begin);
+               /* (a block's last share is open-ended: causal whole prompt, query block qb sees 4 (qb + 1) tiles of 64 keys) */
+               (pitems[0].tile_end < 4 * (pitems[0].qb + 1) ? pitems[0].tile_end : 4 * (pitems[0].qb + 1)) - pitems[0].tile_begin,
+               (pitems[n > 0 ? n - 1 : 0].tile_end < 4 * (pitems[n > 0 ? n - 1 : 0].qb + 1) ? pitems[n > 0 ? n - 1 : 0].tile_end : 4 * (pitems[n > 0 ? n - 1 : 0].qb + 1)) - pitems[n > 0 ? n - 1 : 0].tile_begin);
         p.q = p.out = p.k_cache = p.v_cache = &p;      /* (never dereferenced: validation stops at the variant) */
         p.seqlen_k = 8192; p.dtype = VATTN_DTYPE_F16;
         p.q_row_stride = p.q_head_stride = p.q_batch_stride = p.k_row_stride = p.k_head_stride = p.k_batch_stride = 8;

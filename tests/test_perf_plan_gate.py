@@ -1,4 +1,4 @@
-"""Gate on the prefill launch plan (csrc/prefill_kernels.hip, plan_prefill): on the short / underfilled shapes where the plan has to
+"""`pytest -m perf` / tools/plan_gate.py.  Gate on the prefill launch plan (csrc/prefill_kernels.hip, plan_prefill): on the short / underfilled shapes where the plan has to
 choose a tiling and a KV split, the DEFAULT plan must not lose to any explicit tiling of the product library by more than 3 %
 (+ a 3 us allowance for launch jitter on these 40-200 us kernels).  Timed through the C ABI (vattn_time_attn, HIP events on the launch
 stream), best of three repetitions of 20 launches each (the plan: of six, three before and three after the explicit tilings)."""
@@ -7,7 +7,7 @@ import ctypes as C
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.perf      # NOT gpu: wall-clock assertions stay out of the correctness suite (the plans are pinned by tests/test_plan_table.py)
 DEV = torch.device("cuda:0")
 
 SHAPES = [("small 2k (32/4 heads)", 32, 4, 2048, 0), ("llama70b/tp8 2k", 8, 1, 2048, 0), ("llama70b/tp8 4k", 8, 1, 4096, 0),

@@ -165,7 +165,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                                num_splits=num_splits, _rotary_cos_sin=self._rotary,
                                                _max_seqlen_k=max(c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)),
                                                _pf_plan=self._prefill_plan("varlen", self.prefill_query_lens,
-                                                                           [c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)]))
+                                                                           [c + n for c, n in zip(self.prefill_cache_lens, self.prefill_query_lens)], num_splits))
             return tok
         tok = 0
         for i, (c_len, q_len) in enumerate(zip(self.prefill_cache_lens, self.prefill_query_lens)):
@@ -189,13 +189,16 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                         causal=True, softmax_scale=softmax_scale,
                                         out=output[tok:tok + q_len].view(1, q_len, Hq, D), _max_seqlen_k=c_len + q_len,
                                         num_splits=num_splits, _rotary_cos_sin=self._rotary,
-                                        _pf_plan=self._prefill_plan(i, [q_len], [c_len + q_len]) if q_len > 1 else None)
+                                        _pf_plan=self._prefill_plan(i, [q_len], [c_len + q_len], num_splits) if q_len > 1 else None)
             tok += q_len
         return tok
 
-    def _prefill_plan(self, key, q_lens, k_lens):
+    def _prefill_plan(self, key, q_lens, k_lens, num_splits: int = 0):
         """The work list of one prefill call site of this iteration (flash_attn.prefill_plan: host arithmetic + one small H2D copy),
-        built by the first layer that gets here and shared by the others — it depends on the lengths only."""
+        built by the first layer that gets here and shared by the others — it depends on the lengths only.  None when the call cannot
+        take a list anyway (an explicit split count, or the call is being recorded for the fused prefill || decode launch)."""
+        if num_splits != 0 or _FA._capture_active():
+            return None
         pl = self._pf_plans.get(key)
         if pl is None and self.head_dim == 128:
             import ctypes as C

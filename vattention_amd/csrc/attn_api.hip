@@ -264,6 +264,15 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
     return p->seqlen_q == 1 ? launch_decode_form(p, st) : launch_prefill_form(p, st);
 }
 
+int vattn_attn_plan_describe(const vattn_attn_params* p, vattn_plan_desc* out) {
+    if (!p || !out || p->h_k <= 0 || p->h <= 0 || p->b <= 0 || p->seqlen_q <= 0 || (p->d != 64 && p->d != 128)) return fail(VATTN_K_ERR_INVALID, "vattn_attn_plan_describe: bad shape");
+    memset(out, 0, sizeof *out);
+    if (p->seqlen_q == 1) decode_describe(p, out);
+    else prefill_describe(p, out);
+    out->workspace_bytes = (int64_t)vattn_attn_workspace_bytes(p);
+    return VATTN_K_OK;
+}
+
 int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqlens_host, vattn_decode_item* items_out, int32_t cap, int32_t* seq_out) {
     return decode_plan(p, cache_seqlens_host, items_out, cap, seq_out);
 }

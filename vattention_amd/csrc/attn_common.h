@@ -267,6 +267,8 @@ int* merge_counters(hipStream_t st, size_t n_ints);                      // attn
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
 size_t decode_workspace_bytes(const vattn_attn_params* p);
 int decode_plan(const vattn_attn_params* p, const int32_t* lens, vattn_decode_item* items, int cap, int32_t* seq);   // decode_kernels.hip
+void prefill_describe(const vattn_attn_params* p, vattn_plan_desc* out);   // prefill_kernels.hip
+void decode_describe(const vattn_attn_params* p, vattn_plan_desc* out);    // decode_kernels.hip
 int launch_hybrid(const vattn_attn_params* prefill, const vattn_attn_params* decode, void* ws, hipStream_t st);   // hybrid_kernels.hip
 size_t hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode);
 

@@ -392,12 +392,34 @@ int decode_plan(const vattn_attn_params* p, const int32_t* lens, vattn_decode_it
             if (te > t) te = t;
             items[n].b = b;
             items[n].tile_begin = (int32_t)tb;
-            items[n].tile_end = (int32_t)te;
+            // (the last piece of a sequence is open-ended: the kernel clamps to the tiles the DEVICE-side length gives, so stale host
+            // lengths cost balance, never keys)
+            items[n].tile_end = j == cnt - 1 ? 0x7fffffff : (int32_t)te;
             items[n].index_in_seq = (int32_t)j;
             n++;
         }
     }
     return n;
+}
+
+void decode_describe(const vattn_attn_params* p, vattn_plan_desc* out) {
+    out->form = 1;
+    out->tiling = decode_nb(p);
+    const int groups = decode_groups(p);
+    if (const int nwg = stream_nwg(p)) {
+        out->path = 2;
+        out->workgroups = nwg * p->h_k;
+        out->merge_launch = 1;
+    } else if (p->split_items) {
+        out->path = 1;
+        out->workgroups = p->num_split_items * p->h_k * groups;
+        out->merge_launch = 1;
+    } else {
+        out->path = 0;
+        out->nsplit = pick_splits(p, groups, decode_slots(p));
+        out->workgroups = out->nsplit * p->h_k * groups * p->b;
+        out->merge_launch = out->nsplit > 1;
+    }
 }
 
 size_t decode_workspace_bytes(const vattn_attn_params* p) {

@@ -431,8 +431,12 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     if (!kLab && (pl.tiling == 2 || pl.tiling == 6)) pl.tiling = 1;     // lab-only kernels (validate() rejects them before this)
     if (pl.tiling == 6 && (p->q_lens || p->rotary_cos_sin)) pl.tiling = 1;      // the interleaved kernel has no batched-chunk / fused-RoPE form
     if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
-    // keys an average query block sees; without a host-side length only the chunk itself is certain
-    const long lk = p->max_seqlen_k_hint > 0 ? p->max_seqlen_k_hint : p->seqlen_q;
+    // keys an average query block sees.  Without a host-side bound the cache VIEW's row count stands in for the lengths, exactly as in
+    // FlashAttention's own heuristic (flash_api.cpp:258-323 sizes the split from seqlen_k = k_cache.size(1)); the kernels divide the keys a
+    // block REALLY sees (device-side lengths), so an over-estimate costs balance, never correctness.  [Rounds 1-3 assumed seqlen_q here:
+    // a chunk on a long prefix then never got its key range split — 393 instead of 900-1050 TFLOP/s on a tensor-parallel shard.]
+    const long lk_view = (long)p->seqlen_k + p->seqlen_knew;
+    const long lk = p->max_seqlen_k_hint > 0 ? p->max_seqlen_k_hint : (lk_view > p->seqlen_q ? lk_view : p->seqlen_q);
     const long keys = p->is_causal ? (lk - p->seqlen_q / 2) : lk;
     const long tiles = keys > 0 ? (keys + PF_BN - 1) / PF_BN : 1;
     auto cap_by_tiles = [&](long want) {                             // >= 8 tiles (512 keys) per split: below that the
@@ -765,7 +769,7 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
                     long tb = s_ * per, te = tb + per;
                     if (tb > t) tb = t;
                     if (te > t) te = t;
-                    items[n] = vattn_prefill_item{e, h, qb, (int32_t)tb, (int32_t)te, (int32_t)ns, ns > 1 ? (int32_t)(part_rows + 256 * s_) : -1, 0};
+                    items[n] = vattn_prefill_item{e, h, qb, (int32_t)tb, (int32_t)te, (int32_t)ns, ns > 1 ? (int32_t)(part_rows + 256 * s_) : -1, s_ == ns - 1 ? 1 : 0};
                     n++;
                 }
                 if (ns > 1) part_rows += 256 * ns;
@@ -776,6 +780,11 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
     std::stable_sort(items, items + n, [](const vattn_prefill_item& a, const vattn_prefill_item& c) {
         return (a.tile_end - a.tile_begin) > (c.tile_end - c.tile_begin);
     });
+    // The list is a PERFORMANCE hint, never a statement about the data: the last share of every query block is open-ended (the kernel
+    // clamps every range to the tiles the block really sees, computed from the device-side lengths), so a caller whose host-side lengths
+    // are stale gets the right result at a worse balance instead of dropped keys.
+    for (int i = 0; i < n; i++)
+        if (items[i].reserved) items[i].tile_end = 0x7fffffff;
     counts[0] = n;
     counts[1] = nb;
     counts[2] = (int32_t)part_rows;
@@ -786,6 +795,23 @@ int launch_prefill_form(const vattn_attn_params* p, hipStream_t st) {
     const bool f16 = p->dtype == VATTN_DTYPE_F16;
     if (p->d == 64) return f16 ? launch_prefill_t<_Float16, 64>(p, st) : launch_prefill_t<__bf16, 64>(p, st);
     return f16 ? launch_prefill_t<_Float16, 128>(p, st) : launch_prefill_t<__bf16, 128>(p, st);
+}
+
+void prefill_describe(const vattn_attn_params* p, vattn_plan_desc* out) {
+    out->form = 0;
+    if (p->pf_items && p->d == 128) {
+        out->path = 1;
+        out->tiling = 7;
+        out->workgroups = p->num_pf_items;
+        out->merge_launch = p->num_pf_blocks > 0;
+        return;
+    }
+    const PrefillPlan pl = plan_prefill(p);
+    out->tiling = pl.tiling == 0 ? 1 : pl.tiling;
+    out->nsplit = pl.nsplit;
+    const int bm = pl.tiling == 7 ? 256 : pl.tiling == 4 ? 128 : 256;
+    out->workgroups = ((p->seqlen_q + bm - 1) / bm) * p->h * p->b * pl.nsplit;
+    out->merge_launch = pl.nsplit > 1;
 }
 
 size_t prefill_workspace_bytes(const vattn_attn_params* p) {

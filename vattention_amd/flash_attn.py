@@ -229,17 +229,28 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     p.softmax_scale = float(softmax_scale)
     p.variant = int(_variant)
     p.split_reserved = _STREAM_SWITCH
+    # Prefill form WITHOUT any host-side length (the reference's own call: vattention_flashattention_wrapper.py:159-166 passes the slot's
+    # whole row-block and `cache_seqlens` as a device tensor): the `vattention` drop-in was told every slot's length of this iteration in
+    # step_async(seq_lens) — resolve the row-block's address to its slot and take the length from there.  No device-to-host copy, no
+    # extra argument; a tensor that is not one of the page manager's leaves the view's row count as the bound (FlashAttention's own rule).
+    klens = _cache_seqlens_host
+    if Sq > 1 and hint == 0 and klens is None and cache_seqlens is not None and cache_batch_idx is None and k is None:
+        klens = _lengths_from_page_manager(k_cache, B)
+        if klens is not None:
+            hint = max(klens)
     p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
     if rot is not None:
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
     plan = None
     if Sq > 1 and D == 128 and num_splits == 0 and k is None and not _capture_active():
         # prefill form: a work list for underfilled / unbalanced grids.  `_pf_plan`: a plan object built earlier for the same lengths
-        # (the wrapper: one per iteration), or "host" = build it here from _cache_seqlens_host (the visible keys of every entry)
+        # (this package's wrapper: one per iteration), else built here — and kept, keyed on the shapes and lengths: the L layers of an
+        # iteration issue the same call — from the host-side lengths when there are any (_cache_seqlens_host, or the page manager's).
+        # The list is a performance hint only: its ranges are clamped to the device-side lengths (include/vattn_kernels.h).
         if isinstance(_pf_plan, _PrefillPlan):
             plan = _pf_plan
-        elif _pf_plan == "host" and _cache_seqlens_host is not None:
-            plan = prefill_plan(p, None, _cache_seqlens_host, dev)
+        elif klens is not None and (_pf_plan == "host" or _pf_plan is None) and not torch.cuda.is_current_stream_capturing():
+            plan = _cached_prefill_plan(p, klens, dev)
         if plan is not None:
             plan.attach(p)
     if _cache_seqlens_host is not None and Sq == 1 and B > 1 and num_splits == 0 and not torch.cuda.is_current_stream_capturing():
@@ -254,6 +265,61 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
         p._keep = (cache_seqlens, cache_batch_idx, rot, plan)
         _params_out.append(p)
     return (out, lse) if return_softmax_lse else out
+
+
+def _lengths_from_page_manager(k_cache, B: int):
+    """Visible tokens of the B row-blocks of `k_cache` according to the page manager's last step (vattention.resolve_view), or None."""
+    from . import vattention as _va
+    if _va._pm is None:
+        return None
+    ptr, step = k_cache.data_ptr(), k_cache.stride(0) * k_cache.element_size()
+    out = []
+    for b in range(B):
+        r = _va.resolve_view(ptr + b * step)
+        if r is None or r[1] > k_cache.shape[1]:
+            return None
+        out.append(r[1])
+    return out
+
+
+_plan_cache = {}      # (shapes, lengths, device) -> _PrefillPlan; a few dozen entries, dropped wholesale when full
+
+
+def _cached_prefill_plan(p, klens, dev):
+    key = (p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal, tuple(klens), dev.index)
+    pl = _plan_cache.get(key)
+    if pl is None:
+        if len(_plan_cache) >= 64:
+            _plan_cache.clear()
+        pl = _plan_cache[key] = prefill_plan(p, None, klens, dev)
+    return pl
+
+
+class _Staging:
+    """Pinned host buffers for the small plan tables: a pageable host-to-device copy is staged synchronously by the runtime (the host
+    thread waits behind whatever the stream has queued); from pinned memory the copy is queued like a launch.  A ring of 16 buffers, each
+    guarded by the event of its last copy."""
+    ring, events, pos = [], [], 0
+
+    @classmethod
+    def upload(cls, nbytes: int, fill, dev) -> torch.Tensor:
+        if not cls.ring:
+            cls.ring = [torch.empty(1 << 16, dtype=torch.uint8).pin_memory() for _ in range(16)]
+            cls.events = [None] * 16
+        i = cls.pos = (cls.pos + 1) % 16
+        if cls.ring[i].numel() < nbytes:
+            cls.ring[i] = torch.empty(max(nbytes, 2 * cls.ring[i].numel()), dtype=torch.uint8).pin_memory()
+            cls.events[i] = None
+        if cls.events[i] is not None:
+            cls.events[i].synchronize()
+        buf = cls.ring[i]
+        fill(buf.data_ptr())
+        t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        t.copy_(buf[:nbytes], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        cls.events[i] = ev
+        return t
 
 
 class _PrefillPlan:
@@ -297,11 +363,12 @@ def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0) -> _Pre
     if n == 0:
         return _PrefillPlan()
     nb = int(counts[1])
-    flat = torch.empty(8 * (n + nb), dtype=torch.int32)
-    C.memmove(flat.data_ptr(), items, 32 * n)
-    if nb:
-        C.memmove(flat.data_ptr() + 32 * n, blocks, 32 * nb)
-    return _PrefillPlan(flat.to(dev, non_blocking=True), n, nb, int(counts[2]))
+
+    def fill(dst):
+        C.memmove(dst, items, 32 * n)
+        if nb:
+            C.memmove(dst + 32 * n, blocks, 32 * nb)
+    return _PrefillPlan(_Staging.upload(32 * (n + nb), fill, dev), n, nb, int(counts[2]))
 
 
 def _decode_plan(p, lens_host, dev):
@@ -320,10 +387,10 @@ def _decode_plan(p, lens_host, dev):
         raise RuntimeError("vattn_decode_plan: bad arguments")
     if n == 0:
         return None
-    flat = torch.empty(4 * n + 2 * B, dtype=torch.int32)
-    C.memmove(flat.data_ptr(), items, 16 * n)
-    C.memmove(flat.data_ptr() + 16 * n, seq, 8 * B)
-    t = flat.to(dev, non_blocking=True)
+    def fill(dst):
+        C.memmove(dst, items, 16 * n)
+        C.memmove(dst + 16 * n, seq, 8 * B)
+    t = _Staging.upload(16 * n + 8 * B, fill, dev)
     p.split_items, p.split_seq, p.num_split_items = t.data_ptr(), t.data_ptr() + 16 * n, n
     return t
 

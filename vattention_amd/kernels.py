@@ -32,6 +32,10 @@ class AttnParams(C.Structure):
     ]
 
 
+class PlanDesc(C.Structure):
+    _fields_ = [("form", i32), ("path", i32), ("tiling", i32), ("nsplit", i32), ("workgroups", i32), ("merge_launch", i32), ("workspace_bytes", i64)]
+
+
 class PrefillItem(C.Structure):
     _fields_ = [("b", i32), ("h", i32), ("qb", i32), ("tile_begin", i32), ("tile_end", i32), ("nshares", i32), ("part_row", i32), ("reserved", i32)]
 
@@ -75,6 +79,8 @@ def _bind(lib):
     lib.vattn_prefill_plan.restype = i32
     lib.vattn_prefill_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(i32), C.POINTER(PrefillItem), i32, C.POINTER(PrefillItem), i32,
                                        C.POINTER(i32)]
+    lib.vattn_attn_plan_describe.restype = i32
+    lib.vattn_attn_plan_describe.argtypes = [C.POINTER(AttnParams), C.POINTER(PlanDesc)]
     lib.vattn_decode_plan.restype = i32
     lib.vattn_decode_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(DecodeItem), i32, C.POINTER(i32)]
     return lib
@@ -106,6 +112,15 @@ def klib_lab():
 
 def klib_for(variant: int):
     return klib_lab() if needs_lab(int(variant)) else klib()
+
+
+def describe(p, lib=None) -> dict:
+    """The launch plan of parameter block `p` (vattn_attn_plan_describe): pure host arithmetic."""
+    d = PlanDesc()
+    rc = (lib or klib()).vattn_attn_plan_describe(C.byref(p), C.byref(d))
+    if rc != 0:
+        raise RuntimeError(last_error(lib))
+    return {n: int(getattr(d, n)) for n, _ in d._fields_}
 
 
 def last_error(lib=None) -> str:

@@ -124,16 +124,26 @@ class ReplayStats:
 class HotPathRunner:
     """Owns the cache engine + wrapper for one GPU and replays scheduler iterations."""
 
-    def __init__(self, model: ModelConfig, parallel: ParallelConfig, cache: CacheConfig, device="cuda:0", seed=42):
+    def __init__(self, model: ModelConfig, parallel: ParallelConfig, cache: CacheConfig, device="cuda:0", seed=42, reference=None):
+        """reference: None = this package's wrapper + cache engine; else an object with `.wrapper` (an attention-wrapper INSTANCE) and
+        `.engine_cls` — tools/ref_wrapper_bench.py passes the REFERENCE's own classes (tests/ref_loader.py), which only know the
+        reference's API: no admission look-ahead, no layer-ordered mapping, no host-side hints."""
         from .attention import get_attention_wrapper, set_attention_backend
         from .cache_engine import get_cache_engine, get_cache_mem_alloc_backend
         self.model, self.parallel, self.cache_cfg = model, parallel, cache
         self.device = torch.device(device)
-        set_attention_backend(model.attention_backend)
-        self.wrapper = get_attention_wrapper()
-        self.wrapper.init(model, parallel, 0, self.device)
-        eng = get_cache_engine(model.attention_backend)
-        self.engine = eng(cache, model, parallel, get_cache_mem_alloc_backend(model.attention_backend))
+        if reference is not None:
+            from . import vattention as _va0
+            _va0.enable_layered_async(False)         # the reference wrapper does not gate layers: plain step_async semantics
+            self.wrapper = reference.wrapper
+            self.wrapper.init(model, parallel, 0, self.device)
+            self.engine = reference.engine_cls(cache, model, parallel, get_cache_mem_alloc_backend(model.attention_backend))
+        else:
+            set_attention_backend(model.attention_backend)
+            self.wrapper = get_attention_wrapper()
+            self.wrapper.init(model, parallel, 0, self.device)
+            eng = get_cache_engine(model.attention_backend)
+            self.engine = eng(cache, model, parallel, get_cache_mem_alloc_backend(model.attention_backend))
         self.Hq = model.get_num_q_heads(parallel)
         self.Hkv = model.get_num_kv_heads(parallel)
         self.D = model.get_head_size()
@@ -180,11 +190,11 @@ class HotPathRunner:
             self.engine.step(mds)
             if self.iter_hook is not None:
                 self.iter_hook(self)
-            if self.next_request is not None and self.admission_lookahead:
+            if self.next_request is not None and self.admission_lookahead and hasattr(self.engine, "prefetch_request"):
                 nxt = self.next_request if isinstance(self.next_request, list) else [self.next_request]
                 for sid, n in nxt:
                     self.engine.prefetch_request(sid, n)               # queued behind this step's own look-ahead batch
-                self.next_request = None
+            self.next_request = None
             self.wrapper.begin_forward(mds)
             out = None
             for layer in range(self.L):
@@ -206,6 +216,8 @@ class HotPathRunner:
                 self.stats.decode_tokens += 1
         if self.sample_kv_util:
             self._sample_util()
+        elif self.time_iterations:
+            self.stats.iter_util.append((None, None, 0, None))      # keep iter_util aligned with iter_events / iter_phase
         if self.time_iterations:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(self.stream)
@@ -426,6 +438,7 @@ class HotPathRunner:
         still waiting to be admitted (steady state: the pool is the contended resource) and for the drain tail (no admissions left:
         finished slots keep their pages under deferred reclamation because nobody needs them)."""
         evs, ph, ut = self.stats.iter_events, self.stats.iter_phase, self.stats.iter_util
+        assert len(evs) == len(ph) == len(ut), "per-iteration event / phase / utilisation lists out of step"
         acc = {0: [0.0, 0.0, 0.0, 0.0, 0.0], 1: [0.0, 0.0, 0.0, 0.0, 0.0]}      # time, t*live/mapped, t*live/needed, t*mapped/pool, t with samples
         prev = ev0
         for ev, phase, u in zip(evs, ph, ut):

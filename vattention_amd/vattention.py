@@ -18,6 +18,8 @@ from .page_manager import PageManager
 
 _pm: Optional[PageManager] = None
 _tensors: List[torch.Tensor] = []
+_bases: List[int] = []         # base address of every virtual tensor (resolve_view)
+_last_lens: List[int] = []     # the seq_lens of the last step()/step_async(): slot -> visible tokens of this iteration
 _verbose = False
 _deferred = True
 _default_flags = 0
@@ -47,7 +49,7 @@ def init_kvcache(num_layers: int, num_kv_heads: int, head_size: int, max_batch_s
     """apis.h:3-13.  Returns 2*L virtual tensors [B, max_ctx, kvh, D] (K_0..K_{L-1}, V_0..V_{L-1}) —
     or two [B, max_ctx, L, kvh, D] tensors with megacache — on cuda:<device>, with NO physical
     memory behind them yet.  A HIP context must exist (the reference says "initialize PyTorch first")."""
-    global _pm, _tensors
+    global _pm, _tensors, _bases, _last_lens
     if _pm is not None:
         cleanup()
     itemsize = torch.empty((), dtype=dtype).element_size()
@@ -61,6 +63,8 @@ def init_kvcache(num_layers: int, num_kv_heads: int, head_size: int, max_batch_s
     shape, stride = pm.shape(), pm.stride()
     tensors = [ext.tensor_from_va(pm.tensor_base(i), shape, stride, dtype, device) for i in range(pm.num_tensors)]
     _pm, _tensors = pm, tensors
+    _bases = [int(pm.tensor_base(i)) for i in range(pm.num_tensors)]
+    _last_lens = [0] * max_batch_size
     return list(tensors)
 
 
@@ -71,15 +75,18 @@ def reserve_physical_pages(free_memory: int) -> int:
 
 def step(seq_lens: List[int], eager_reclaim: bool) -> None:
     """apis.h:27-29 (the `_sync` backends)."""
+    global _last_lens
     _require().step(seq_lens, eager_reclaim)
+    _last_lens = list(seq_lens)
 
 
 def step_async(seq_lens: List[int]) -> None:
     """apis.h:31-35: maps what this iteration needs before returning, plans and hands the look-ahead
     mapping to the mapper thread; the GIL is released for the duration of the native call."""
-    global _layered_pending
+    global _layered_pending, _last_lens
     pm = _require()
     pm.step_async(seq_lens)
+    _last_lens = list(seq_lens)
     if pm.cfg.flags & L.FLAG_LAYERED_ASYNC:
         _layered_pending = pm.layers_ready() < pm.cfg.num_layers
 
@@ -102,13 +109,13 @@ def num_free_kvblocks() -> int:
 def cleanup() -> None:
     """apis.h:41-43: joins the mapper, unmaps everything, frees VA and physical handles.  Tensors
     returned by init_kvcache must not be used afterwards."""
-    global _pm, _tensors
+    global _pm, _tensors, _bases, _last_lens
     if _pm is None:
         return
     torch.cuda.synchronize()
     _pm.cleanup()
     _pm.close()
-    _pm, _tensors = None, []
+    _pm, _tensors, _bases, _last_lens = None, [], [], []
 
 
 def set_verbose(val: bool) -> None:
@@ -194,6 +201,31 @@ def stats() -> dict:
 
 def counts() -> dict:
     return _require().counts()
+
+
+def resolve_view(ptr: int):
+    """(slot, visible tokens) of the KV-cache row-block that starts at device address `ptr`, or None when `ptr` is not the first row of
+    a slot of one of this manager's virtual tensors.  The attention drop-in uses it for the reference's PREFILL call
+    (vattention_flashattention_wrapper.py:146-166): the wrapper hands over `kv_cache[l][slot]` — every row of the slot, max_ctx of them —
+    and the length only as a DEVICE tensor, but the engine told this module every slot's length of the iteration in
+    step_async(seq_lens) (vATTN_cache_engine.py:98-121): the launch plan needs no device-to-host copy and no extra argument."""
+    if _pm is None or not _bases:
+        return None
+    lay = _pm.layout
+    per_req = int(lay.virt_bytes_per_req)
+    total = int(lay.virt_bytes_total)
+    for base in _bases:
+        off = ptr - base
+        if 0 <= off < total:
+            slot = off // per_req
+            within = off - slot * per_req
+            # the first row of the slot: offset 0, or layer l's rows of a megacache tensor ([B, ctx, L, kvh, D]: l * kvh * D * itemsize)
+            row_bytes = _pm.cfg.num_kv_heads * _pm.cfg.head_size * _pm.cfg.itemsize
+            if within >= (_pm.cfg.num_layers * row_bytes if _pm.cfg.megacache else 1):
+                return None
+            n = int(_last_lens[slot]) if slot < len(_last_lens) else 0
+            return (int(slot), n) if n > 0 else None
+    return None
 
 
 def layout() -> dict:
