@@ -72,7 +72,8 @@ def run(which: str, impl: str, layers: int, mem: int, lengths):
             enable_op_timers(False)
             ops = {k: {"launches": v["n"], "timed": v["timed"], "ms_per_launch": round(v["ms"] / v["timed"], 4) if v["timed"] else None,
                        "est_total_ms": round(v["ms"] * v["n"] / v["timed"], 1) if v["timed"] else None} for k, v in det.items()}
-            return {"impl": impl, "tokens": tokens, "seconds": round(dt, 3), "tokens_per_s": round(tokens / dt, 1), "ops": ops,
+            import vattention_amd.flash_attn as FA
+            return {"impl": impl, "shim_counters": dict(FA.counters), "tokens": tokens, "seconds": round(dt, 3), "tokens_per_s": round(tokens / dt, 1), "ops": ops,
                     "wrapper_class": type(r.wrapper).__module__ + "." + type(r.wrapper).__name__,
                     "engine_class": type(r.engine).__module__ + "." + type(r.engine).__name__}
         finally:

@@ -238,6 +238,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
         klens = _lengths_from_page_manager(k_cache, B)
         if klens is not None:
             hint = max(klens)
+            counters["lengths_from_page_manager"] += 1
     p.max_seqlen_k_hint = min(hint, Sk + Sn) if hint > 0 else 0
     if rot is not None:
         p.rotary_cos_sin, p.rotary_row_stride, p.rotary_dim = rot.data_ptr(), rot.stride(0), rot.shape[1]
@@ -253,6 +254,9 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
             plan = _cached_prefill_plan(p, klens, dev)
         if plan is not None:
             plan.attach(p)
+            counters["work_list_attached"] += plan.t is not None
+    if Sq > 1:
+        counters["prefill_calls"] += 1
     if _cache_seqlens_host is not None and Sq == 1 and B > 1 and num_splits == 0 and not torch.cuda.is_current_stream_capturing():
         # (the plan's tables travel by a host-to-device copy: not while the stream is being captured into a graph — the uniform split then)
         if _plan_tiles:                                        # (tests / A-B: pieces of exactly this many 32-key tiles)
@@ -283,6 +287,7 @@ def _lengths_from_page_manager(k_cache, B: int):
 
 
 _plan_cache = {}      # (shapes, lengths, device) -> _PrefillPlan; a few dozen entries, dropped wholesale when full
+counters = {"prefill_calls": 0, "lengths_from_page_manager": 0, "plan_built": 0, "plan_cache_hit": 0, "work_list_attached": 0}      # introspection (tools/, tests)
 
 
 def _cached_prefill_plan(p, klens, dev):
@@ -292,6 +297,9 @@ def _cached_prefill_plan(p, klens, dev):
         if len(_plan_cache) >= 64:
             _plan_cache.clear()
         pl = _plan_cache[key] = prefill_plan(p, None, klens, dev)
+        counters["plan_built"] += 1
+    else:
+        counters["plan_cache_hit"] += 1
     return pl
 
 
