@@ -26,6 +26,24 @@ from the reference's own file by oracle/gen_golden_attn_intree.py and committed 
 mask of its own): it pins softmax(q.k^T/sqrt(d) + mask).v and the LSE, not the operator's semantics — hence still
 "unpinned" in the task's sense.
 
+What pins what (round 4 — "partial" made as tight as the tree allows; there is still no fixture of the OPERATOR itself):
+
+    semantic of flash_attn_with_kvcache            pinned by                                                          how
+    ---------------------------------------------  -----------------------------------------------------------------  ---------------------------
+    softmax(q.k^T.scale + mask).v, fp32, and LSE   tests/golden/attn_intree_ref_mha.npz, 5 plain + 20 composed cases   in-tree ref_mha_bmhk, executed
+    append position and content (k, v given)       op_* cases: caches after the call == after the reference's          cache_kernels.cu:483-520 restated
+                                                   cache_flat statement at row cache_seqlens[b] (checksums + rows)     as flat index arithmetic
+    cache_batch_idx (slot of batch entry b)        op_* cases with permuted / partial slot lists                       composition (row selection)
+    cache_seqlens (+ seqlen_new) visible keys      op_* cases, Lk in {1, 5, 63, 64, 65, 300, 4097}                     composition (cut)
+    strided [:, :max_len] cache views              op_strided_view                                                     composition
+    bottom-right causal alignment                  op_* chunk cases (mask handed to ref_mha_bmhk)                      OURS, following mask.h:164-196
+    GQA head mapping h -> h // (Hq / Hkv)          op_* cases, groups 1 / 3(MHA) / 4 / 7 / 8                            OURS, following the docstring :1180-1184
+    rows that see no key -> 0, LSE = +inf          op_chunk_longer_than_keys                                           OURS (ref_mha_bmhk gives NaN)
+    fp16 agreement at atol = 1e-3                  tests/test_gpu_attention.py::test_pod_sweep_shapes_...               the reference's own GPU-vs-GPU
+                                                   (POD sweep shapes, pod_attn/tests/attn_sweep.py:82-97)              criterion, kernels vs this file
+
+The HIP kernels are additionally compared with the composed vectors DIRECTLY (test_kernels_against_the_operator_by_composition_vectors).
+
 Two precisions:
   * ``math="f64"``  — exact-arithmetic ground truth on the fp16/bf16 inputs (what tests compare to);
   * ``math="f32"``  — fp32 accumulate, P rounded to the I/O dtype before PV (the reference kernel's

@@ -173,7 +173,48 @@ def _intree_cases():
     return z, sorted({k.split("/")[0] for k in z.files})
 
 
-@pytest.mark.parametrize("name", _intree_cases()[1])
+def _op_case(name):
+    """Inputs of an operator-by-composition case, re-created from its seed with the generating script's own recipe."""
+    import oracle.gen_golden_attn_intree as gen
+    z, _ = _intree_cases()
+    case = next(c for c in gen.OP_CASES if "op_" + c[0] == name)
+    _n, B, Sq, Sn, lens, slots, idx, Hq, Hkv, D, causal, dtype = case
+    kc, vc, q, kn, vn = gen.op_inputs(int(z[name + "/seed"][0]), B, Sq, Sn, lens, slots, Hq, Hkv, D, dtype)
+    return z, case, kc, vc, q, kn, vn
+
+
+@pytest.mark.parametrize("name", [n for n in _intree_cases()[1] if n.startswith("op_")])
+def test_operator_by_composition_vectors(name):
+    """The OPERATOR's index semantics against vectors composed from reference text (oracle/gen_golden_attn_intree.py, OP_CASES): the
+    append executed as the reference's cache_flat statement, the slot picked by cache_batch_idx, the keys cut at cache_seqlens (+ new
+    tokens), attention by the in-tree ref_mha_bmhk.  The oracle must produce the same outputs and LSEs from ONE call of the operator
+    it restates — and leave the caches in the state the cache_flat statement left them."""
+    z, case, kc, vc, q, kn, vn = _op_case(name)
+    _n, B, Sq, Sn, lens, slots, idx, Hq, Hkv, D, causal, dtype = case
+    cl = torch.tensor(lens, dtype=torch.int32)
+    bi = torch.tensor(idx, dtype=torch.int32) if idx is not None else None
+    ml = max(lens) + Sn
+    kview, vview = (kc[:, :ml], vc[:, :ml]) if "strided" in name else (kc, vc)
+    got, lse = flash_attn_with_kvcache_ref(q, kview, vview, kn if Sn else None, vn if Sn else None, cache_seqlens=cl, cache_batch_idx=bi,
+                                           causal=bool(causal), math="f64", return_lse=True)
+    ref = torch.from_numpy(z[name + "/out"]).double()
+    dead = torch.from_numpy(z[name + "/masked_rows"])
+    assert torch.allclose(got, ref, atol=3e-5, rtol=3e-5), (got - ref).abs().max().item()
+    if dead.any():
+        assert float(got[dead].abs().max()) == 0.0                 # rows that see no key
+    ref_lse = torch.from_numpy(z[name + "/lse"]).double()           # [B, Hq, Sq]
+    live = ~dead[:, None, :].expand(-1, Hq, -1)
+    assert torch.allclose(lse[live], ref_lse[live], atol=3e-5, rtol=3e-6)
+    # the caches: checksums of every slot as the cache_flat statement left them, and the appended rows bit for bit
+    assert torch.equal(kc.view(torch.int16).to(torch.int64).sum(dim=(1, 2, 3)), torch.from_numpy(z[name + "/k_sum"]))
+    assert torch.equal(vc.view(torch.int16).to(torch.int64).sum(dim=(1, 2, 3)), torch.from_numpy(z[name + "/v_sum"]))
+    for b in range(B):
+        slot = idx[b] if idx is not None else b
+        if Sn:
+            assert torch.equal(kc[slot, lens[b]:lens[b] + Sn], kn[b]) and torch.equal(vc[slot, lens[b]:lens[b] + Sn], vn[b])
+
+
+@pytest.mark.parametrize("name", [n for n in _intree_cases()[1] if not n.startswith("op_")])
 def test_matches_the_in_tree_pytorch_mha_reference_vectors(name):
     """tests/golden/attn_intree_ref_mha.npz: outputs and LSEs of `ref_mha_bmhk` of the CUTLASS example vendored inside the reference
     tree (…/41_fused_multi_head_attention/fmha_backward_test.py:78-105), produced in this container by

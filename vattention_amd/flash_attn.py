@@ -59,9 +59,10 @@ def _rotary_table(rotary_cos, rotary_sin, _rotary_cos_sin, rotary_interleaved, q
     return t
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
+def _workspace(nbytes: int, device, stream_ptr=None) -> torch.Tensor:
     # one scratch buffer per (device, stream): split-KV partials of calls on different streams must not share storage
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           stream_ptr if stream_ptr is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
@@ -124,7 +125,19 @@ def relaunch(p, q_ptr: int, k_new_ptr: int, v_new_ptr: int, out_ptr: int, k_cach
     p.q, p.out, p.k_cache, p.v_cache = q_ptr, out_ptr, k_cache_ptr, v_cache_ptr
     if p.k_new:
         p.k_new, p.v_new = k_new_ptr, v_new_ptr
-    _launch(p, dev)
+    fast = getattr(p, "_fast", None)
+    if fast is None or _capture is not None:
+        _launch(p, dev)
+        return
+    # (the block's library and workspace need were settled by its first launch: a batch-1 decode is tens of microseconds per layer, and
+    # every host microsecond on this path shows up as an idle GPU)
+    lib, need = fast
+    st = K.current_stream_ptr(dev)
+    if need:
+        p.workspace = _workspace(need, dev, st).data_ptr()
+    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), st)
+    if rc != 0:
+        raise RuntimeError(K.last_error(lib))
 
 
 def _launch(p, dev, keep=()):
@@ -134,12 +147,14 @@ def _launch(p, dev, keep=()):
         return
     lib = K.klib_for(p.variant)          # the product library; the lab build only for measurement variants (tests, kbench)
     need = lib.vattn_attn_workspace_bytes(C.byref(p))
+    st = K.current_stream_ptr(dev)
     if need:
-        ws = _workspace(need, dev)       # kept alive by the per-(device, stream) cache until a larger one replaces it
+        ws = _workspace(need, dev, st)   # kept alive by the per-(device, stream) cache until a larger one replaces it
         p.workspace = ws.data_ptr()
-    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), K.current_stream_ptr(dev))
+    rc = lib.vattn_flash_attn_with_kvcache(C.byref(p), st)
     if rc != 0:
         raise RuntimeError(K.last_error(lib))
+    p._fast = (lib, need)                # relaunch(): same shapes, same plan
 
 
 def _check_cuda(*ts):
