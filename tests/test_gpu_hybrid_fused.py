@@ -138,3 +138,39 @@ def test_fused_hybrid_argument_rules():
                     lambda: flash_attn_with_kvcache(q64[:, :1], k64[1:], k64[1:], cache_seqlens=cl, causal=True), torch.device(DEV))
     hybrid_attn(pre, dec, torch.device(DEV))          # and the valid form runs
     torch.cuda.synchronize()
+
+
+def test_product_entry_point_issues_the_two_launches_back_to_back():
+    """Round 4: the fused kernel is lab-only; the PRODUCT library's vattn_hybrid_attn (what a binding of the reference's POD call
+    site reaches) runs the plan-chosen prefill launch and the device-planned decode launch in order on the caller's stream — results
+    bit-identical to the two stand-alone calls, appended rows in place."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache, hybrid_attn
+    torch.manual_seed(5)
+    Hq, Hkv, D, ctx = 8, 2, 128, 3000
+    kc = torch.randn(6, ctx, Hkv, D, device=DEV).half()
+    vc = torch.randn(6, ctx, Hkv, D, device=DEV).half()
+    T, c = 700, 1500
+    q = torch.randn(T + 4, Hq, D, device=DEV).half()
+    kn, vn = torch.randn(4, 1, Hkv, D, device=DEV).half(), torch.randn(4, 1, Hkv, D, device=DEV).half()
+    totals = torch.tensor([c + T], dtype=torch.int32, device=DEV)
+    dl = torch.tensor([2500, 31, 900, 1777], dtype=torch.int32, device=DEV)
+    di = torch.tensor([1, 2, 4, 5], dtype=torch.int32, device=DEV)
+
+    def run(fused_entry):
+        kg, vg = kc.clone(), vc.clone()
+        out = torch.zeros_like(q)
+        pre = lambda: flash_attn_with_kvcache(q[:T].unsqueeze(0), kg[0:1], vg[0:1], cache_seqlens=totals, causal=True, out=out[:T].unsqueeze(0))
+        dec = lambda: flash_attn_with_kvcache(q[T:].unsqueeze(1), kg[:, :2501], vg[:, :2501], kn, vn, cache_seqlens=dl, cache_batch_idx=di, causal=True,
+                                              out=out[T:].unsqueeze(1))
+        if fused_entry:
+            hybrid_attn(pre, dec, torch.device(DEV), _product=True)
+        else:
+            pre()
+            dec()
+        torch.cuda.synchronize()
+        return out, kg, vg
+
+    a, ka, va_ = run(True)
+    b, kb, vb = run(False)
+    assert torch.equal(a, b) and torch.equal(ka, kb) and torch.equal(va_, vb)
+    assert float(a.abs().max()) > 0

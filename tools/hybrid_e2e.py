@@ -34,7 +34,8 @@ def run(a, backend):
 
 
 if __name__ == "__main__":
-    os.environ["VATTN_POD_FUSED"] = "1"      # fa_pod = the fused launch here (off by default in the product: see the wrapper)
+    from vattention_amd.attention.vattention_flashattention_pod_wrapper import VAttentionFlashAttentionPodWrapper as _Pod
+    _Pod.FUSED_ENABLED = True      # fa_pod = the LAB library's fused launch here (the product has none: see the wrapper)
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--ctx", type=int, default=16384)

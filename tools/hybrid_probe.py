@@ -80,8 +80,9 @@ def main():
 
         t_par_u = timeit(both(pu))
         t_par_a = timeit(both(pa))
-        # the fused launch (vattn_hybrid_attn): by-arrival roles (product), and with every workgroup preferring one queue (A/B)
-        lib = K.klib()
+        # the fused launch (vattn_hybrid_attn of the LAB library; the product's entry point is the serial order): by-arrival roles, and with
+        # every workgroup preferring one queue (A/B)
+        lib = K.klib_lab()
         need = lib.vattn_hybrid_workspace_bytes(C.byref(pu), C.byref(pd))
         ws = torch.zeros(need // 4 + 64, dtype=torch.float32, device=DEV)
 
@@ -90,7 +91,7 @@ def main():
                 pu.variant = (pu.variant & ~(3 << 12)) | (mode << 12)
                 rc = lib.vattn_hybrid_attn(C.byref(pu), C.byref(pd), C.c_void_p(ws.data_ptr()), C.c_void_p(s_main.cuda_stream))
                 if rc != 0:
-                    raise RuntimeError(K.last_error())
+                    raise RuntimeError(K.last_error(lib))
             return f
 
         t_f0, t_f1, t_f2 = timeit(fused(0)), timeit(fused(1)), timeit(fused(2))

@@ -12,9 +12,9 @@ The fused launch co-locates one matrix-bound and one HBM-bound workgroup on ever
 (profiles/r02_hybrid_probe.txt, r02_hybrid_e2e.txt) it LOSES to the serial order and to two streams on every Sarathi-shaped batch
 (0.26-0.64x): the stand-alone kernels already saturate what each is bound by (HBM for decode at 12 waves per CU, board power for
 prefill), and inside one kernel both bodies share one register allocation (256 per lane), which leaves decode a third of its
-waves.  So the fused launch is built, parity-checked against the oracle (tests/test_gpu_hybrid_fused.py) and OFF by default:
-`fa_pod` follows the streams wrapper's per-iteration policy unless FUSED_ENABLED is set (env VATTN_POD_FUSED=1), in which case
-begin_forward() takes the fused launch when the smaller part's estimated time is at least FUSE_MIN_SHARE of the larger one's."""
+waves.  Round 4 closed the row: the fused launch is LAB-ONLY (built into tools/lab/libvattn_lab.so, parity-checked against the oracle by
+tests/test_gpu_hybrid_fused.py); there is no environment switch any more.  `fa_pod` IS the streams wrapper's per-iteration policy;
+the class attribute FUSED_ENABLED exists for the tests and tools/hybrid_*.py, which set it to drive the lab kernel end to end."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
@@ -28,7 +28,7 @@ from .vattention_flashattention_streams_wrapper import VAttentionFlashAttentionS
 
 class VAttentionFlashAttentionPodWrapper(VAttentionFlashAttentionStreamsWrapper):
     _inst = None
-    FUSED_ENABLED = None          # None: read VATTN_POD_FUSED from the environment
+    FUSED_ENABLED = False         # tests / tools only (the lab library's fused launch)
     FUSE_MIN_SHARE = 0.15
     # stand-alone rates of the two bodies inside the fused launch [measured, profiles/r02_hybrid_probe.txt]
     FUSED_PREFILL_FLOPS = 4.5e14
@@ -38,9 +38,7 @@ class VAttentionFlashAttentionPodWrapper(VAttentionFlashAttentionStreamsWrapper)
         self._fused = self._plan_fused()
 
     def _plan_fused(self) -> bool:
-        import os
-        enabled = self.FUSED_ENABLED if self.FUSED_ENABLED is not None else os.environ.get("VATTN_POD_FUSED", "0") == "1"
-        if not enabled:
+        if not self.FUSED_ENABLED:
             return False
         if not self.prefill_query_lens or not self.decode_batch_size or self.head_dim != 128:
             return False

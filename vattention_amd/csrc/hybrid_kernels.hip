@@ -16,10 +16,36 @@
 // __threadfence and the group's counter).
 // Control words live at the head of the caller's workspace; they must be zero before the FIRST launch and the kernel leaves
 // them zero (the last workgroup to leave resets them), so back-to-back launches on one stream need no memset.
+// ROUND 4 — CLOSED: the fused launch is LAB-ONLY (-DVATTN_LAB, tools/lab/libvattn_lab.so).  Three rounds of measurements (fused 0.26-0.75x,
+// CU-masked streams 0.42-0.93x, two plain streams 0.88-1.19x of the serial order) say that on MI355X each of the two
+// stand-alone kernels already owns what bounds it — HBM for decode, board power for prefill — so co-residency creates no capacity; and the
+// last candidate, time-slicing the two phases at workgroup granularity inside one persistent launch, can only remove one launch boundary
+// (~2 us) and the decode phase's ramp per layer from launches of 0.5-2 ms: < 1 %, against the >= 5 % the row was asked to show.  The
+// PRODUCT library therefore implements the C entry point (the reference's POD call site binds it) as what measures best: the plan-chosen
+// prefill launch, then the device-planned decode launch, back to back on the caller's stream.
 #include "decode_body.h"
 #include "prefill_body.h"
 
 namespace vattn_k {
+
+#ifndef VATTN_LAB
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t hybrid_workspace_bytes(const vattn_attn_params* pp, const vattn_attn_params* pd) {
+    return al256(prefill_workspace_bytes(pp)) + al256(decode_workspace_bytes(pd)) + 256;
+}
+int launch_hybrid(const vattn_attn_params* pp, const vattn_attn_params* pd, void* ws, hipStream_t st) {
+    if (pp->dtype != pd->dtype) return fail(VATTN_K_ERR_INVALID, "prefill and decode parts must have the same dtype");
+    if (pp->seqlen_q < 2 || pd->seqlen_q != 1) return fail(VATTN_K_ERR_INVALID, "hybrid launch: first part must be a prefill (seqlen_q > 1), second a decode (seqlen_q == 1)");
+    if (pp->k_new) return fail(VATTN_K_ERR_UNSUPPORTED, "hybrid launch: append the prefill chunk's keys/values with cache_flat first");
+    if (!ws) return fail(VATTN_K_ERR_INVALID, "hybrid launch needs its workspace (vattn_hybrid_workspace_bytes)");
+    vattn_attn_params a = *pp, b = *pd;
+    a.workspace = ws;
+    b.workspace = (char*)ws + al256(prefill_workspace_bytes(pp));
+    int rc = launch_prefill_form(&a, st);
+    if (rc) return rc;
+    return launch_decode_form(&b, st);
+}
+#else
 
 constexpr int HY_CU_SLOTS = 2048;                    // (xcc, se, sh, cu) keys
 constexpr int HY_CTL_INTS = 4 + HY_CU_SLOTS;         // next[2], exited, pad, arrivals[HY_CU_SLOTS]; then done[HY_DONE_CAP]
@@ -152,5 +178,6 @@ int launch_hybrid(const vattn_attn_params* pp, const vattn_attn_params* pd, void
     if (!ws) return fail(VATTN_K_ERR_INVALID, "hybrid launch needs its workspace (vattn_hybrid_workspace_bytes, zero-filled once)");
     return pp->dtype == VATTN_DTYPE_F16 ? launch_hybrid_t<_Float16>(pp, pd, ws, st) : launch_hybrid_t<__bf16>(pp, pd, ws, st);
 }
+#endif  // VATTN_LAB
 
 }  // namespace vattn_k

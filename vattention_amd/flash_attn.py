@@ -80,8 +80,9 @@ _capture = None      # a list while hybrid_attn() records the two parameter bloc
 _hybrid_ws = {}      # (device, stream) -> zero-initialised workspace of the fused launch (the kernel leaves its control words zero)
 
 
-def hybrid_attn(prefill_call, decode_call, device, _role_mode: int = 0) -> None:
-    """Fused prefill || decode for a hybrid batch (include/vattn_kernels.h, vattn_hybrid_attn; the reference's POD entry point
+def hybrid_attn(prefill_call, decode_call, device, _role_mode: int = 0, _product: bool = False) -> None:
+    """LAB ONLY (tools/lab/libvattn_lab.so; the product's vattn_hybrid_attn issues the two launches back to back — what measures best).
+    Fused prefill || decode for a hybrid batch (include/vattn_kernels.h, vattn_hybrid_attn; the reference's POD entry point
     pod_attn/flash_attn_interface.py true_fused_attn_with_kvcache): `prefill_call` and `decode_call` are callables that each issue
     exactly ONE attention call of this module (flash_attn_with_kvcache / flash_attn_varlen_with_kvcache, results via out=); the
     two calls are recorded instead of launched and go to the GPU as one launch on the current stream."""
@@ -101,7 +102,9 @@ def hybrid_attn(prefill_call, decode_call, device, _role_mode: int = 0) -> None:
     (pp, keep_p), (pd, keep_d) = cap
     if _role_mode:
         pp.variant = (pp.variant & ~(3 << 12)) | ((_role_mode & 3) << 12)
-    lib = K.klib_lab() if (K.needs_lab(pp.variant) or K.needs_lab(pd.variant)) else K.klib()
+    # the fused launch is lab-only since round 4 (csrc/hybrid_kernels.hip: measured slower than serial three ways); _product: the product
+    # library's entry point of the same name, which issues the two launches back to back
+    lib = K.klib() if _product else K.klib_lab()
     need = lib.vattn_hybrid_workspace_bytes(C.byref(pp), C.byref(pd))
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _hybrid_ws.get(key)
