@@ -61,6 +61,10 @@ class loaded:
         how = available()
         if not how:
             raise RuntimeError("reference wrapper/engine not available (neither /root/reference nor oracle/_ref/pyref)")
+        if self.cpu_kernels is None:
+            # (imported BEFORE sys.modules is saved: a module first imported inside the context would be dropped from sys.modules on exit
+            # while the package still holds it as an attribute — the next `import vattention_amd.vattention` then builds a second copy)
+            import vattention_amd.cache_ops, vattention_amd.dropin, vattention_amd.flash_attn, vattention_amd.vattention  # noqa: F401, E401
         self.saved = dict(sys.modules)
         for name in list(sys.modules):
             if name == "sarathi" or name.startswith("sarathi.") or name in ("vattention", "flash_attn"):

@@ -115,8 +115,8 @@ def test_split_plans_from_the_workspace_query():
     assert dec_splits(16, 32768, 32, 4) == 12           # c2: 16 x 4 kv heads x 12 = 768
     assert dec_splits(1, 32768, 32, 4) == 48
     assert dec_splits(4, 32768, 32, 4) == 48
-    assert dec_splits(1, 131072, 28, 4) == 48           # one 128 k sequence, 4 kv heads (Yi-34B/TP2): 192 workgroups, more splits do not pay
-    assert dec_splits(1, 131072, 14, 2) == 64           # ... 2 kv heads (TP4 shard): 64 splits measured best
+    assert dec_splits(1, 131072, 28, 4) == 64           # one 128 k sequence, 4 kv heads (Yi-34B/TP2): measured over rotating caches (round 4)
+    assert dec_splits(1, 131072, 14, 2) == 96           # ... 2 kv heads (TP4 shard)
     assert dec_splits(8, 131072, 28, 4) == 24           # batch 8 at 128 k: 32 groups x 24 = 768, as before
     assert dec_splits(256, 2048, 32, 8) == 1
     assert dec_splits(1, 2048, 32, 4) == 16             # one 32-key tile per wave and split at most

@@ -48,8 +48,8 @@ DECODE = {
     ("configs[4] llama70b/tp8 B64@32k", 8, 1, 64, 32768): (2, 1, 0, 768, 1, 6922752),
     ("configs[4] llama70b/tp8 B256@32k", 8, 1, 256, 32768): (2, 1, 0, 768, 1, 8521728),
     ("configs[3] yi34b/tp2 B8@128k", 28, 4, 8, 131072): (2, 1, 0, 768, 1, 6656128),
-    ("configs[3] yi34b/tp2 B1@128k", 28, 4, 1, 131072): (0, 1, 48, 192, 1, 693504),
-    ("yi34b/tp4 B1@128k", 14, 2, 1, 131072): (0, 1, 64, 128, 1, 462336),
+    ("configs[3] yi34b/tp2 B1@128k", 28, 4, 1, 131072): (0, 1, 64, 256, 1, 924672),
+    ("yi34b/tp4 B1@128k", 14, 2, 1, 131072): (0, 1, 96, 192, 1, 693504),
     ("mqa G32 B16@16k", 32, 1, 16, 16384): (0, 2, 32, 512, 1, 8454144),
     ("mqa G64 B16@8k", 64, 1, 16, 8192): (0, 2, 16, 512, 1, 8454144),
     ("yi6b B16@2k", 32, 4, 16, 2048): (2, 1, 0, 768, 1, 6922368),

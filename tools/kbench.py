@@ -133,7 +133,32 @@ def decode(variant):
         idx = torch.arange(B, dtype=torch.int32, device=DEV) % slots
         for splits in SPLITS:
             p, keep = params(q, kc, vc, cl, idx, kn, vn, splits=splits, variant=variant)
-            ms = time_ms(p, 3, 20)
+            if ROTATE:
+                # launches of one shape over R different caches in turn, R x bytes >= 1.5 GB: nothing is served from the 256 MiB
+                # Infinity Cache (a small launch repeated on ONE cache is: B1 @ 128 k reads 52 us that way and 63 us in a real model,
+                # whose 60 layers each own their K/V)
+                by1 = B * 2.0 * ctx * Hkv * 128 * 2
+                R = max(2, int(1.5e9 // by1) + 1)
+                ps = [(p, keep)]
+                for _ in range(R - 1):
+                    kc2, vc2 = torch.randn_like(kc), torch.randn_like(vc)
+                    ps.append(params(q, kc2, vc2, cl, idx, kn, vn, splits=splits, variant=variant))
+                lib = K.klib_for(p.variant)
+                st = torch.cuda.current_stream().cuda_stream
+                for pp, _k in ps:
+                    lib.vattn_flash_attn_with_kvcache(C.byref(pp), st)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                iters = max(2, 40 // R + 1)
+                e0.record()
+                for _ in range(iters):
+                    for pp, _k in ps:
+                        lib.vattn_flash_attn_with_kvcache(C.byref(pp), st)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / (iters * R)
+                del ps
+            else:
+                ms = time_ms(p, 3, 20)
             by = B * 2.0 * ctx * Hkv * 128 * 2 + B * Hq * 128 * 2 * 2
             print("  %-22s B=%3d ctx=%6d Hq=%2d Hkv=%d splits=%d : %8.4f ms  %7.1f GB/s  (%.1f%% of 8000, %.1f%% of 6290)" % (
                 name, B, ctx, Hq, Hkv, splits, ms, by / ms / 1e6, by / ms / 1e6 / 80, by / ms / 1e6 / 62.9))
@@ -141,6 +166,7 @@ def decode(variant):
 
 
 ONLY = None
+ROTATE = False
 WORKLIST = False
 WL_TILES = 0
 MEGA = 1
@@ -153,6 +179,7 @@ if __name__ == "__main__":
     if "--splits" in sys.argv:
         SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
     WORKLIST = "--worklist" in sys.argv
+    ROTATE = "--rotate" in sys.argv      # decode: rotate over enough caches that the Infinity Cache cannot serve repeated launches
     WL_TILES = int(sys.argv[sys.argv.index("--wl-tiles") + 1]) if "--wl-tiles" in sys.argv else 0
     if "--mega" in sys.argv:      # decode only: K/V as one layer's view of a megacache tensor with this many layers
         MEGA = int(sys.argv[sys.argv.index("--mega") + 1])

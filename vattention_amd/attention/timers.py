@@ -47,16 +47,57 @@ def drain_op_timers_detail() -> dict:
     torch.cuda.synchronize()
     out = {}
     for name, evs in _records.items():
-        out[name] = {"ms": sum(a.elapsed_time(b) for a, b, _ in evs), "timed": len(evs), "n": _counts.get(name, len(evs)),
-                     "work": float(sum(w for _, _, w in evs))}
+        out[name] = {"ms": sum(r[0].elapsed_time(r[1]) for r in evs), "timed": sum(r[3] if len(r) > 3 else 1 for r in evs),
+                     "n": _counts.get(name, len(evs)), "work": float(sum(r[2] for r in evs))}
     _records.clear()
     _counts.clear()
+    _groups.clear()
     return out
 
 
 def drain_op_timers() -> dict:
     """{operation name: estimated total milliseconds} (timed share scaled to all invocations); clears the records."""
     return {k: v["ms"] * (v["n"] / v["timed"] if v["timed"] else 0.0) for k, v in drain_op_timers_detail().items()}
+
+
+_groups = {}                       # name -> (start event, launches so far, work so far) of an open group
+
+
+def group_begin(name: str) -> bool:
+    """Open a GROUP measurement: ONE event pair around a run of back-to-back launches of the same operation (the L decode launches of a
+    decode-only iteration).  A HIP event is a barrier packet with a signal — a few microseconds of its own — so bracketing every launch
+    of a 30-60 us kernel with its own pair inflates each reading by 10-20 % (batch-1 decode at 128 k: 63 us per launch by per-launch
+    events, 52 us by tools/kbench.py's pair around twenty launches); the group pays that once per L launches, and still contains every
+    real gap between them.  Returns False (nothing opened) when timers are off or this iteration is not sampled."""
+    if not _enabled:
+        return False
+    n = _counts[name + "#groups"]
+    _counts[name + "#groups"] = n + 1
+    if n % _every != 0:
+        return False
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    _groups[name] = [ev, 0, 0.0]
+    return True
+
+
+def group_add(name: str, work: float) -> None:
+    """Account one launch of a grouped iteration (the caller uses no timer of its own); if the iteration's group is open — it is one of
+    the sampled ones — the launch is timed by the group's event pair."""
+    _counts[name] += 1
+    g = _groups.get(name)
+    if g is not None:
+        g[1] += 1
+        g[2] += work
+
+
+def group_end(name: str) -> None:
+    g = _groups.pop(name, None)
+    if g is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    _records[name].append((g[0], end, g[2], g[1]))
 
 
 class OpTimer:

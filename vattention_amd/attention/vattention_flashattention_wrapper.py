@@ -27,6 +27,7 @@ from ..cache_ops import cache_flat, cache_flat_rope
 from .. import flash_attn as _FA
 from ..flash_attn import flash_attn_varlen_with_kvcache, flash_attn_with_kvcache
 from .base_attention_wrapper import BaseAttentionWrapper
+from . import timers as _T
 from .timers import OperationMetrics
 
 
@@ -38,6 +39,7 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         self.is_metadata_initialized = False
         self.is_profiling_iteration = False
         self._rotary = None
+        self._num_layers = model_config.get_num_layers(parallel_config)
         self._reset()
 
     def set_fused_rotary(self, cos_sin_cache: Optional[torch.Tensor]) -> None:
@@ -219,7 +221,20 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
         plan = self._dec_plan
         sig = (query.stride(0), key.stride(0), value.stride(0), output.stride(0), k_all.stride(), v_all.stride(), tok, float(softmax_scale),
                query.dtype, k_all.dtype)
+        # op timers of a DECODE-ONLY iteration: one event pair around its L back-to-back launches (timers.group_begin) instead of one
+        # pair per launch — an event costs microseconds of its own, which is 10-20 % of a batch-1 decode launch
+        grouped = _T.op_timers_enabled() and not self.prefill_query_lens and layer_id is not None
+        if grouped:
+            if layer_id == 0:
+                _T.group_begin("attn_decode")
+            _T.group_add("attn_decode", self._dc_bytes)
         if plan is not None and plan["sig"] == sig and not _FA._capture_active():
+            if grouped:
+                _FA.relaunch(plan["p"], query.data_ptr() + plan["q_off"], key.data_ptr() + plan["k_off"], value.data_ptr() + plan["v_off"],
+                             output.data_ptr() + plan["o_off"], k_all.data_ptr(), v_all.data_ptr(), self.device)
+                if layer_id == self._num_layers - 1:
+                    _T.group_end("attn_decode")
+                return
             with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id) as tm:
                 tm.work = self._dc_bytes
                 _FA.relaunch(plan["p"], query.data_ptr() + plan["q_off"], key.data_ptr() + plan["k_off"], value.data_ptr() + plan["v_off"],
@@ -230,7 +245,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
             dq = query[tok:tok + nb].view(nb, 1, Hq, D)
             dk = key[tok:tok + nb].view(nb, 1, Hkv, D)
             dv = value[tok:tok + nb].view(nb, 1, Hkv, D)
-        with self.get_timer(OperationMetrics.ATTN_DECODE, layer_id) as tm:
+        import contextlib
+        with (contextlib.nullcontext(_T.OpTimer("attn_decode")) if grouped else self.get_timer(OperationMetrics.ATTN_DECODE, layer_id)) as tm:
             tm.work = self._dc_bytes
             flash_attn_with_kvcache(dq, k_all[:, :self.max_cache_len], v_all[:, :self.max_cache_len], dk, dv,
                                     cache_seqlens=self.decode_cache_lens, block_table=None,
@@ -238,6 +254,8 @@ class VAttentionFlashAttentionWrapper(BaseAttentionWrapper):
                                     cache_batch_idx=self.batch_index_gen,
                                     out=output[tok:tok + nb].view(nb, 1, Hq, D), _rotary_cos_sin=self._rotary, _params_out=capture)
             # (no host-side lengths: the launch balances a ragged batch from `cache_seqlens` on the device, csrc/decode_body.h)
+        if grouped and layer_id == self._num_layers - 1:
+            _T.group_end("attn_decode")
         if capture:
             es = query.element_size()
             self._dec_plan = {"sig": sig, "p": capture[0], "q_off": tok * query.stride(0) * es, "k_off": tok * key.stride(0) * es,

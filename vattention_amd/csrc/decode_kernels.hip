@@ -135,7 +135,11 @@ int pick_splits(const vattn_attn_params* p, int gblocks, long slots = 768) {
     // -> at most 48 splits; 64 when fewer than four (sequence, kv head) groups exist and the context is long enough to keep ~700
     // keys per split (one 128 k sequence on a TP4 shard, 2 kv heads: 35.4 us at 48 splits, 30.8 at 64, 33.7 at 128; with 4 kv heads
     // 48 / 64 / 128 splits measure 52.3 / 52.8 / 53.4 us: profiles/r02_kbench_decode_splits.txt)
-    const long cap_len = (wg <= 3 && tiles / 21 >= 64) ? 64 : 48;
+    // Round 4 re-measured these with the launches ROTATING over enough caches that the 256 MiB Infinity Cache cannot serve a repeated
+    // launch (tools/kbench.py --rotate, profiles/r04_decode_b1_rotating_caches.txt: one 128 k sequence is 268 MB of K/V on a TP2 shard —
+    // repeated on ONE cache it reads 51 us, over rotating caches 64 us, which is what a 60-layer model sees): 2 kv heads 47.0 / 40.5 /
+    // 36.0 / 37.3 us at 48 / 64 / 96 / 128 splits, 4 kv heads 64.8 / 61.1 / 64.9 / 62.1 us, one 32 k sequence on 4 kv heads 24.8 / 26.1 / 27.8
+    const long cap_len = (tiles / 21 < 64) ? 48 : (wg <= 2 ? 96 : wg <= 4 ? 64 : 48);
     if (cap > cap_len) cap = cap_len;
     if (wg * 10 >= slots * 6) return 1;      // the batch alone (nearly) fills the chip: splitting only adds combine work
     // otherwise: fill whole rounds of resident workgroups exactly (measured on MI355X, tools/kbench.py --splits:
