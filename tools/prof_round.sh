@@ -4,7 +4,7 @@
 # (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, never combined with API traces), SQ / L2 counters of both (tools/pmc_*.sh).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
-O=${1:-gpurun_out/prof3}
+O=${1:-gpurun_out/prof4}
 mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 2 --warmup 1 --no-dynamic --no-cpu-baseline > $O/bench_prof.json 2> $O/kt.err
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) > $O/bench_kernel_stats.md 2>> $O/kt.err
