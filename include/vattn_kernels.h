@@ -34,7 +34,15 @@ extern "C" {
 #define VATTN_DTYPE_F16 0
 #define VATTN_DTYPE_BF16 1
 
+#define VATTN_KERNELS_ABI 4u            /* bumped whenever vattn_attn_params changes */
+
 typedef struct vattn_attn_params {
+    /* sizeof(vattn_attn_params) and VATTN_KERNELS_ABI of the header the CALLER was built against.  The block grows between releases
+     * (the plan fields below are extensions) and the kernels branch on pointers inside it: a caller built against an older header, or
+     * one that does not zero the block, would have the library read past its object.  Every entry point that takes the block checks
+     * both words first and refuses a mismatch (VATTN_K_ERR_INVALID).  ZERO the block (memset) before filling it in. */
+    uint32_t struct_size;
+    uint32_t abi_version;
     /* q / out: [b, seqlen_q, h, d] */
     const void* q;
     void* out;

@@ -55,6 +55,7 @@ int main(void) {
     {
         vattn_attn_params p;
         memset(&p, 0, sizeof p);
+        p.struct_size = (uint32_t)sizeof p; p.abi_version = VATTN_KERNELS_ABI;
         rc = vattn_flash_attn_with_kvcache(&p, NULL);
         printf("null_params %d err '%s'\n", rc, vattn_kernels_last_error());
         printf("workspace_bytes %zu sizeof_params %zu\n", vattn_attn_workspace_bytes(&p), sizeof p);
@@ -68,6 +69,7 @@ int main(void) {
         int32_t dlens[64], dseq[128], qlen[1] = {8192}, klen[1] = {8192}, counts[3];
         int32_t n, i, longest = 0;
         memset(&p, 0, sizeof p);
+        p.struct_size = (uint32_t)sizeof p; p.abi_version = VATTN_KERNELS_ABI;
         p.b = 64; p.seqlen_q = 1; p.seqlen_k = 32768; p.seqlen_knew = 1; p.h = 8; p.h_k = 1; p.d = 128;
         for (i = 0; i < 64; i++) dlens[i] = 500 + 450 * i;                         /* 500 .. 28 850 tokens */
         n = vattn_decode_plan(&p, dlens, ditems, 4096, dseq);
@@ -78,6 +80,7 @@ int main(void) {
         }
         printf("decode_plan items %d first_seq_pieces %d last_seq_pieces %d longest_piece_tiles %d\n", n, dseq[1], dseq[127], longest);
         memset(&p, 0, sizeof p);
+        p.struct_size = (uint32_t)sizeof p; p.abi_version = VATTN_KERNELS_ABI;
         p.b = 1; p.seqlen_q = 8192; p.h = 8; p.h_k = 1; p.d = 128; p.is_causal = 1;
         n = vattn_prefill_plan(&p, qlen, klen, pitems, 4096, pblocks, 512, counts);
         printf("prefill_plan items %d split_blocks %d partial_rows %d first_piece_tiles %d last_piece_tiles %d\n", n, counts[1], counts[2],

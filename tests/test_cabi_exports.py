@@ -47,6 +47,27 @@ def test_params_struct_matches_header_size():
     assert ctypes.sizeof(K.DecodeItem) == sz_di == 16 and ctypes.sizeof(K.PrefillItem) == sz_pi == 32
 
 
+def test_params_block_carries_its_size_and_abi_version():
+    """the block grows between releases and the kernels branch on pointers inside it.  A caller built against another
+    header (wrong struct_size / abi_version), or one that forgot to set them, is refused by every entry point that takes the block
+    — never read past."""
+    from vattention_amd import kernels as K
+    lib = K.klib()
+    p = K.AttnParams()
+    assert p.struct_size == ctypes.sizeof(K.AttnParams) and p.abi_version == K.ABI_VERSION
+    p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d = 4, 1, 4096, 8, 2, 128
+    assert lib.vattn_attn_workspace_bytes(ctypes.byref(p)) > 0
+    for field, bad in (("struct_size", p.struct_size - 16), ("abi_version", K.ABI_VERSION - 1), ("struct_size", 0)):
+        q = K.AttnParams()
+        q.b, q.seqlen_q, q.seqlen_k, q.h, q.h_k, q.d = 4, 1, 4096, 8, 2, 128
+        setattr(q, field, bad)
+        assert lib.vattn_attn_workspace_bytes(ctypes.byref(q)) == 0
+        assert lib.vattn_flash_attn_with_kvcache(ctypes.byref(q), None) == -11
+        assert b"struct_size" in lib.vattn_kernels_last_error()
+        assert lib.vattn_attn_plan_describe(ctypes.byref(q), ctypes.byref(K.PlanDesc())) == -11
+        assert lib.vattn_decode_plan(ctypes.byref(q), (ctypes.c_int32 * 4)(1, 2, 3, 4), (K.DecodeItem * 8)(), 8, (ctypes.c_int32 * 8)()) == -11
+
+
 def test_no_gpu_calls_fail_loudly():
     """Without a device the product refuses to run instead of falling back."""
     import pytest

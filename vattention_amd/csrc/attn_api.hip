@@ -202,8 +202,13 @@ int fail(int code, const char* msg) {
     return code;
 }
 
+// the caller's header and ours describe the same block (include/vattn_kernels.h)
+bool abi_ok(const vattn_attn_params* p) { return p && p->struct_size == (uint32_t)sizeof(vattn_attn_params) && p->abi_version == VATTN_KERNELS_ABI; }
+
 int validate(const vattn_attn_params* p) {
-    if (!p || !p->q || !p->out || !p->k_cache || !p->v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
+    if (!p) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
+    if (!abi_ok(p)) return fail(VATTN_K_ERR_INVALID, "vattn_attn_params: struct_size / abi_version do not match this library (zero the block, then set both from include/vattn_kernels.h)");
+    if (!p->q || !p->out || !p->k_cache || !p->v_cache) return fail(VATTN_K_ERR_INVALID, "null tensor pointer");
     if (p->dtype != VATTN_DTYPE_F16 && p->dtype != VATTN_DTYPE_BF16)
         return fail(VATTN_K_ERR_UNSUPPORTED, "FlashAttention only support fp16 and bf16 data type");      // flash_api.cpp:1325-1326
     // d = 256 instantiates but spills (O^T alone is 128 accumulator registers per wave): not shipped until it has its own tiling
@@ -252,6 +257,7 @@ extern "C" {
 const char* vattn_kernels_last_error(void) { return g_err.c_str(); }
 
 size_t vattn_attn_workspace_bytes(const vattn_attn_params* p) {
+    if (!abi_ok(p)) return 0;
     if (!p || p->h_k <= 0 || p->h <= 0 || p->b <= 0 || p->seqlen_q <= 0) return 0;
     return p->seqlen_q != 1 ? prefill_workspace_bytes(p) : decode_workspace_bytes(p);
 }
@@ -265,6 +271,7 @@ int vattn_flash_attn_with_kvcache(const vattn_attn_params* p, void* stream) {
 }
 
 int vattn_attn_plan_describe(const vattn_attn_params* p, vattn_plan_desc* out) {
+    if (!abi_ok(p)) return fail(VATTN_K_ERR_INVALID, "vattn_attn_params: struct_size / abi_version do not match this library");
     if (!p || !out || p->h_k <= 0 || p->h <= 0 || p->b <= 0 || p->seqlen_q <= 0 || (p->d != 64 && p->d != 128)) return fail(VATTN_K_ERR_INVALID, "vattn_attn_plan_describe: bad shape");
     memset(out, 0, sizeof *out);
     if (p->seqlen_q == 1) decode_describe(p, out);
@@ -274,15 +281,18 @@ int vattn_attn_plan_describe(const vattn_attn_params* p, vattn_plan_desc* out) {
 }
 
 int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqlens_host, vattn_decode_item* items_out, int32_t cap, int32_t* seq_out) {
+    if (!abi_ok(p)) return VATTN_K_ERR_INVALID;
     return decode_plan(p, cache_seqlens_host, items_out, cap, seq_out);
 }
 
 int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
                            int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* counts_out) {
+    if (!abi_ok(p)) return VATTN_K_ERR_INVALID;
     return prefill_worklist(p, q_lens_host, k_lens_host, items_out, cap_items, blocks_out, cap_blocks, counts_out);
 }
 
 size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode) {
+    if (!abi_ok(prefill) || !abi_ok(decode)) return 0;
     if (!prefill || !decode || decode->h_k <= 0 || decode->h <= 0 || decode->b <= 0) return 0;
     return hybrid_workspace_bytes(prefill, decode);
 }

@@ -451,7 +451,7 @@ int PageManager::wait_layer(uint32_t layer) {
         layer_wait_ns_ += now_ns() - t0;
     }
     // (no message is written here: last_error_ belongs to the calls that hold state_mu_, and the engine thread may be inside
-    // one of them; the C entry point reports a fixed text for this code, the next step()/wait() reports the driver's message)
+    // one of them; the C entry point returns only the code — vattn_last_error is NOT updated, include/vattn.h; the Python wrapper raises a fixed text — and the next step()/wait() reports the driver's message)
     return layered_error_.load();
 }
 
@@ -732,7 +732,7 @@ int PageManager::ensure_created(uint32_t page) {   // exec_mu_ held
     return VATTN_OK;
 }
 
-int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async, size_t* first_failed, bool layered) {   // exec_mu_ held
+int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async, size_t* first_failed, bool layered, bool skip_maps) {   // exec_mu_ held
     const uint64_t t0 = now_ns();
     const uint64_t page = cfg_.page_size;
     const bool merge = !(cfg_.flags & VATTN_FLAG_NO_ACCESS_MERGE);
@@ -770,8 +770,11 @@ int PageManager::execute(const std::vector<PhysOp>& ops, bool is_async, size_t* 
         layer_cv_.notify_all();
     };
     int rc = VATTN_OK;          // first error
-    bool map_failed = false;    // a create / map failed: the remaining maps are skipped (and rolled back by the caller),
-                                // the remaining unmaps — whose bookkeeping is already applied — still run
+    bool map_failed = skip_maps; // a create / map failed: the remaining maps are skipped (and rolled back by the caller),
+                                // the remaining unmaps — whose bookkeeping is already applied — still run.  skip_maps: an EARLIER batch of
+                                // this join window failed — this one's maps are not even tried (they sit above positions the joiner
+                                // is about to take back), only its unmaps run
+    if (skip_maps && first_failed) *first_failed = 0;
     bool unmapped = false, quiesced = false;
     const uint64_t c0_ns = st_.create_ns, c0_n = st_.handles_created, f0_ns = st_.fence_wait_ns + st_.quiesce_ns, m0 = st_.map_calls, u0 = st_.unmap_calls;
     uint64_t tlb_ns = 0;
@@ -880,12 +883,20 @@ void PageManager::rollback_maps(const std::vector<PhysOp>& ops, size_t first_fai
     }
     if (groups.empty()) return;
     std::lock_guard<std::mutex> e(exec_mu_);
+    bool quiesced = false;
     for (size_t jj = ops.size(); jj-- > 0;) {
         const PhysOp& op = ops[jj];
         if (op.kind != 0) continue;
         const auto g = std::make_pair(op.slot, pos_of(op));
         if (std::find(groups.begin(), groups.end(), g) == groups.end()) continue;
         if (jj < first_failed) {                             // this one reached the driver: take it out again
+            // ... but kernels of the running iteration may already read it (the synchronously mapped first layers of a layer-ordered
+            // step): the device drains once before the first unmap of a rollback (an error path: the cost does not matter)
+            if (!quiesced && be_.quiesce) {
+                (void)be_.quiesce(be_.ctx);
+                st_.quiesce_calls++;
+                quiesced = true;
+            }
             if (be_.unmap(be_.ctx, bases_[op.tensor] + op.offset, cfg_.page_size) == 0) {
                 st_.unmap_calls++;
                 st_.pages_mapped_now--;
@@ -906,12 +917,14 @@ void PageManager::rollback_maps(const std::vector<PhysOp>& ops, size_t first_fai
 int PageManager::wait_locked_free() {   // state_mu_ held; joins every queued background batch
     const uint64_t t0 = now_ns();
     std::vector<PhysOp> failed;
+    std::vector<std::vector<PhysOp>> later;
     size_t failed_at = 0;
     int e = 0;
     {
         std::unique_lock<std::mutex> q(q_mu_);
         done_cv_.wait(q, [this] { return inflight_ == 0; });
         join_wait_ns_ += now_ns() - t0;
+        later.swap(failed_later_);
         if (have_failed_) {
             failed.swap(failed_ops_);
             failed_at = failed_at_;
@@ -929,6 +942,7 @@ int PageManager::wait_locked_free() {   // state_mu_ held; joins every queued ba
         if (e) last_error_ = async_error_msg_;
         if (!fatal_) async_error_ = 0;          // reported once; bookkeeping is consistent again after the rollback below
     }
+    for (size_t i = later.size(); i-- > 0;) rollback_maps(later[i], 0);      // youngest first: each batch maps above the one before it
     if (!failed.empty()) rollback_maps(failed, failed_at);
     return e;
 }
@@ -990,13 +1004,21 @@ void PageManager::mapper_main() {
             q.unlock();
             int rc;
             size_t failed_at = ops.size();
+            const bool after_failure = have_failed_;      // (q_mu_ was held when this was read; only this thread sets it)
             {
                 std::lock_guard<std::mutex> e(exec_mu_);
-                rc = execute(ops, true, &failed_at, layered);
+                rc = execute(ops, true, &failed_at, layered, after_failure);
             }
             q.lock();
             if (rc && !async_error_) async_error_ = rc;
-            if (rc && failed_at < ops.size() && !have_failed_) {      // the joiner rolls the unexecuted maps back
+            if (after_failure) {
+                // a batch queued BEHIND a failed one (step_async queues the look-ahead right after the layer-ordered half): its maps lie
+                // at or above the positions the joiner takes back from the failed batch — executed, they would stay mapped in the
+                // driver and in pagemap_ under a slot whose count no longer covers them.  None of them ran; the joiner reverts them all.
+                bool any_map = false;
+                for (const PhysOp& op : ops) any_map |= op.kind == 0;
+                if (any_map) failed_later_.emplace_back(std::move(ops));
+            } else if (rc && failed_at < ops.size()) {      // the joiner rolls the unexecuted maps back
                 failed_ops_ = std::move(ops);
                 failed_at_ = failed_at;
                 have_failed_ = true;

@@ -157,6 +157,7 @@ private:
     vattn_stats st_{};
     // a background batch whose map failed: the joiner rolls its unexecuted maps back (bookkeeping is guarded by state_mu_,
     // which the mapper never takes)
+    std::vector<std::vector<PhysOp>> failed_later_;   // batches queued behind a failed one: their maps were not tried (page_manager.cpp, mapper_main)
     std::vector<PhysOp> failed_ops_;
     size_t failed_at_ = 0;
     bool have_failed_ = false;
@@ -176,7 +177,7 @@ private:
 
     int flush_sync();
     void flush_async();
-    int execute(const std::vector<PhysOp>& ops, bool is_async, size_t* first_failed, bool layered = false);
+    int execute(const std::vector<PhysOp>& ops, bool is_async, size_t* first_failed, bool layered = false, bool skip_maps = false);
     void note_popped(uint32_t lowest);
     int ensure_created(uint32_t page);
     void mapper_main();

@@ -277,7 +277,15 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+            if (my_q < Sq) {
+                if constexpr ((ABL & 1024) != 0) {      // LAB A/B: Q read once per workgroup — streaming (nt), so that it does not evict the K/V the XCD shares
+                    typedef unsigned nt4 __attribute__((ext_vector_type(4)));
+                    const nt4 t = __builtin_nontemporal_load((const nt4*)(qptr + 16 * kk + 8 * g));
+                    v = make_uint4(t[0], t[1], t[2], t[3]);
+                } else {
+                    v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+                }
+            }
             raw[kk] = as_v8<V8>(v);
         }
         if (p.rotary_cos_sin && my_q < Sq) {
@@ -641,7 +649,13 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                         __builtin_memcpy(&uo, &wo, 8);
                         const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
-                        *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        if constexpr ((ABL & 1024) != 0) {      // LAB A/B: O written once — nt
+                            typedef unsigned nt4 __attribute__((ext_vector_type(4)));
+                            const nt4 t = {r0[0], r1[0], r0[1], r1[1]};
+                            __builtin_nontemporal_store(t, (nt4*)(optr + 32 * db + 8 * (2 * pr + g)));
+                        } else {
+                            *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        }
                     }
             } else {
 #pragma unroll
@@ -710,6 +724,7 @@ void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, in
             case 2: return launch64_t<_Float16, 128, 24, 4, 4, 8, 9, 3>(p, st, nsplit, done, merge_mode);    // row-max chain from group 4
             case 11: return launch64_t<_Float16, 128, 24, 4, 8, 12, 13, 2>(p, st, nsplit, done, merge_mode); // barrier after group 11, DMA every second group
             case 12: return launch64_t<_Float16, 128, 24, 4, 8, 24, 24, 1>(p, st, nsplit, done, merge_mode); // round 2's placement: barrier after 23, DMA 24-31
+            case 15: return launch64_t<_Float16, 1024 | 128, 24, 4>(p, st, nsplit, done, merge_mode);         // A/B (round 4): non-temporal Q loads and O stores
             case 10: return launch64_t<_Float16, 256 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no epilogue stores
             case 13: return launch64_t<_Float16, 512 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no zero-fill of the V ring
             case 4: return launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no LDS-DMA in the steady state

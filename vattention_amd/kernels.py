@@ -10,8 +10,12 @@ from . import _lib as L
 vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
 
 
+ABI_VERSION = 4      # VATTN_KERNELS_ABI of include/vattn_kernels.h
+
+
 class AttnParams(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
         ("q", vp), ("out", vp),
         ("q_batch_stride", i64), ("q_row_stride", i64), ("q_head_stride", i64),
         ("o_batch_stride", i64), ("o_row_stride", i64), ("o_head_stride", i64),
@@ -30,6 +34,14 @@ class AttnParams(C.Structure):
         ("split_items", vp), ("split_seq", vp), ("num_split_items", i32), ("split_reserved", i32),
         ("pf_items", vp), ("pf_blocks", vp), ("num_pf_items", i32), ("num_pf_blocks", i32), ("pf_part_rows", i32), ("pf_reserved", i32),
     ]
+
+
+def _attn_params_init(self, *a, **kw):
+    C.Structure.__init__(self, *a, **kw)      # zero-initialised by ctypes
+    self.struct_size, self.abi_version = C.sizeof(AttnParams), ABI_VERSION
+
+
+AttnParams.__init__ = _attn_params_init
 
 
 class PlanDesc(C.Structure):
