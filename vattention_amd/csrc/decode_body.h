@@ -25,7 +25,8 @@ template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES, int PF 
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
                                             const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0,
                                             const int item = -1, const int item_tb = 0, const int item_te = 0,
-                                            const int st_mode = 0, const int st_slot = 0, const int st_lk = 0, const unsigned st_block = 0) {
+                                            const int st_mode = 0, const int st_slot = 0, const int st_lk = 0, const unsigned st_block = 0,
+                                            const int st_done = 0, const int st_total = 0) {
     // st_mode != 0: a piece [item_tb, item_te) of the device-planned stream decomposition (decode_stream_kernel below).  Slot and visible
     // length come from the workgroup's plan (LDS) instead of two dependent global loads; st_mode 1 = the piece is the whole sequence: the
     // final rows are written; st_mode 2 = a partial, published as one record block at byte offset st_block of the workspace (16-byte
@@ -304,6 +305,18 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
 #pragma unroll
         for (int u = 0; u < PF; u++) load_tile(u, first + u * W < loop_end ? first + u * W : ntiles_total);
         for (int tile0 = first; tile0 < loop_end; tile0 += PF * W) {
+            if (st_total > 0) {
+                // (LAB, off in the product: measured neutral.)  FAIR SHARE of the CU among its resident workgroups.  The CU issues the vector-memory instructions of its OLDEST waves
+                // first: three workgroups of equal work, dispatched back to back, finish one after the other (B16 @ 32 k: ids 0-255 at
+                // 100 us, 256-511 at 149 us, 512-767 at 178 us, tools/decode_skew_probe.py) and the CU spends the last third of the launch
+                // with a third of its waves — too few bytes in flight.  Issue priority follows the share of the workgroup's range that
+                // is still ahead of it, in quarters: whoever is behind outranks whoever is ahead, age only breaks ties inside a quarter.
+                const int q4 = (4 * (st_total - st_done - (tile0 - tile_begin))) / st_total;      // wave-uniform
+                if (q4 >= 3) __builtin_amdgcn_s_setprio(3);
+                else if (q4 == 2) __builtin_amdgcn_s_setprio(2);
+                else if (q4 == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
 #pragma unroll
             for (int u = 0; u < PF; u++) {
                 const int tile = tile0 + u * W;
@@ -727,8 +740,14 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     const int nwg = gridDim.x, w = blockIdx.x;
     const int X = stream_switch_tiles(p);
     constexpr unsigned RB = StreamRec<NB, HD>::kFloats * 4u;
+    // LAB instrumentation (tools/decode_skew_probe.py, variant bit 22): the buffer behind softmax_lse receives, from its 32 KiB mark on,
+    // per workgroup the 100 MHz wall clock at entry, after the plan and at exit
+    unsigned long long* const ts = (kLab && (p.variant & (1 << 22)) && p.softmax_lse) ? (unsigned long long*)p.softmax_lse + 4096 : nullptr;
+    const unsigned wg_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (kLab && ts && tid == 0) ts[3 * wg_id] = wall_clock64();
     StreamPlan pl;
     stream_plan_load(p, X, pl);
+    if (kLab && ts && tid == 0) ts[3 * wg_id + 1] = wall_clock64();
     const StreamGeom geo = stream_geom(pl.total, pl.maxt, p.b, nwg);
     auto publish_and_merge = [&](const int b, const int first_rec, const int cnt) {      // LAB: in-launch merge
         // publish: this workgroup's record stores have left the CU (write-through), then ONE device-scope ticket
@@ -743,6 +762,11 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     };
     // the current piece (all wave-uniform): sequence, its slot and visible length, tiles [tb, te), the sequence's records
     int b, slot, lk, tb, te, first_rec, cnt;
+    int done = 0, total = 0;                            // tiles of this workgroup's range behind / in all of its pieces (fair-share priority)
+    // LAB ONLY (variant bit 23): fair-share issue priority, see decode_body.  It does what it was built for — the three workgroups of a CU
+    // finish within 20 us of each other instead of 80 — and changes the launch time by < 0.5 % on every shape (profiles/r04_decode_skew.txt):
+    // a CU with one or two workgroups left still draws its share of the bandwidth, so the staggered finish was never the loss.
+    const bool fair = kLab && (p.variant & (1 << 23)) != 0;
     int g0 = 0, g1 = 0;
     // stream mode: the first piece at or after sequence `from` that holds real tiles of this workgroup's range (plan read from LDS)
     auto next_piece = [&](const int from) -> bool {
@@ -775,10 +799,12 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
         first_rec = b * geo.S + b;
         slot = stream_plan_get(pl.slot, pl.sh, b);
         lk = stream_plan_get(pl.lk, pl.sh, b);
+        total = fair ? te - tb : 0;
     } else {
         g0 = w * geo.T;
         if (g0 >= pl.total) return;
         g1 = min(pl.total, g0 + geo.T);
+        total = fair ? g1 - g0 : 0;
         // the range may hold several sequences: the plan moves to LDS (every wave stores the SAME values and reads only after its own
         // stores: no barrier), so that its twelve registers are not carried through the key loops
         const int b0 = stream_plan_find(pl, g0);
@@ -796,9 +822,17 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     for (;;) {
         const unsigned blk = stream_table_bytes(p.b) + (((unsigned)(w + b) * p.h_k + hk) * gblocks + gb) * RB;
         if (tb == 0 && hk == 0 && gb == 0 && tid == 0) stream_publish_seq(p, b, first_rec, cnt);      // (the owner of the sequence's first piece)
-        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, 0, tb, te, cnt == 1 ? 1 : (kLab && counters) ? 3 : 2, slot, lk, blk);
+        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, 0, tb, te, cnt == 1 ? 1 : (kLab && counters) ? 3 : 2, slot, lk, blk,
+                                       done, total);
+        done += te - tb;
         if (kLab && cnt > 1 && counters != nullptr) publish_and_merge(b, first_rec, cnt);      // product: the records are merged by decode_stream_combine_kernel
-        if (geo.uniform || !next_piece(b + 1)) return;
+        if (geo.uniform || !next_piece(b + 1)) {
+            if (kLab && ts) {
+                __syncthreads();
+                if (tid == 0) ts[3 * wg_id + 2] = wall_clock64();
+            }
+            return;
+        }
         __syncthreads();                                 // the previous piece's in-workgroup merge is done with the LDS
     }
 }
