@@ -290,6 +290,38 @@ def test_pod_sweep_shapes_at_the_reference_tolerance(Hq, Hkv, cs, cl, bs):
     assert torch.allclose(out_d.cpu().float(), ref_d.float(), atol=1e-3), "decode output mismatch: %.3e" % (out_d.cpu().float() - ref_d.float()).abs().max().item()
 
 
+@pytest.mark.parametrize("B,lo,hi,Hkv,nwg", [(256, 4000, 29000, 1, 0), (16, 32767, 32767, 4, 0), (40, 1, 3000, 8, -7), (9, 10, 2500, 2, -11), (100, 0, 900, 1, -50)],
+                         ids=["ragged256", "uniform16", "spanning", "few", "sparse"])
+def test_decode_stream_plan_table_matches_the_model(B, lo, hi, Hkv, nwg):
+    """The plan the decode launch derives ON THE DEVICE — the (first record, count) of every sequence, left at the head of the launch's
+    workspace for the merge launch — against its CPU restatement (oracle/stream_plan.py), for the product's own workgroup count
+    (vattn_attn_plan_describe) and forced ones."""
+    import ctypes as C
+    import vattention_amd.flash_attn as FA
+    from oracle.stream_plan import plan as model
+    from vattention_amd import kernels as K
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    g = torch.Generator().manual_seed(B + hi)
+    lens = torch.randint(lo, hi + 1, (B,), generator=g).tolist()
+    Hq, D = Hkv * 4, 128
+    ml = max(lens) + 1
+    kc = torch.randn(B, ml, Hkv, D, device=DEV, dtype=torch.float16)
+    vc = torch.randn(B, ml, Hkv, D, device=DEV, dtype=torch.float16)
+    q = torch.randn(B, 1, Hq, D, device=DEV, dtype=torch.float16)
+    kn, vn = torch.randn(B, 1, Hkv, D, device=DEV, dtype=torch.float16), torch.randn(B, 1, Hkv, D, device=DEV, dtype=torch.float16)
+    cap = []
+    FA._workspaces.clear()
+    flash_attn_with_kvcache(q, kc, vc, kn, vn, cache_seqlens=torch.tensor(lens, dtype=torch.int32, device=DEV), causal=True, num_splits=nwg, _params_out=cap)
+    torch.cuda.synchronize()
+    d = K.describe(cap[0])
+    assert d["path"] == 2
+    per_head = d["workgroups"] // Hkv
+    uniform, pieces, records = model(lens, ml, 1, per_head)
+    ws = next(iter(FA._workspaces.values()))
+    table = ws[:2 * B].view(torch.int32).cpu().view(B, 2).tolist()
+    assert [tuple(r) for r in table] == records, "device plan differs from the model (uniform=%s, %d workgroups per kv head)" % (uniform, per_head)
+
+
 def _op_names():
     from tests.test_attn_oracle import _intree_cases
     return [n for n in _intree_cases()[1] if n.startswith("op_")]
