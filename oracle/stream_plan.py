@@ -35,6 +35,10 @@ def plan(lens: List[int], seqlen_k: int, seqlen_knew: int, nwg: int, switch_tile
     T = max(DC_MIN_WG_TILES, (total + nwg - 1) // nwg)
     S = nwg // B
     uniform = S >= 1 and (maxt + S - 1) // S <= T
+    if not uniform:          # a short tile space: fewer, longer ranges (stream_geom)
+        tpw = total // nwg
+        eff = max(1, nwg // 3) if tpw < 20 else nwg
+        T = max(DC_MIN_WG_TILES, (total + eff - 1) // eff)
     pieces: List[List[Tuple[int, int, int, int]]] = [[] for _ in range(nwg)]
     records = []
     if uniform:

@@ -1,6 +1,3 @@
-S="B1@128k,B1@32k,B1@8k,B2@32k,B4@32k"
-for i in 1 2; do
-echo "== product (grid heuristics for B=1)"; python tools/kbench.py decode --rotate --only "$S" 2>&1 | grep "splits="
-echo "== lab: two K/V register sets per wave (PF = 2), grid heuristics"; python tools/kbench.py decode --variant $((262144 + 524288)) --rotate --only "$S" 2>&1 | grep "splits="
-done
-for n in 32 48 64 96; do echo "== PF=2, $n splits"; python tools/kbench.py decode --variant $((262144 + 524288)) --rotate --only "B1@128k,B1@32k" --splits $n 2>&1 | grep "splits="; done
+python tools/ragged_decode_probe.py 2>&1 | grep "==\|DEVICE\|512 work\|768 work\|256 work\|EQUAL"
+python tools/ragged_decode_probe.py --small 2>&1 | grep "==\|DEVICE\|512 work\|768 work\|256 work\|EQUAL"
+echo "== kbench rotating"; python tools/kbench.py decode --rotate --only "B16@32k,B8@32k,B4@32k,B64@8k,B256@2k,tp8 B64,B16@2k" 2>&1 | grep "splits="

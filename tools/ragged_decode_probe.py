@@ -32,7 +32,8 @@ def timeit(fn, iters=30):
 def main():
     torch.zeros(1, device=DEV)
     reqs = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "c3_arxiv_lengths_256.json")))["requests"]
-    for scale, what in ((1.0, "trace prompt lengths + 100"), (0.5, "half of them")):
+    SCALES = ((1.0, "trace prompt lengths + 100"), (0.5, "half of them")) if "--small" not in sys.argv else ((0.25, "a quarter of them"), (0.12, "an eighth of them"))
+    for scale, what in SCALES:
         lens = [int(p * scale) + 100 for p, _ in reqs]
         B, ctx = len(lens), max(lens) + 8
         kc = torch.randn(B, ctx, Hkv, D, device=DEV, dtype=torch.float16)
@@ -55,7 +56,7 @@ def main():
         cl = torch.tensor(lens, dtype=torch.int32, device=DEV)
         run(cl, None, 0, "DEVICE-planned stream (product default)", 0)
         run(cl, None, 0, "device-planned stream, in-launch merge (lab)", 1 << 20)
-        for n in (384, 512, 640, 768, 1024, 1536):
+        for n in (256, 384, 512, 640, 768, 1024, 1536):
             run(cl, None, 0, "device-planned stream, %d workgroups" % n, 0, -n)
         import vattention_amd.flash_attn as FA
         for x in (0, 2, 8, 16):

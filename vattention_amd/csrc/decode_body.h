@@ -573,6 +573,17 @@ __device__ __forceinline__ StreamGeom stream_geom(const int total, const int max
     g.T = stream_tiles_per_wg(total, nwg);
     g.S = nwg / B;
     g.uniform = g.S >= 1 && (maxt + g.S - 1) / g.S <= g.T;
+    if (!g.uniform) {
+        // A SHORT tile space is streamed by fewer, longer ranges: a third of the workgroups (one per CU) below 20 positions per
+        // workgroup — the rest of the grid exits at once.  The host sized the grid for the longest contexts the cache view allows; how
+        // much there really is to read is only known here.  [Measured, 256 ragged sequences on one kv head, mean 1.2 k tokens: 34.8 us
+        // with 256 workgroups, 36.2 with 512, 36.4 with 768 (profiles/r04_decode_stream.txt (7)): every range pays a prologue, a record
+        // and a share of the merge, and a launch of a few tens of microseconds has no stream to hide them behind.  Between 20 and 64
+        // positions two workgroups per CU measured within the noise of three (2.5 k tokens: 59.2 vs 61.7 us; 4.8 k: 122 vs 123-127).]
+        const int tpw = total / nwg;
+        const int eff = tpw < 20 ? max(1, nwg / 3) : nwg;
+        g.T = stream_tiles_per_wg(total, eff);
+    }
     return g;
 }
 // records of sequence b (tiles at positions [excl + X, incl)): first record and count
