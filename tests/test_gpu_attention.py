@@ -322,6 +322,22 @@ def test_decode_stream_plan_table_matches_the_model(B, lo, hi, Hkv, nwg):
     assert [tuple(r) for r in table] == records, "device plan differs from the model (uniform=%s, %d workgroups per kv head)" % (uniform, per_head)
 
 
+def test_decode_stream_plan_without_cache_seqlens_or_batch_idx():
+    """cache_seqlens = None (every sequence is the whole cache view) and cache_batch_idx = None (identity): the device-side plan takes
+    both defaults (flash_attn_interface.py:1168-1254: both arguments are optional)."""
+    from vattention_amd.flash_attn import flash_attn_with_kvcache
+    torch.manual_seed(21)
+    B, Hq, Hkv, D, ctx = 5, 8, 2, 128, 1500
+    q = torch.randn(B, 1, Hq, D).half()
+    kc, vc = torch.randn(B, ctx, Hkv, D).half(), torch.randn(B, ctx, Hkv, D).half()
+    ref64 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=torch.full((B,), ctx, dtype=torch.int32), causal=True)
+    ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=torch.full((B,), ctx, dtype=torch.int32), causal=True, math="f32")
+    for nwg in (0, -3, -40):
+        out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), causal=True, num_splits=nwg)
+        torch.cuda.synchronize()
+        _check(out, ref64, ref32, torch.float16, "decode without cache_seqlens, num_splits=%d" % nwg)
+
+
 def _op_names():
     from tests.test_attn_oracle import _intree_cases
     return [n for n in _intree_cases()[1] if n.startswith("op_")]
