@@ -176,10 +176,29 @@ def rooflines(detail: dict, traffic=None) -> dict:
     return out
 
 
+_REAL_STDOUT = None
+
+
+def _own_stdout():
+    """stdout carries the bench line and nothing else: whatever the libraries print on fd 1 (the page manager dumps its state there before
+    an OOM error, as the reference does, vattention.cu:294-295 — the capacity leg provokes one) is sent to stderr from here on."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line: str):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(a))
+    _own_stdout()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -246,10 +265,10 @@ def main():
             res = capacity_leg(dev, mem_for_kv)
         else:
             raise SystemExit("--leg must be dynamic, dynamic_tp8_rank or capacity")
-        print(json.dumps({a.leg: res}), flush=True)
+        _emit(json.dumps({a.leg: res}))
         return
     if a.qps:       # stand-alone open-loop replay (not a bench line)
-        print(json.dumps(open_loop_leg(make_runner, mem_for_kv, lengths256, a.qps, a.requests or 256)), flush=True)
+        _emit(json.dumps(open_loop_leg(make_runner, mem_for_kv, lengths256, a.qps, a.requests or 256)))
         return
 
     runner = make_runner(w["model"], w["tp"], w["ctx"], w["page"], w["batch"], w["backend"], mem_for_kv, a.layers)
@@ -508,7 +527,7 @@ def main():
             dig["capacity"] = {k: extras["capacity"].get(k) for k in ("mapped_over_budget", "mapped_over_hbm", "tokens_resident", "fill_seconds")}
         if dig:
             out["legs"] = dig
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
 
 
 def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, dtype, with_cpu) -> dict:

@@ -44,3 +44,20 @@ def test_open_loop_interval_recipe_matches_the_reference_generator():
         t += min(-math.log(1.0 - arng.random()) / qps, 3.0 / qps)
         got.append(t)
     assert got == want and max(b - a for a, b in zip(got, got[1:])) <= 3.0 / qps + 1e-12
+
+
+def test_stdout_carries_the_bench_line_only():
+    """bench.py owns fd 1: what a library prints there (the page manager's state dump before an OOM error, 260 lines in the capacity leg)
+    goes to stderr, and stdout is exactly ONE JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, ctypes; sys.path.insert(0, %r); import bench; bench._own_stdout(); print('python noise'); "
+            "ctypes.CDLL(None).puts(b'native noise'); ctypes.CDLL(None).fflush(None); os.write(1, b'raw fd noise\\n'); bench._emit('{\"metric\": 1}')" % root)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("\n") == 1 and json.loads(r.stdout) == {"metric": 1}, r.stdout
+    for noise in ("python noise", "native noise", "raw fd noise"):
+        assert noise in r.stderr
