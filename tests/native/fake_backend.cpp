@@ -27,6 +27,7 @@ struct Fake {
     std::set<uint32_t> fences;                              // slots with a recorded fence
     uint64_t n_fence_wait = 0;
     int delay_us = 0;
+    bool validate = true;      // false: count calls only (tools/pagemgr_steps_bench.py prices the manager, not this double's containers)
 };
 Fake g;
 
@@ -53,11 +54,12 @@ int f_create(void*, uint64_t, uint64_t* out) {
     if (g.n_create >= g.fail_create_after) return -1;
     g.n_create++;
     *out = g.next_handle++;
-    g.live_handles.insert(*out);
+    if (g.validate) g.live_handles.insert(*out);
     return 0;
 }
 int f_release(void*, uint64_t h) {
     std::lock_guard<std::mutex> l(g.mu);
+    if (!g.validate) { g.n_release++; return 0; }
     if (!g.live_handles.erase(h)) { g.violations++; return -1; }
     g.n_release++;
     return 0;
@@ -72,6 +74,7 @@ int f_map(void*, uint64_t va, uint64_t bytes, uint64_t h) {
     std::lock_guard<std::mutex> l(g.mu);
     if (g.n_map >= g.fail_map_after) return -1;            // injected driver failure (not a contract violation)
     g.n_map++;
+    if (!g.validate) return 0;
     if (!inside_reservation(va, bytes) || !g.live_handles.count(h) || g.mapped.count(va) || va % g.min_gran) { g.violations++; return -1; }
     g.mapped[va] = {bytes, h};
     return 0;
@@ -79,6 +82,7 @@ int f_map(void*, uint64_t va, uint64_t bytes, uint64_t h) {
 int f_access(void*, uint64_t va, uint64_t bytes) {
     std::lock_guard<std::mutex> l(g.mu);
     g.n_access++;
+    if (!g.validate) return 0;
     uint64_t p = va;
     while (p < va + bytes) {            // the range must be exactly covered by whole mappings
         auto it = g.mapped.find(p);
@@ -92,6 +96,7 @@ int f_access(void*, uint64_t va, uint64_t bytes) {
 int f_unmap(void*, uint64_t va, uint64_t bytes) {
     std::lock_guard<std::mutex> l(g.mu);
     g.n_unmap++;
+    if (!g.validate) return 0;
     // (unmaps of a freed slot's pages must follow a fence wait or a quiesce; pages an ACTIVE slot no longer needs may go at once)
     auto it = g.mapped.find(va);
     if (it == g.mapped.end() || it->second.first != bytes) { g.violations++; return -1; }
@@ -135,8 +140,9 @@ void vattn_fake_reset(uint64_t min_gran, uint64_t rec_gran) {
     g.violations = g.n_create = g.n_map = g.n_access = g.n_unmap = g.n_release = 0;
     g.next_handle = 1; g.next_va = 0x7f0000000000ull; g.fail_create_after = ~0ull; g.fail_map_after = ~0ull;
     g.fences.clear(); g.n_fence_wait = 0;
-    g.min_gran = min_gran; g.rec_gran = rec_gran;
+    g.min_gran = min_gran; g.rec_gran = rec_gran; g.validate = true;
 }
+void vattn_fake_set_validate(int on) { g.validate = on != 0; }
 void vattn_fake_fail_create_after(uint64_t n) { g.fail_create_after = n; }
 void vattn_fake_fail_map_after(uint64_t n) { g.fail_map_after = n; }     // the (n+1)-th map call from now on the counter fails
 uint64_t vattn_fake_quiesce_count() { return g.n_quiesce; }
