@@ -26,7 +26,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
                                             const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0,
                                             const int item = -1, const int item_tb = 0, const int item_te = 0,
                                             const int st_mode = 0, const int st_slot = 0, const int st_lk = 0, const unsigned st_block = 0,
-                                            const int st_done = 0, const int st_total = 0) {
+                                            const int st_done = 0, const int st_total = 0, const int tstride = 1) {
     // st_mode != 0: a piece [item_tb, item_te) of the device-planned stream decomposition (decode_stream_kernel below).  Slot and visible
     // length come from the workgroup's plan (LDS) instead of two dependent global loads; st_mode 1 = the piece is the whole sequence: the
     // final rows are written; st_mode 2 = a partial, published as one record block at byte offset st_block of the workspace (16-byte
@@ -64,8 +64,13 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     const int ntiles_total = (st_mode && Lk <= 0) ? 1 : (Lk + DC_BN - 1) / DC_BN;
     const int tiles_per_split = (ntiles_total + num_splits - 1) / num_splits;
     // item >= 0: a piece [item_tb, item_te) of a length-balanced plan (vattn_decode_plan) instead of split `split` of num_splits
-    const int tile_begin = item >= 0 ? item_tb : split * tiles_per_split;
-    const int tile_end = min(ntiles_total, item >= 0 ? item_te : tile_begin + tiles_per_split);
+    // tstride > 1 (STRIPED pieces): this workgroup's tiles are tile_begin, tile_begin + tstride, ... — the pieces of a sequence interleave
+    // tile by tile instead of each streaming its own contiguous range, so that the workgroups that run together sweep ONE window of the
+    // sequence (tools/decode_skew_probe.py: with contiguous ranges megabytes apart, the kv head whose bytes have address bits [9:8] = 01
+    // runs 20 % behind the others and the launch waits for it).  Split mode: piece `split` of num_splits; piece mode: item_tb is the piece index.
+    const bool striped = tstride > 1;
+    const int tile_begin = item >= 0 ? item_tb : (striped ? split : split * tiles_per_split);
+    const int tile_end = min(ntiles_total, item >= 0 ? item_te : (striped ? ntiles_total : tile_begin + tiles_per_split));
 
     // Fused append (seqlen_knew == 1): the new K/V row sits at key index Lk-1.  Every workgroup that reads the tile
     // holding it substitutes the row from k_new/v_new in registers; the gb == 0 workgroup also stores it into the
@@ -298,13 +303,14 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     // loop and processed after it.
     const int last_tile = ntiles_total - 1;
     const bool special_last = fused_append || (Lk % DC_BN) != 0 || Lk <= 0;
-    const int first = __builtin_amdgcn_readfirstlane(tile_begin + wave);
-    const bool own_last = special_last && last_tile >= first && last_tile < tile_end && ((last_tile - first) % W) == 0;
+    const int wstep = __builtin_amdgcn_readfirstlane(W * tstride);          // distance between two tiles of one wave
+    const int first = __builtin_amdgcn_readfirstlane(tile_begin + wave * tstride);
+    const bool own_last = special_last && last_tile >= first && last_tile < tile_end && ((last_tile - first) % wstep) == 0;
     const int loop_end = own_last ? last_tile : tile_end;          // wave-uniform
     if (first < loop_end) {
 #pragma unroll
-        for (int u = 0; u < PF; u++) load_tile(u, first + u * W < loop_end ? first + u * W : ntiles_total);
-        for (int tile0 = first; tile0 < loop_end; tile0 += PF * W) {
+        for (int u = 0; u < PF; u++) load_tile(u, first + u * wstep < loop_end ? first + u * wstep : ntiles_total);
+        for (int tile0 = first; tile0 < loop_end; tile0 += PF * wstep) {
             if (st_total > 0) {
                 // (LAB, off in the product: measured neutral.)  FAIR SHARE of the CU among its resident workgroups.  The CU issues the vector-memory instructions of its OLDEST waves
                 // first: three workgroups of equal work, dispatched back to back, finish one after the other (B16 @ 32 k: ids 0-255 at
@@ -319,9 +325,9 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
             }
 #pragma unroll
             for (int u = 0; u < PF; u++) {
-                const int tile = tile0 + u * W;
+                const int tile = tile0 + u * wstep;
                 if (tile >= loop_end) break;                 // wave-uniform
-                const int nxt = tile + PF * W;
+                const int nxt = tile + PF * wstep;
                 process_tile(std::false_type{}, u, tile, nxt < loop_end ? nxt : ntiles_total);
             }
         }
@@ -535,6 +541,13 @@ __device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params
 //     last piece merges inside the launch (device-scope ticket per (sequence, kv head)): measured equal or slower, see decode_kernels.hip.
 // Partials travel as 16-byte device-scope (write-through) stores — nothing is left dirty in the L2s for the kernel boundary to write
 // back — one 128-byte-aligned record block per (record, kv head, group) that exactly one workgroup writes and exactly one reads.
+// STRIPED pieces (see decode_body).  Product: the split-KV launch of ONE sequence (profiles/r04_decode_striped_ab.txt: one 128 k sequence
+// on 28 / 4 heads 60.5 -> 58.5 us; chip-filling batches +-0, one kv head per GPU -3 %: those keep contiguous pieces).  LAB: variant bit 24
+// stripes every uniform decomposition, bit 25 keeps the single sequence contiguous (A/B: tools/decode_striped_ab.py).
+__device__ __forceinline__ bool decode_striped_all(const vattn_attn_params& p) { return kLab && (p.variant & (1 << 24)) != 0; }
+__device__ __forceinline__ bool decode_striped(const vattn_attn_params& p) {
+    return decode_striped_all(p) || (p.b == 1 && !(kLab && (p.variant & (1 << 25)) != 0));
+}
 constexpr int DC_MAXB = 256;                         // sequences per launch the plan prologue handles (4 per lane of a wave)
 // A workgroup whose range crosses into another sequence pays a second prologue / epilogue (partial stores drained, Q fetched, the K/V
 // stream restarted): a few microseconds during which its neighbours on the CU keep streaming but IT falls behind — and a one-round
@@ -755,11 +768,18 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     // per workgroup the 100 MHz wall clock at entry, after the plan and at exit
     unsigned long long* const ts = (kLab && (p.variant & (1 << 22)) && p.softmax_lse) ? (unsigned long long*)p.softmax_lse + 4096 : nullptr;
     const unsigned wg_id = blockIdx.y * gridDim.x + blockIdx.x;
-    if (kLab && ts && tid == 0) ts[3 * wg_id] = wall_clock64();
+    if (kLab && ts && tid == 0) {
+        ts[3 * wg_id] = wall_clock64();
+        // where the dispatcher put this workgroup: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13]) and XCC_ID, behind the stamps
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        ts[3 * (unsigned)(gridDim.x * gridDim.y) + wg_id] = ((unsigned long long)xcc << 32) | hw;
+    }
     StreamPlan pl;
     stream_plan_load(p, X, pl);
     if (kLab && ts && tid == 0) ts[3 * wg_id + 1] = wall_clock64();
     const StreamGeom geo = stream_geom(pl.total, pl.maxt, p.b, nwg);
+    const bool striped = decode_striped_all(p) && geo.uniform && geo.S > 1;      // (lab; the product stripes the single-sequence launch only)
     auto publish_and_merge = [&](const int b, const int first_rec, const int cnt) {      // LAB: in-launch merge
         // publish: this workgroup's record stores have left the CU (write-through), then ONE device-scope ticket
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -803,14 +823,20 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
         if (b >= p.b) return;
         const int excl = b ? stream_plan_get(pl.incl, pl.sh, b - 1) : 0, incl = stream_plan_get(pl.incl, pl.sh, b);
         const int t = incl - excl - X, per = (t + geo.S - 1) / geo.S;
-        tb = sidx * per;
-        te = min(t, tb + per);
+        if (striped) {               // piece sidx = tiles sidx, sidx + S, ...: min(S, t) pieces hold tiles
+            tb = sidx;
+            te = t;
+            cnt = min(geo.S, t);
+        } else {
+            tb = sidx * per;
+            te = min(t, tb + per);
+            cnt = (t + per - 1) / per;
+        }
         if (te <= tb) return;
-        cnt = (t + per - 1) / per;
         first_rec = b * geo.S + b;
         slot = stream_plan_get(pl.slot, pl.sh, b);
         lk = stream_plan_get(pl.lk, pl.sh, b);
-        total = fair ? te - tb : 0;
+        total = (fair && !striped) ? te - tb : 0;
     } else {
         g0 = w * geo.T;
         if (g0 >= pl.total) return;
@@ -834,7 +860,7 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
         const unsigned blk = stream_table_bytes(p.b) + (((unsigned)(w + b) * p.h_k + hk) * gblocks + gb) * RB;
         if (tb == 0 && hk == 0 && gb == 0 && tid == 0) stream_publish_seq(p, b, first_rec, cnt);      // (the owner of the sequence's first piece)
         decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, 0, tb, te, cnt == 1 ? 1 : (kLab && counters) ? 3 : 2, slot, lk, blk,
-                                       done, total);
+                                       done, total, striped ? geo.S : 1);
         done += te - tb;
         if (kLab && cnt > 1 && counters != nullptr) publish_and_merge(b, first_rec, cnt);      // product: the records are merged by decode_stream_combine_kernel
         if (geo.uniform || !next_piece(b + 1)) {
@@ -892,7 +918,8 @@ __global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB >
         gb = blockIdx.y % gblocks;
         b = blockIdx.z;
     }
-    decode_body<T, HD, USE_TR, NB, W, PF>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0);
+    decode_body<T, HD, USE_TR, NB, W, PF>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0, -1, 0, 0, 0, 0, 0, 0, 0, 0,
+                                          (decode_striped(p) && num_splits > 1) ? num_splits : 1);
     if (kLab && W == DC_WAVES && done != nullptr && num_splits > 1)
         decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket, merge_mode);
 }
