@@ -28,8 +28,9 @@ def _check(out_gpu, ref64, ref32, dtype, what):
         "%s: kernel err %.3e vs reference-numerics err %.3e" % (what, err.max().item(), e_ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1 << 20, 1 << 19, 1, 65536, 131072, 262144],
-                         ids=["stream", "stream_in_launch_merge", "grid_heuristics", "plain_read", "wg512", "wg1024", "two_register_sets"])
+@pytest.mark.parametrize("variant", [0, 1 << 20, 1 << 19, 1, 65536, 131072, 262144, 1 << 24, 1 << 25],
+                         ids=["stream", "stream_in_launch_merge", "grid_heuristics", "plain_read", "wg512", "wg1024", "two_register_sets",
+                              "striped_everywhere", "single_sequence_contiguous"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("B,G,Hkv,lens", [
     (1, 8, 4, [777]),                    # Yi-6B group size
@@ -39,7 +40,8 @@ def _check(out_gpu, ref64, ref32, dtype, what):
 ])
 def test_decode_parity(B, G, Hkv, lens, dtype, variant):
     """variant 0 = the product path: the device-planned stream decomposition (merged by a second launch); bit 20 (lab): merged inside the
-    launch; bit 19: the grid heuristics of rounds 1-3; the rest are lab shapes.  num_splits < 0 forces that many workgroups per kv head on the
+    launch; bit 19: the grid heuristics of rounds 1-3; bit 24 (lab): STRIPED pieces in every uniform decomposition (the product stripes the
+    single-sequence split launch only), bit 25 (lab): contiguous pieces there too; the rest are lab shapes.  num_splits < 0 forces that many workgroups per kv head on the
     stream path (pieces that cross sequence boundaries, ranges that end inside a tile space smaller than the grid, ...)."""
     from vattention_amd.flash_attn import flash_attn_with_kvcache
     torch.manual_seed(1234)
@@ -57,7 +59,7 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
     kc2, vc2 = kc.clone(), vc.clone()
     ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :max_len], vc2[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     kg, vg = kc.to(DEV), vc.to(DEV)
-    stream = variant in (0, 1 << 20)
+    stream = variant in (0, 1 << 20, 1 << 24, 1 << 25)
     for splits in (0, 1, 3) + ((-1, -2, -5, -37, -300) if stream else ()):
         kgi, vgi = kg.clone(), vg.clone()
         for rep in range(2 if stream else 1):          # (the in-launch merge's tickets reset themselves: a second call must work too)
