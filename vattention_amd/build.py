@@ -72,7 +72,7 @@ def build_lib(force=False):
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-inline-asm"] + os.environ.get("VATTN_CXXFLAGS", "").split()
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-inline-asm"] + os.environ.get("VATTN_CXXFLAGS", "").split()
         objdir = os.path.join(ROOT, "build", "obj")
         os.makedirs(objdir, exist_ok=True)
         objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]
@@ -100,7 +100,7 @@ def build_lab(force=False):
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-unused-value", "-Wno-inline-asm"]
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-inline-asm"]
         objdir = os.path.join(ROOT, "build", "obj_lab")
         os.makedirs(objdir, exist_ok=True)
         objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]

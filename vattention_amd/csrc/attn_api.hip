@@ -309,20 +309,20 @@ int vattn_selftest_layouts(void* stream, int32_t* detail_out) {
     hipStream_t st = (hipStream_t)stream;
     int* d = nullptr;
     if (hipMalloc(&d, 8 * sizeof(int)) != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed");
-    hipMemsetAsync(d, 0, 8 * sizeof(int), st);
+    (void)hipMemsetAsync(d, 0, 8 * sizeof(int), st);      // (a failure of any of these surfaces in the synchronising copy below)
     unsigned* gsrc = nullptr;
     unsigned hsrc[512];
     for (int i = 0; i < 512; i++) hsrc[i] = (unsigned)i;
-    if (hipMalloc(&gsrc, sizeof(hsrc)) != hipSuccess) { hipFree(d); return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed"); }
-    hipMemcpyAsync(gsrc, hsrc, sizeof(hsrc), hipMemcpyHostToDevice, st);
+    if (hipMalloc(&gsrc, sizeof(hsrc)) != hipSuccess) { (void)hipFree(d); return fail(VATTN_K_ERR_LAUNCH, "hipMalloc failed"); }
+    (void)hipMemcpyAsync(gsrc, hsrc, sizeof(hsrc), hipMemcpyHostToDevice, st);
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d, (const unsigned*)gsrc);
     (void)hipFuncSetAttribute((const void*)selftest_dma_high_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
     hipLaunchKernelGGL(selftest_dma_high_kernel, dim3(1), dim3(64), 96 << 10, st, d, (const unsigned*)gsrc);
     int h[8] = {0};
     hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d);
-    hipFree(gsrc);
+    (void)hipFree(d);
+    (void)hipFree(gsrc);
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     int bad = 0;
     for (int i = 0; i < 8; i++) {
@@ -337,17 +337,18 @@ float vattn_time_attn(const vattn_attn_params* p, void* stream, int32_t warmup, 
     for (int i = 0; i < warmup; i++)
         if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, st);
-    for (int i = 0; i < iters; i++)
-        if (vattn_flash_attn_with_kvcache(p, stream) != 0) return -1.f;
-    hipEventRecord(e1, st);
-    hipEventSynchronize(e1);
+    if (hipEventCreate(&e0) != hipSuccess) return -1.f;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return -1.f; }
+    hipError_t e = hipEventRecord(e0, st);
+    for (int i = 0; i < iters && e == hipSuccess; i++)
+        if (vattn_flash_attn_with_kvcache(p, stream) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return -1.f;
     return ms / (iters > 0 ? iters : 1);
 }
 
