@@ -54,6 +54,39 @@ def check():
     return bad
 
 
+def weighted():
+    # LAB bit 26: one sequence, the kv head whose bytes sit in the slow address quarter gets 5 shares of the workgroups where the others get 4
+    from tools import kbench
+    Wv = (1 << 22) | (1 << 26)
+    torch.manual_seed(2)
+    bad = 0
+    for (ctx, Hq, Hkv) in [(4099, 28, 4), (131071, 28, 4), (20000, 14, 2), (65, 32, 4), (40000, 32, 8), (8191, 8, 1)]:
+        for dt in (torch.float16, torch.bfloat16):
+            q = torch.randn(1, 1, Hq, 128, device=DEV, dtype=dt)
+            kc = torch.randn(2, ctx + 1, Hkv, 128, device=DEV, dtype=dt)
+            vc = torch.randn(2, ctx + 1, Hkv, 128, device=DEV, dtype=dt)
+            kn = torch.randn(1, 1, Hkv, 128, device=DEV, dtype=dt)
+            vn = torch.randn(1, 1, Hkv, 128, device=DEV, dtype=dt)
+            cl = torch.full((1,), ctx, dtype=torch.int32, device=DEV)
+            idx = torch.ones(1, dtype=torch.int32, device=DEV)
+            oa, ka, va, da = run(1 << 22, q, kc, vc, cl, idx, kn, vn)
+            ob, kb, vb, db = run(Wv, q, kc, vc, cl, idx, kn, vn)
+            err = (oa - ob).abs().max().item()
+            ok = err <= (2e-3 if dt == torch.float16 else 1.6e-2) and torch.equal(ka, kb) and torch.equal(va, vb) and torch.isfinite(ob).all().item()
+            bad += not ok
+            print("  %s weighted heads: ctx=%6d Hq=%2d Hkv=%d %s: max |weighted - even| %.2e" % ("ok " if ok else "BAD", ctx, Hq, Hkv, "f16 " if dt == torch.float16 else "bf16", err))
+    print("weighted parity: %s" % ("all ok" if not bad else "%d BAD" % bad))
+    if bad:
+        return
+    kbench.ROTATE = True
+    kbench.SPLITS = [0]
+    kbench.ONLY = "yi34b/tp2 B1@128k,yi34b/tp4 B1@128k,yi6b B1@32k"
+    for rep in range(2):
+        for v, name in ((1 << 22, "even split (striped)"), (Wv, "WEIGHTED heads (striped)")):
+            print("== %s (lab library), pass %d" % (name, rep + 1))
+            kbench.decode(v)
+
+
 def timing():
     from tools import kbench
     kbench.ROTATE = True
@@ -67,6 +100,9 @@ def timing():
 
 if __name__ == "__main__":
     torch.zeros(1, device=DEV)
+    if "--weighted" in sys.argv:
+        weighted()
+        sys.exit(0)
     bad = check()
     if not bad:
         timing()

@@ -548,6 +548,24 @@ __device__ __forceinline__ bool decode_striped_all(const vattn_attn_params& p) {
 __device__ __forceinline__ bool decode_striped(const vattn_attn_params& p) {
     return decode_striped_all(p) || (p.b == 1 && !(kLab && (p.variant & (1 << 25)) != 0));
 }
+// LAB (variant bit 26, single-sequence split launch): split counts per kv head weighted by where the head's bytes live — the head whose
+// 256-byte block of every row has address bits [9:8] = 01 streams ~20 % slower at this occupancy (profiles/r04_decode_head_skew.txt) and
+// gets 5 shares where the others get 4.  `total` workgroups in a 1-D grid; returns this head's count and its first workgroup.
+__device__ __forceinline__ bool decode_head_is_slow(const vattn_attn_params& p, const int hk) {
+    if ((p.k_row_stride * 2) % 1024 != 0) return false;
+    return ((((unsigned long long)p.k_cache + (unsigned long long)hk * (unsigned long long)p.k_head_stride * 2ull) >> 8) & 3ull) == 1ull;
+}
+__device__ __forceinline__ int decode_weighted_splits(const vattn_attn_params& p, const int total, const int hk, int& first) {
+    int wsum = 0, wbefore = 0, wmine = 4;
+    for (int h = 0; h < p.h_k; h++) {
+        const int w = decode_head_is_slow(p, h) ? 5 : 4;
+        if (h < hk) wbefore += w;
+        if (h == hk) wmine = w;
+        wsum += w;
+    }
+    first = (int)((long long)total * wbefore / wsum);
+    return (int)((long long)total * (wbefore + wmine) / wsum) - first;
+}
 constexpr int DC_MAXB = 256;                         // sequences per launch the plan prologue handles (4 per lane of a wave)
 // A workgroup whose range crosses into another sequence pays a second prologue / epilogue (partial stores drained, Q fetched, the K/V
 // stream restarted): a few microseconds during which its neighbours on the CU keep streaming but IT falls behind — and a one-round
@@ -899,7 +917,20 @@ __global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB >
                                           (int)blockIdx.x, it.tile_begin, it.tile_end);
         return;
     }
-    if (gridDim.y == 1 && gridDim.z == 1 && gblocks > 1) {
+    int my_splits = num_splits;                        // pieces of THIS head's sequence (== num_splits except in the lab's weighted form)
+    if (kLab && merge_mode == 7) {
+        // LAB: heads get different numbers of workgroups (decode_weighted_splits); blockIdx.x = workgroup of the flattened (head, piece)
+        b = 0;
+        gb = 0;
+        hk = 0;
+        int first = 0;
+        for (int h = 0; h < p.h_k; h++) {
+            int f;
+            const int n = decode_weighted_splits(p, (int)gridDim.x, h, f);
+            if ((int)blockIdx.x >= f && (int)blockIdx.x < f + n) { hk = h; first = f; my_splits = n; }
+        }
+        split = (int)blockIdx.x - first;
+    } else if (gridDim.y == 1 && gridDim.z == 1 && gblocks > 1) {
         // G > 32 query heads per kv head (MQA models): the head-block groups of one (split, kv head, sequence) read the
         // SAME K/V rows.  1-D grid laid out so that those sibling workgroups get consecutive slots on ONE XCD (ids 8 apart):
         // the first reader pulls the rows from HBM, the others hit that XCD's L2
@@ -919,7 +950,7 @@ __global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB >
         b = blockIdx.z;
     }
     decode_body<T, HD, USE_TR, NB, W, PF>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0, -1, 0, 0, 0, 0, 0, 0, 0, 0,
-                                          (decode_striped(p) && num_splits > 1) ? num_splits : 1);
+                                          (decode_striped(p) && num_splits > 1) ? my_splits : 1);
     if (kLab && W == DC_WAVES && done != nullptr && num_splits > 1)
         decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket, merge_mode);
 }

@@ -25,7 +25,7 @@ namespace vattn_k {
 // partials with independent loads.  Serves the decode form (sq = 1) and the KV-split prefill form.
 // workspace: float o_part[splits][b][sq][h][HD]; float lse_part[splits][b][sq][h]  (log2 domain)
 template <typename T, int HD>
-__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits, int sq) {   // 128 threads: one per split weight, first HD also one per output column
+__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits, int sq, int wtotal) {   // 128 threads: one per split weight, first HD also one per output column
     __shared__ float wsm[128];
     __shared__ float red[4];
     const int64_t row = blockIdx.x;                  // (b * sq + q) * h + head
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int n
     const float* oacc = (const float*)p.workspace;
     const int64_t sstride = (int64_t)p.b * sq * p.h;
     const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
+    if (kLab && wtotal > 0) {      // LAB (weighted heads): num_splits is the layout's stride; this head merges its own piece count
+        int f;
+        num_splits = decode_weighted_splits(p, wtotal, hh / (p.h / p.h_k), f);
+    }
     const float my = (tid < num_splits) ? lacc[(int64_t)tid * sstride + row] : -INFINITY;    // num_splits <= 128
     // up to kEarly partials per thread are asked for BEFORE the weights exist: their loads fly together with the LSE loads instead of
     // behind the two reductions (the kernel is two dependent memory latencies long, nothing else)
@@ -269,6 +273,12 @@ template <typename T, int HD, int NB, int W = DC_WAVES, int PF = 1> int launch_d
     const int splits = planned ? 2 : pick_splits(p, groups, decode_slots(p));
     if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
     dim3 grid(splits, p->h_k * groups, p->b), block(64 * W);
+    // LAB (variant bit 26): one sequence, kv heads get workgroups in proportion to how slowly their bytes stream (decode_weighted_splits):
+    // a 1-D grid of the same total; the partials' layout takes the largest head's count (5/4 of the even share, rounded up)
+    const bool weighted = kLab && (p->variant & (1 << 26)) && !(p->variant & (1 << 25)) && use_tr && p->b == 1 && groups == 1 && !planned && splits > 1 && W == DC_WAVES && PF == 1 && p->h_k > 1;
+    const int wtotal = weighted ? splits * p->h_k : 0;
+    const int layout_splits = weighted ? (splits * 5) / 4 + 2 : splits;
+    if (weighted) grid = dim3((unsigned)wtotal, 1, 1);
     if (planned) grid = dim3((unsigned)p->num_split_items, p->h_k * groups, 1);
     if (groups > 1 && !(p->variant & 64) && !planned) {            // sibling groups share an XCD (variant bit 6: plain 3-D grid, for A/B)
         const long w = (long)splits * p->h_k * p->b;
@@ -287,7 +297,7 @@ template <typename T, int HD, int NB, int W = DC_WAVES, int PF = 1> int launch_d
     const vattn_attn_params& q = *p;
     int* done = (W == DC_WAVES && PF == 1 && !planned && decode_inline_merge(p, splits, groups)) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
     const bool inline_merge = done != nullptr;
-    const int mm = !inline_merge ? 0 : (p->variant & 1024) ? 2 : 1;
+    const int mm = weighted ? 7 : !inline_merge ? 0 : (p->variant & 1024) ? 2 : 1;
     if constexpr (W != DC_WAVES || PF != 1) {
         hipLaunchKernelGGL((decode_kernel<T, HD, true, NB, W, PF>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
     } else {
@@ -298,10 +308,10 @@ template <typename T, int HD, int NB, int W = DC_WAVES, int PF = 1> int launch_d
                 plain = true;
             }
         }
-        if (!plain) hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
+        if (!plain) hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, layout_splits, groups, fused_append, done, mm);
     }
     if (planned) hipLaunchKernelGGL((combine_items_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q);
-    else if (splits > 1 && !inline_merge) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, splits, 1);
+    else if (splits > 1 && !inline_merge) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, layout_splits, 1, wtotal);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;
@@ -432,7 +442,8 @@ size_t decode_workspace_bytes(const vattn_attn_params* p) {
     const int groups = decode_groups(p);
     const int splits = pick_splits(p, groups, decode_slots(p));
     if (splits <= 1) return 0;
-    return (size_t)splits * p->b * p->h * (p->d + 1) * sizeof(float);
+    const int layout_splits = (kLab && (p->variant & (1 << 26)) && p->b == 1) ? (splits * 5) / 4 + 2 : splits;      // (lab: weighted heads; a little more than needed when the form is not taken)
+    return (size_t)layout_splits * p->b * p->h * (p->d + 1) * sizeof(float);
 }
 
 }  // namespace vattn_k
