@@ -87,6 +87,22 @@ int main(void) {
                /* (a block's last share is open-ended: causal whole prompt, query block qb sees 4 (qb + 1) tiles of 64 keys) */
                (pitems[0].tile_end < 4 * (pitems[0].qb + 1) ? pitems[0].tile_end : 4 * (pitems[0].qb + 1)) - pitems[0].tile_begin,
                (pitems[n > 0 ? n - 1 : 0].tile_end < 4 * (pitems[n > 0 ? n - 1 : 0].qb + 1) ? pitems[n > 0 ? n - 1 : 0].tile_end : 4 * (pitems[n > 0 ? n - 1 : 0].qb + 1)) - pitems[n > 0 ? n - 1 : 0].tile_begin);
+        {   /* what WILL be launched, asked on the host (no GPU): configs[1]'s whole prompt and its batch-16 decode step */
+            vattn_attn_params d;
+            vattn_plan_desc desc;
+            memset(&d, 0, sizeof d);
+            d.struct_size = (uint32_t)sizeof d; d.abi_version = VATTN_KERNELS_ABI;
+            d.b = 1; d.seqlen_q = 32702; d.seqlen_k = 32768; d.h = 32; d.h_k = 4; d.d = 128; d.is_causal = 1; d.dtype = VATTN_DTYPE_F16;
+            rc = vattn_attn_plan_describe(&d, &desc);
+            printf("describe_prefill %d form %d path %d tiling %d nsplit %d workgroups %d merge %d\n", rc, desc.form, desc.path, desc.tiling, desc.nsplit,
+                   desc.workgroups, desc.merge_launch);
+            d.b = 16; d.seqlen_q = 1; d.seqlen_knew = 1;
+            rc = vattn_attn_plan_describe(&d, &desc);
+            printf("describe_decode %d form %d path %d tiling %d workgroups %d merge %d workspace %lld\n", rc, desc.form, desc.path, desc.tiling,
+                   desc.workgroups, desc.merge_launch, (long long)desc.workspace_bytes);
+            d.abi_version = VATTN_KERNELS_ABI - 1;     /* a block built against another header is refused, not read */
+            printf("describe_other_abi %d\n", vattn_attn_plan_describe(&d, &desc));
+        }
         p.q = p.out = p.k_cache = p.v_cache = &p;      /* (never dereferenced: validation stops at the variant) */
         p.seqlen_k = 8192; p.dtype = VATTN_DTYPE_F16;
         p.q_row_stride = p.q_head_stride = p.q_batch_stride = p.k_row_stride = p.k_head_stride = p.k_batch_stride = 8;

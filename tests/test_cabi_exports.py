@@ -109,6 +109,11 @@ def test_plain_c_client_drives_the_boundary(tmp_path):
     m = re.search(r"prefill_plan items (\d+) split_blocks (\d+) partial_rows (\d+) first_piece_tiles (\d+) last_piece_tiles (\d+)", text)
     assert m and int(m.group(1)) > 256 and int(m.group(2)) > 0 and int(m.group(3)) % 256 == 0 and int(m.group(4)) >= int(m.group(5)), text
     assert "lab_variant -11" in text and "measurement build" in text
+    # vattn_attn_plan_describe from plain C: configs[1]'s prompt = prefill64 over a 4096-workgroup grid, its batch-16 decode step = the
+    # device-planned stream decomposition on 768 workgroups + a merge launch; another header's block is refused
+    assert "describe_prefill 0 form 0 path 0 tiling 7 nsplit 1 workgroups 4096 merge 0" in text
+    assert "describe_decode 0 form 1 path 2 tiling 1 workgroups 768 merge 1 workspace 6922368" in text
+    assert "describe_other_abi -11" in text
 
 
 def test_split_plans_from_the_workspace_query():
