@@ -155,6 +155,14 @@ int vattn_free_batch_idx_on_stream(vattn_t* m, int slot, void* stream);
  * path); alloc_new_batch_idx skips reserved slots; vattn_free_batch_idx / vattn_cancel_premap release the reservation. */
 int vattn_premap(vattn_t* m, uint64_t seqlen);
 int vattn_cancel_premap(vattn_t* m, int slot);
+/* Lazy pool (the default: handles are created on first map or by the idle mapper thread): block until the mapper has created the
+ * handles it creates ahead of demand — the WHOLE pool when it has at most 40 000 pages, a window of 4 096 below the pool's frontier
+ * otherwise — or `timeout_ms` have passed (< 0: no limit).  Returns the number of handles still to be created ahead of demand (0 =
+ * ready; always 0 with VATTN_FLAG_EAGER_CREATE / VATTN_FLAG_NO_MAPPER_THREAD).  The reference commits every page inside
+ * reserve_physical_pages (/root/reference/vattention/cudaInternal.h:45-59); an engine calls this once after reserve, before it admits
+ * requests, so that no launch of the first iterations shares the driver with a burst of hipMemCreate calls (round 5:
+ * profiles/r05_cold_pool.md — the kernels are not slowed by concurrent creation, the LAUNCHES are late).  Thread-safe. */
+int64_t vattn_wait_pool_ready(vattn_t* m, int64_t timeout_ms);
 /* VATTN_FLAG_LAYERED_ASYNC: block until the pages the current step needs are mapped for `layer` (returns at once when no
  * layered batch is pending); VATTN_ERR_* if the mapper failed (vattn_last_error is NOT updated by this call — it may run
  * concurrently with the engine thread's calls; the next vattn_step* / vattn_wait reports the driver's message).  A caller that

@@ -147,6 +147,26 @@ def test_lazy_pool_and_driver_failure_surface():
     p.pm.close()
 
 
+def test_wait_pool_ready_returns_once_the_mapper_has_created_the_pool():
+    """vattn_wait_pool_ready (round 5): a small pool (<= 40 000 pages) is created WHOLE by the idle mapper thread; the call returns 0
+    once every handle exists (what the reference's reserve_physical_pages guarantees, cudaInternal.h:45-59) — and at once, with 0,
+    where nothing is created ahead of demand (inline mode)."""
+    cfg = dict(num_layers=2, num_kv_heads=8, head_size=128, max_batch_size=4, max_context_length=8192,
+               itemsize=2, page_size=2 << 20, megacache=False)
+    p = ProductImpl(cfg, flags=0)                              # mapper thread
+    assert p.reserve_physical_pages(256 << 20) == 128
+    assert p.pm.wait_pool_ready(-1) == 0
+    assert fake_counters()["n_create"] == 128                  # the whole pool, none on demand later
+    s = p.alloc_new_batch_idx(4000)
+    p.step([4000 if i == s else 0 for i in range(4)], False)
+    assert fake_counters()["n_create"] == 128
+    p.pm.close()
+    q = ProductImpl(cfg, flags=4)                              # inline: lazy, no mapper
+    assert q.reserve_physical_pages(256 << 20) == 128
+    assert q.pm.wait_pool_ready(0) == 0 and fake_counters()["n_create"] == 0
+    q.pm.close()
+
+
 @pytest.mark.parametrize("flags", [0, 4], ids=["mapper_thread", "inline"])
 def test_lifecycle_cleanup_twice_use_after_cleanup_destroy_with_pending_work(flags):
     """Teardown paths of the C ABI: cleanup is idempotent, mutating calls after cleanup are explicit errors (the reference

@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
         "vattn_free_batch_idx": (i32, [vp, i32]),
         "vattn_free_batch_idx_on_stream": (i32, [vp, i32, vp]),
         "vattn_premap": (i32, [vp, u64]),
+        "vattn_wait_pool_ready": (i64, [vp, i64]),
         "vattn_cancel_premap": (i32, [vp, i32]),
         "vattn_wait_layer": (i32, [vp, u32]),
         "vattn_layers_ready": (u32, [vp]),

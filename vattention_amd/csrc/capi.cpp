@@ -68,6 +68,7 @@ int vattn_free_batch_idx(vattn_t* m, int slot) { return m->pm->free_batch_idx(sl
 int vattn_free_batch_idx_on_stream(vattn_t* m, int slot, void* stream) { return m->pm->free_batch_idx(slot, stream, true); }
 int vattn_premap(vattn_t* m, uint64_t seqlen) { return m->pm->premap(seqlen); }
 int vattn_cancel_premap(vattn_t* m, int slot) { return m->pm->cancel_premap(slot); }
+int64_t vattn_wait_pool_ready(vattn_t* m, int64_t timeout_ms) { return m->pm->wait_pool_ready(timeout_ms); }
 int vattn_wait_layer(vattn_t* m, uint32_t layer) { return m->pm->wait_layer(layer); }
 uint32_t vattn_layers_ready(vattn_t* m) { return m->pm->layers_ready(); }
 int vattn_set_sync_layers(vattn_t* m, uint32_t n) { return m->pm->set_sync_layers(n); }

@@ -526,6 +526,18 @@ int PageManager::cancel_premap(int slot) {
     return VATTN_OK;
 }
 
+// include/vattn.h vattn_wait_pool_ready.  Reads atomics only (no manager lock: the engine thread may sit here while nothing else runs,
+// and a test may call it beside step_async); the mapper's idle loop is what makes progress.
+int64_t PageManager::wait_pool_ready(int64_t timeout_ms) {
+    const uint64_t t0 = now_ns();
+    for (;;) {
+        const uint64_t left = precreate_left_.load(), floor = precreate_floor();
+        if (left <= floor || fatal_.load()) return 0;      // (a failed creation zeroes precreate_left_)
+        if (timeout_ms >= 0 && now_ns() - t0 >= (uint64_t)timeout_ms * 1000000ull) return (int64_t)(left - floor);
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
 int PageManager::free_batch_idx(int slot, void* stream, bool with_fence) {   // vattention.cu:591-594
     std::lock_guard<std::mutex> l(state_mu_);
     if (slot < 0 || slot >= (int)cfg_.max_batch_size) return fail(VATTN_ERR_INVALID, "slot out of range");
@@ -1001,10 +1013,10 @@ void PageManager::mapper_main() {
             const bool layered = queue_layered_.front() != 0;
             queue_.pop_front();
             queue_layered_.pop_front();
+            const bool after_failure = have_failed_;      // read under q_mu_ (the joiner resets it under q_mu_ once inflight_ == 0)
             q.unlock();
             int rc;
             size_t failed_at = ops.size();
-            const bool after_failure = have_failed_;      // (q_mu_ was held when this was read; only this thread sets it)
             {
                 std::lock_guard<std::mutex> e(exec_mu_);
                 rc = execute(ops, true, &failed_at, layered, after_failure);

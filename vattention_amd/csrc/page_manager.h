@@ -51,6 +51,7 @@ public:
     int free_batch_idx(int slot, void* stream = nullptr, bool with_fence = false);
     int premap(uint64_t seqlen);
     int cancel_premap(int slot);
+    int64_t wait_pool_ready(int64_t timeout_ms);      // include/vattn.h vattn_wait_pool_ready
     int wait_layer(uint32_t layer);
     uint32_t layers_ready();
     int set_sync_layers(uint32_t n);

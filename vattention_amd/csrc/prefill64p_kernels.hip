@@ -1,0 +1,588 @@
+// Persistent form of prefill64_kernel for WORK-LIST launches (vattn_prefill_plan_wg): one workgroup per CU walks a host-assigned QUEUE
+// of (entry, head, 256-row query block, key-tile range) pieces, and the tile stream does not stop between them (round 5; DESIGN §5,
+// VERDICT r04 next-round item 1; the operator: /root/reference/pod_attn/pod_attn/flash_fwd_kernel.h:57-499, its launch rule
+// flash_fwd_launch_template.h:60-61,239-263 — one CTA per query block, which is what prefill64_kernel also does).
+//
+// What a piece costs in prefill64_kernel besides its key tiles: the workgroup's dispatch, two levels of dependent scalar loads (the
+// piece, then the lengths it points to), a cold prologue — Q from HBM, the first K / V tiles' round trips, the first S' with the matrix
+// pipe otherwise idle — and the drain of the DMA ring; the planner prices it at 3 tile times (csrc/prefill_kernels.hip), which is
+// 3 % of the dynamic legs' average piece (99 tiles) and 10-25 % of the cut pieces of a tensor-parallel shard (12-30 tiles).  Here:
+//   * the DMA stream is CONTINUOUS across pieces: the K(t+3) / V(t+2) fetches issued in the last three steps of a piece are the next
+//     piece's first tiles (the running descriptors are re-based instead of advanced: K in step nt-3, V in step nt-2);
+//   * the next piece's Q block travels HBM -> LDS by LDS-DMA while the current piece computes (a per-wave 16 KiB staging area behind the
+//     V ring) and is moved into the accumulator registers between the last two steps; the LAST step of a piece then computes
+//     S'(first tile of the next piece) in its phase A, exactly as every other step computes S'(t+1);
+//   * between two pieces only the epilogue of the finished one is left: normalise and store O (or the fp32 partial), zero the
+//     accumulators, take the new piece's first row maxima as its reference.
+// A piece shorter than 3 tiles does not chain OUT (its re-base points would lie in its predecessor's steps); the piece after it starts
+// cold — the same prologue as prefill64_kernel's.  Fused RoPE is not taken here (the launch keeps prefill64_kernel for it).
+// The tile step itself — the 64 hand-placed groups { MFMA ; fragment read ahead ; softmax slice } — is prefill64_kernel's product
+// instantiation (padded K image, NA = 24, fragment ring of 4, barrier at group 8, DMA in groups 9, 12, .. 30), restated here with
+// the four hooks the stream needs: descriptor re-base, mask parameters of the tile being scored, exported row maxima, no max-growth
+// test across a piece boundary.
+#include "prefill64_common.h"
+
+namespace vattn_k {
+
+constexpr int kQStage = 87040;                 // LDS offset of the Q staging area: 4 waves x 16 KiB (K ring 36 864 + V ring 49 152 + 16, rounded up to 1 KiB)
+constexpr int kSmem64p = kQStage + 65536;      // 152 576 bytes: one workgroup per CU (160 KiB of LDS)
+
+// one 1-KiB piece of the next Q block: lane i's 16 bytes (row l31, d = 16 kk + 8 g ..) land at M0 + 16 i — the layout the fragment
+// registers want, so the read-back is lane-linear; OFF = 32 kk bytes rides in the instruction
+template <int OFF> __device__ __forceinline__ void dma_q_piece(unsigned lds_addr, u32x4 rsrc, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen offset:%3 lds" : : "s"(lds_addr), "s"(rsrc), "v"(voff), "i"(OFF) : "memory", "m0");
+}
+
+template <typename T, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3>
+__global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p) {
+    using X = Tr<T>;
+    using V8 = typename X::v8;
+    constexpr int HD = 128;
+    using S = PfSmem<HD>;
+    constexpr int BM = 256;
+    constexpr int KK = HD / 16;
+    constexpr int DB = HD / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring, V ring (prefill64_kernel's map), 16 spare bytes, Q staging; LDS address 0
+    constexpr int KPIECE = 1088;
+    constexpr int KSLOT = 16 * 1088;
+    constexpr int VBASE = 36864;
+    static_assert(D0 >= BJ && D0 + 7 * DS < 32, "DMA pieces behind the barrier, inside phase B");
+    static_assert(NA >= 16 && NA < 32, "key slice 0 of P is packed in phase-A groups 13 / 15");
+    static_assert(MS >= 4 && MS + 19 < 32, "row-max chain inside phase B");
+    auto dma_gap = [](int k) { return D0 + DS * k; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+    const bool causal = p.is_causal != 0;
+    const int G = p.h / p.h_k;
+    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
+    const unsigned q_rs_bytes = (unsigned)p.q_row_stride * 2u;
+
+    // ---- this workgroup's queue: pieces [q_idx, q_end) of the list, in order ----
+    int q_idx = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x]);
+    const int q_end = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x + 1]);
+    if (q_idx >= q_end) return;
+
+    // one piece, resolved against the DEVICE-side lengths (the list is a hint: include/vattn_kernels.h)
+    struct Piece {
+        int b, h, q_wg0, Sq, Lk, off, tb, nt, it_row;
+        long long q_first;
+        unsigned long long kbase, vbase;      // byte addresses of (slot, kv head) row 0
+    };
+    auto load_piece = [&](int idx, Piece& c) {
+        const vattn_prefill_item it = p.pf_items[idx];
+        c.b = __builtin_amdgcn_readfirstlane(it.b);
+        c.h = __builtin_amdgcn_readfirstlane(it.h);
+        const int qb = __builtin_amdgcn_readfirstlane(it.qb);
+        const int it_tb = __builtin_amdgcn_readfirstlane(it.tile_begin), it_te = __builtin_amdgcn_readfirstlane(it.tile_end);
+        c.it_row = __builtin_amdgcn_readfirstlane(it.nshares > 1 ? it.part_row : -1);
+        const int hk = c.h / G;
+        const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[c.b] : c.b);
+        int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[c.b] : p.seqlen_k) + p.seqlen_knew);
+        Lk = Lk > p.seqlen_k ? p.seqlen_k : Lk;
+        c.Lk = Lk;
+        c.Sq = p.q_lens ? __builtin_amdgcn_readfirstlane(p.q_lens[c.b]) : p.seqlen_q;
+        c.q_first = p.q_start ? (long long)__builtin_amdgcn_readfirstlane(p.q_start[c.b]) : 0;
+        c.off = Lk - c.Sq;
+        c.q_wg0 = qb * BM;
+        int n_end = Lk;
+        if (causal) n_end = min(Lk, c.q_wg0 + BM + c.off);
+        if (n_end < 0) n_end = 0;
+        int nt_all = (n_end + PF_BN - 1) / PF_BN;
+        if (c.q_wg0 >= c.Sq) nt_all = 0;                       // a block beyond its entry's rows: nothing to score, nothing to store
+        c.tb = min(nt_all, it_tb);
+        c.nt = min(nt_all, it_te);
+        c.kbase = (unsigned long long)((const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride);
+        c.vbase = (unsigned long long)((const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride);
+    };
+    // first tile of a wave's rows that needs masking (ragged end of the sequence / causal diagonal), prefill64_kernel's rule
+    auto t_mask_of = [&](const Piece& c) -> int { return min(c.Lk >> 6, causal ? ((c.q_wg0 + wave * 64 + c.off - 63) >> 6) + 1 : 0x7fffffff); };
+
+    // ---- DMA addressing (tile-invariant per-lane offsets; prefill64_kernel's padded K image and V sub-tiles) ----
+    unsigned koff[4], voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = 4 * (4 * wave + j) + (lane & 3);
+        koff[j] = (unsigned)row * k_rs_bytes + (unsigned)((lane >> 2) << 4);
+        const int key = 16 * j + (lane >> 2);
+        voff[j] = (unsigned)key * v_rs_bytes + (unsigned)((4 * wave + (lane & 3)) << 4);
+    }
+    using M = Mfma<T>;
+    const unsigned k_lds_wave = (unsigned)(wave * 4 * KPIECE);
+    const unsigned v_lds_wave = (unsigned)(VBASE + wave * 4096);
+    const unsigned q_lds_wave = (unsigned)(kQStage + wave * 16384);
+    const unsigned qvoff = (unsigned)l31 * q_rs_bytes + (unsigned)(g << 4);      // row l31 of a 32-row block, d = 8 g .. (+ 32 kk bytes in the instruction)
+    auto tile_desc = [&](unsigned long long base, int t, int Lk_, unsigned rs_bytes) -> u32x4 {
+        int rem = Lk_ - t * PF_BN;
+        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
+        const unsigned long long a = base + (unsigned long long)t * PF_BN * rs_bytes;
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+        r[2] = __builtin_amdgcn_readfirstlane((unsigned)rem * rs_bytes);
+        r[3] = 0x00020000u;
+        return r;
+    };
+    // cold start only: K(t) -> K slot `ks`, V(t) -> V slot `vs`
+    auto dma_k_all = [&](const Piece& c, int t, int ks) {
+        const u32x4 r = tile_desc(c.kbase, t, c.Lk, k_rs_bytes);
+        const unsigned l0 = k_lds_wave + (unsigned)(ks * KSLOT);
+        dma_piece_first(l0, r, koff[0]);
+        dma_piece(l0 + KPIECE, r, koff[1]);
+        dma_piece(l0 + 2 * KPIECE, r, koff[2]);
+        dma_piece(l0 + 3 * KPIECE, r, koff[3]);
+    };
+    auto dma_v_all = [&](const Piece& c, int t, int vs) {
+        const u32x4 r = tile_desc(c.vbase, t, c.Lk, v_rs_bytes);
+        const unsigned l0 = v_lds_wave + (unsigned)(vs * S::kTileBytes);
+        dma_piece_first(l0, r, voff[0]);
+        dma_piece(l0 + 1024, r, voff[1]);
+        dma_piece(l0 + 2048, r, voff[2]);
+        dma_piece(l0 + 3072, r, voff[3]);
+    };
+    // this wave's 64 rows of piece c's Q block -> its staging area (16 pieces of 1 KiB); rows at or beyond Sq fetch nothing
+    auto dma_q_stage = [&](const Piece& c) {
+        const int qw0 = c.q_wg0 + wave * 64;
+        const unsigned long long a = (unsigned long long)((const T*)p.q + (p.q_start ? 0 : (int64_t)c.b * p.q_batch_stride) + (c.q_first + qw0) * p.q_row_stride +
+                                                          (int64_t)c.h * p.q_head_stride);
+        int rows = c.Sq - qw0;
+        rows = rows < 0 ? 0 : (rows > 64 ? 64 : rows);
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+        r[2] = __builtin_amdgcn_readfirstlane(rows > 0 ? (unsigned)(rows - 1) * q_rs_bytes + 256u : 0u);
+        r[3] = 0x00020000u;
+        asm volatile("s_nop 4" ::: "memory");                  // descriptor SGPRs written by readfirstlane -> VMEM
+        const unsigned v1 = qvoff + 32u * q_rs_bytes;
+#define VATTN_QP(KKI) dma_q_piece<32 * (KKI)>(q_lds_wave + 1024u * (KKI), r, qvoff); dma_q_piece<32 * (KKI)>(q_lds_wave + 8192u + 1024u * (KKI), r, v1);
+        VATTN_QP(0) VATTN_QP(1) VATTN_QP(2) VATTN_QP(3) VATTN_QP(4) VATTN_QP(5) VATTN_QP(6) VATTN_QP(7)
+#undef VATTN_QP
+    };
+
+    const float escale = p.softmax_scale * kLog2e;
+    V8 qf[2][KK];
+    // staging -> the Q^T fragment registers (accumulator half)
+    auto q_from_stage = [&]() {
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++)
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                qf[qc][kk] = *(const V8*)(smem + kQStage + wave * 16384 + (qc * 8 + kk) * 1024 + lane * 16);
+                asm volatile("" : "+a"(qf[qc][kk]));
+            }
+    };
+    // cold start: Q straight from global memory (prefill64_kernel's prologue)
+    auto q_from_global = [&](const Piece& c) {
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) {
+            const int my_q = c.q_wg0 + wave * 64 + 32 * qc + l31;
+            const T* qptr = (const T*)p.q + (p.q_start ? 0 : (int64_t)c.b * p.q_batch_stride) + (c.q_first + my_q) * p.q_row_stride + (int64_t)c.h * p.q_head_stride;
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (my_q < c.Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+                qf[qc][kk] = as_v8<V8>(v);
+                asm volatile("" : "+a"(qf[qc][kk]));
+            }
+        }
+    };
+
+    f32x16 o[DB][2];
+    float nmsub[2];
+    float l_acc[2][2];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < DB; i++)
+#pragma unroll
+            for (int qc = 0; qc < 2; qc++) o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++)
+#pragma unroll
+            for (int a4 = 0; a4 < 2; a4++) l_acc[qc][a4] = 0.f;
+    };
+
+    // LDS fragment addressing (prefill64_kernel's)
+    const unsigned kfrag_lane = (unsigned)((l31 >> 2) * KPIECE + (l31 & 3) * 16 + g * 64);
+    auto kfrag = [&](const char* ksm, int f) -> V8 {
+        const int kk = f >> 1, kb = f & 1;
+        return *(const V8*)(ksm + kb * 8 * KPIECE + kk * 128 + kfrag_lane);
+    };
+    const int i16 = lane & 15, dh = (lane >> 4) & 1;
+    const unsigned vfrag_lane = (unsigned)((4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2);
+    auto vfrag = [&](const char* vsm, int f) -> V8 {
+        const int ks = f >> 2, db = f & 3;
+        const char* a1 = vsm + db * S::kVSubBytes + (16 * ks) * 64 + vfrag_lane;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
+        return join_tr<V8>(lo, hi);
+    };
+    // masks tile tt of the piece whose (visible keys, first row of this wave + bottom-right offset) are (Lk_, qoff_)
+    auto mask_tile = [&](int tt, f32x16 (&s)[2][2], int Lk_, int qoff_) {
+        const int n0 = tt * PF_BN;
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) {
+            const int lim = causal ? min(Lk_ - 1, qoff_ + 32 * qc + l31) : Lk_ - 1;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = n0 + 32 * kb + 8 * (r >> 2) + 4 * g + (r & 3);
+                    if (key > lim) s[kb][qc][r] = -INFINITY;
+                }
+        }
+    };
+    auto row_max = [&](const f32x16 (&s)[2][2], int qc) -> float {
+        float m0 = fmaxf(s[0][qc][0], s[1][qc][0]);
+#pragma unroll
+        for (int r = 1; r < 16; r++) m0 = fmaxf(fmaxf(m0, s[0][qc][r]), s[1][qc][r]);
+        return fmaxf(m0, swap_halves(m0));
+    };
+    auto raise_max = [&](int qc, float delta) {
+        const float alpha = fast_exp2(-delta);
+        nmsub[qc] -= delta;
+#pragma unroll
+        for (int i = 0; i < DB; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha;
+#pragma unroll
+        for (int a4 = 0; a4 < 2; a4++) l_acc[qc][a4] *= alpha;
+    };
+    auto pack_p = [&](const f32x16 (&pt)[2][2], int ks, int qc) -> V8 {
+        V8 r;
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = X::cvt(pt[ks >> 1][qc][8 * (ks & 1) + j]);
+        return r;
+    };
+
+    f32x16 sc[2][2];
+    f32x16 sd[2][2];
+
+    auto GE = [](int e) { return e < NA ? 1 + (e * 30) / NA : 33 + ((e - NA) * 17) / (32 - NA); };
+#define P64_X0(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3)]
+#define P64_X1(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3) + 1]
+    auto softmax_stages = [&](int Gp, f32x16 (&cur)[2][2]) {
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+            const int qc = (e >> 2) & 1;
+            if (GE(e) - 1 == Gp)
+                asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale), "v"(nmsub[qc]));
+            if (GE(e) == Gp) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
+            if (GE(e) + 1 == Gp)
+                asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][0]), "+v"(l_acc[qc][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
+        }
+    };
+
+    // ---- the DMA stream's scalars (prefill64_kernel's; the descriptors live in s[92:95] / s[96:99]) ----
+    const unsigned k_tile_b = (unsigned)PF_BN * k_rs_bytes, v_tile_b = (unsigned)PF_BN * v_rs_bytes;
+    int k_rows_left = 0, v_rows_left = 0;
+    auto bound = [](int rows, unsigned rs) -> unsigned {
+        int r;
+        asm("s_min_i32 %0, %1, 64\n\ts_max_i32 %0, %0, 0" : "=s"(r) : "s"(rows) : "scc");
+        return (unsigned)r * rs;
+    };
+    u32x4 rk = {0u, 0u, 0u, 0x00020000u};
+    u32x4 rv = {0u, 0u, 0u, 0x00020000u};
+    // points the running descriptors at tile t of a piece (cold start: K(tb+2) / V(tb+1); re-base: the next piece's K(tb) / V(tb))
+    auto k_rebase = [&](unsigned long long base, int t, int Lk_) {
+        const unsigned long long a = base + (unsigned long long)t * k_tile_b;
+        k_rows_left = Lk_ - t * PF_BN;
+        const unsigned bnd = bound(k_rows_left, k_rs_bytes);
+        asm volatile("s_mov_b32 s92, %1\n\ts_and_b32 s93, %2, 0xffff\n\ts_mov_b32 s94, %3\n\ts_mov_b32 s95, 0x00020000"
+                     : "={s[92:95]}"(rk) : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(bnd) : "scc");
+    };
+    auto v_rebase = [&](unsigned long long base, int t, int Lk_) {
+        const unsigned long long a = base + (unsigned long long)t * v_tile_b;
+        v_rows_left = Lk_ - t * PF_BN;
+        const unsigned bnd = bound(v_rows_left, v_rs_bytes);
+        asm volatile("s_mov_b32 s96, %1\n\ts_and_b32 s97, %2, 0xffff\n\ts_mov_b32 s98, %3\n\ts_mov_b32 s99, 0x00020000"
+                     : "={s[96:99]}"(rv) : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(bnd) : "scc");
+    };
+    unsigned vs_cur = 0, vs_dma = 2 * S::kTileBytes;
+
+    // what a step does besides prefill64_kernel's: `rk_to` / `rv_to` != null: instead of moving the K / V descriptor one tile on, point it
+    // at the NEXT piece's first tile (wave-uniform); (Lk_n, qoff_n, mask_next, tn): mask parameters of the tile being scored, S'(tn);
+    // `seam`: that tile opens the next piece — no max-growth test against the finished piece's reference; mx0 / mx1 out: its row maxima
+    // (after masking), log2-domain growth aside.
+    auto step = [&](const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2, const Piece* rk_to, const Piece* rv_to, const bool mask_next,
+                    const int tn, const int Lk_n, const int qoff_n, const bool seam, float& mx0_out, float& mx1_out) {
+        const int s_cur = par;
+        const char* ksm = smem + (s_cur ^ 1) * KSLOT;
+        const char* ksm_next = smem + s_cur * KSLOT;
+        const char* vsm = smem + VBASE + vs_cur;
+        const unsigned lk0 = k_lds_wave + (unsigned)((s_cur ^ 1) * KSLOT);
+        unsigned lv0 = 0;
+        V8 pf[2][2];
+        V8 kf[RING];
+        SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int f = i >> 1, qc = i & 1;
+            if (f < RING - 1) {
+                const V8 a = f == 0 ? kf0 : (f == 1 ? kf1 : kf2);
+                if (i < 4) M::qk_first_a(nxt[f & 1][qc], a, qf[qc][f >> 1]);
+                else M::qk_acc_a(nxt[f & 1][qc], a, qf[qc][f >> 1]);
+            } else if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
+            else M::qk_acc(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
+            if ((i & 1) == 0 && f + RING - 1 < 2 * KK) kf[(f + RING - 1) % RING] = kfrag(ksm, f + RING - 1);
+            softmax_stages(i, cur);
+            if (i == 13) pf[0][0] = pack_p(cur, 0, 0);
+            if (i == 15) pf[0][1] = pack_p(cur, 0, 1);
+            if (i == 17) lv0 = v_lds_wave + vs_dma;
+            if (i == 19) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
+                                      : "+s"(vs_cur), "=&s"(vs_dma) : "i"(S::kTileBytes), "i"(3 * S::kTileBytes) : "scc");
+            if (i == 21) {
+                if (rk_to) k_rebase(rk_to->kbase, rk_to->tb, rk_to->Lk);
+                else k_rsrc_advance(rk, k_rows_left, k_tile_b, k_rs_bytes);
+            }
+            if (i == 23) {
+                if (rv_to) v_rebase(rv_to->vbase, rv_to->tb, rv_to->Lk);
+                else v_rsrc_advance(rv, v_rows_left, v_tile_b, v_rs_bytes);
+            }
+            SCHED_FENCE();
+        }
+        V8 vf[RING];
+        vf[0] = vfrag(vsm, 0);
+        vf[1] = vfrag(vsm, 1);
+        if (RING > 3) vf[2] = vfrag(vsm, 2);
+        float mx0 = -INFINITY, mx1 = -INFINITY, g0 = -INFINITY, g1 = -INFINITY, grow = -INFINITY;
+        SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const int f = j >> 1, ks = j >> 3, qc = j & 1;
+            if (j == BJ) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            M::pv(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
+            if ((j & 1) == 0 && f + RING - 1 < 16) vf[(f + RING - 1) % RING] = vfrag(vsm, f + RING - 1);
+            softmax_stages(32 + j, cur);
+            if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
+            if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
+            if (j >= MS && j < MS + 16) {
+                const int r = j - MS;
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx0) : "v"(nxt[0][0][r]), "v"(nxt[1][0][r]));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx1) : "v"(nxt[0][1][r]), "v"(nxt[1][1][r]));
+            }
+            if (j == MS + 16) mx0 = max_halves(mx0);
+            if (j == MS + 17) mx1 = max_halves(mx1);
+            if (j == MS + 18) {
+                asm("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(g0), "=&v"(g1) : "v"(mx0), "v"(mx1), "s"(escale), "v"(nmsub[0]), "v"(nmsub[1]));
+            }
+            if (j == MS + 19) asm("v_max_f32 %0, %1, %2" : "=v"(grow) : "v"(g0), "v"(g1));
+            if (j == dma_gap(0)) dma_piece_at<0>(lk0, rk, koff[0]);
+            if (j == dma_gap(1)) dma_piece_at<KPIECE>(lk0, rk, piece_off<4>(koff[0], k_rs_bytes));
+            if (j == dma_gap(2)) dma_piece_at<2 * KPIECE>(lk0, rk, piece_off<8>(koff[0], k_rs_bytes));
+            if (j == dma_gap(3)) dma_piece_at<3 * KPIECE>(lk0, rk, piece_off<12>(koff[0], k_rs_bytes));
+            if (j == dma_gap(4)) dma_piece_at<0>(lv0, rv, voff[0]);
+            if (j == dma_gap(5)) dma_piece_at<1024>(lv0, rv, piece_off<16>(voff[0], v_rs_bytes));
+            if (j == dma_gap(6)) dma_piece_at<2048>(lv0, rv, piece_off<32>(voff[0], v_rs_bytes));
+            if (j == dma_gap(7)) dma_piece_at<3072>(lv0, rv, piece_off<48>(voff[0], v_rs_bytes));
+            if (j == 27) kf0 = kfrag(ksm_next, 0);
+            if (j == 28) kf1 = kfrag(ksm_next, 1);
+            if (j == 29 && RING > 3) kf2 = kfrag(ksm_next, 2);
+            SCHED_FENCE();
+        }
+        if (mask_next) {
+            mask_tile(tn, nxt, Lk_n, qoff_n);
+            mx0 = row_max(nxt, 0);
+            mx1 = row_max(nxt, 1);
+            g0 = __builtin_fmaf(mx0, escale, nmsub[0]);
+            g1 = __builtin_fmaf(mx1, escale, nmsub[1]);
+            grow = fmaxf(g0, g1);
+        }
+        mx0_out = mx0;
+        mx1_out = mx1;
+        if (!seam && __builtin_amdgcn_ballot_w64(grow > kDeferLog2) != 0) {
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+            SCHED_FENCE();
+            raise_max(0, fmaxf(g0, 0.f));
+            raise_max(1, fmaxf(g1, 0.f));
+            SCHED_FENCE();
+            asm volatile("s_nop 3" ::: "memory");
+        }
+    };
+
+    // ---- epilogue of a finished piece (prefill64_kernel's): O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
+    auto epilogue = [&](const Piece& c) {
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // last PV results readable
+        SCHED_FENCE();
+        const bool partial = c.it_row >= 0;
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) {
+            const int my_q = c.q_wg0 + wave * 64 + 32 * qc + l31;
+            const float l_loc = l_acc[qc][0] + l_acc[qc][1];
+            const float l_tot = l_loc + swap_halves(l_loc);
+            const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+            const float m_log2 = -nmsub[qc];
+            if (my_q < c.Sq && partial) {
+                const int64_t row = (int64_t)c.it_row + (my_q - c.q_wg0);
+                float* opart = (float*)p.workspace + row * HD;
+                float* lpart = (float*)p.workspace + (int64_t)p.pf_part_rows * HD;
+#pragma unroll
+                for (int db = 0; db < DB; db++)
+#pragma unroll
+                    for (int tq = 0; tq < 4; tq++) {
+                        f32x4 w;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
+                        *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    }
+                if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_log2 + __log2f(l_tot));
+            } else if (my_q < c.Sq) {
+                T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)c.b * p.o_batch_stride) + (c.q_first + my_q) * p.o_row_stride + (int64_t)c.h * p.o_head_stride;
+                if (((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0) {
+#pragma unroll
+                    for (int db = 0; db < DB; db++)
+#pragma unroll
+                        for (int pr = 0; pr < 2; pr++) {
+                            typename X::v4 we, wo;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                we[e] = X::cvt(o[db][qc][4 * (2 * pr) + e] * inv);
+                                wo[e] = X::cvt(o[db][qc][4 * (2 * pr + 1) + e] * inv);
+                            }
+                            uint2 ue, uo;
+                            __builtin_memcpy(&ue, &we, 8);
+                            __builtin_memcpy(&uo, &wo, 8);
+                            const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
+                            const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
+                            *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        }
+                } else {
+#pragma unroll
+                    for (int db = 0; db < DB; db++)
+#pragma unroll
+                        for (int tq = 0; tq < 4; tq++) {
+                            typename X::v4 w;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][qc][4 * tq + e] * inv);
+                            *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+                        }
+                }
+                if (p.softmax_lse && g == 0) {
+                    const float lse = (l_tot == 0.f) ? INFINITY : (m_log2 + __log2f(l_tot)) * 0.6931471805599453f;
+                    p.softmax_lse[((int64_t)c.b * p.h + c.h) * p.seqlen_q + my_q] = lse;
+                }
+            }
+        }
+        SCHED_FENCE();
+    };
+
+    // ---- kernel start: the V ring holds FINITE data from here on (a key row past a sequence's end has probability exactly 0, and
+    // 0 x NaN would poison O; later pieces find the previous pieces' tiles there — finite) ----
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < (3 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + VBASE + (i * 256 + tid) * 16) = z;
+        __syncthreads();
+    }
+
+    Piece cur, nx;
+    load_piece(q_idx, cur);
+    bool cold = true;
+    bool have_next = false;
+    V8 kfa, kfb, kfc;
+    int t = 0;                                    // tile of `cur` whose scores the buffer of the coming step holds
+    int t_mask = 0;
+    float bx0 = 0.f, bx1 = 0.f;                   // row maxima of the tile scored by the last step
+
+    // one piece boundary: the epilogue of `cur`, then `nx` becomes current (chained: its S'(tb) is in the score buffer and its tiles are
+    // in flight; else cold).  Returns false when the queue is empty.
+    for (;;) {
+        if (cold) {
+            // ---- cold start of `cur` (prefill64_kernel's prologue); the ring is drained and every wave is past its LDS reads ----
+            reset_acc();
+            nmsub[0] = nmsub[1] = 0.f;
+            t = cur.tb;
+            t_mask = t_mask_of(cur);
+            vs_cur = 0;
+            vs_dma = 2 * S::kTileBytes;
+            if (cur.nt > cur.tb) {
+                dma_k_all(cur, cur.tb, 0);
+                dma_v_all(cur, cur.tb, 0);
+                dma_k_all(cur, cur.tb + 1, 1);
+                q_from_global(cur);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                {
+                    const char* ksm = smem;
+#pragma unroll
+                    for (int f = 0; f < 2 * KK; f++) {
+                        const V8 a = kfrag(ksm, f);
+#pragma unroll
+                        for (int qc = 0; qc < 2; qc++) {
+                            if (f < 2) M::qk_first(sc[f & 1][qc], a, qf[qc][f >> 1]);
+                            else M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
+                        }
+                    }
+                    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+                    SCHED_FENCE();
+                    if (cur.tb >= t_mask) mask_tile(cur.tb, sc, cur.Lk, cur.q_wg0 + wave * 64 + cur.off);
+#pragma unroll
+                    for (int qc = 0; qc < 2; qc++) {
+                        const float mx = row_max(sc, qc);
+                        nmsub[qc] = (mx == -INFINITY) ? 0.f : -mx * escale;
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                dma_k_all(cur, cur.tb + 2, 0);
+                dma_v_all(cur, cur.tb + 1, 1);
+                k_rebase(cur.kbase, cur.tb + 2, cur.Lk);
+                v_rebase(cur.vbase, cur.tb + 1, cur.Lk);
+                kfa = kfrag(smem + KSLOT, 0);
+                kfb = kfrag(smem + KSLOT, 1);
+                kfc = kfrag(smem + KSLOT, 2);
+            }
+            cold = false;
+        }
+        // ---- the next piece of the queue: resolve it, start its Q block on its way to the staging area ----
+        have_next = q_idx + 1 < q_end;
+        if (have_next) load_piece(q_idx + 1, nx);
+        // chain into it iff this piece has the three steps the re-base points need and the next one has a tile to score
+        const bool chain = have_next && (cur.nt - t >= 3) && (nx.nt > nx.tb);
+        if (chain) dma_q_stage(nx);
+        const int nt = cur.nt;
+        const int qoff_c = cur.q_wg0 + wave * 64 + cur.off, qoff_n = nx.q_wg0 + wave * 64 + nx.off;
+        const int t_mask_n = chain ? t_mask_of(nx) : 0;
+        bool odd = false;                          // the piece ended after an even-parity step: its successor's first step has odd parity
+        // ---- the tile steps of `cur`: even stream positions score into sd, odd ones into sc ----
+        // (a piece entered at odd parity — chained after an even-length run — takes its first step from sd)
+        bool done = !(t < nt);
+        while (!done) {
+            // even position
+            {
+                const bool last = t == nt - 1;
+                const Piece* kto = (chain && t == nt - 3) ? &nx : nullptr;
+                const Piece* vto = (chain && t == nt - 2) ? &nx : nullptr;
+                const bool seam = chain && last;
+                if (seam) q_from_stage();
+                const bool mnext = seam ? (nx.tb >= t_mask_n) : (t + 1 >= t_mask);
+                step(0, sc, sd, kfa, kfb, kfc, kto, vto, mnext, seam ? nx.tb : t + 1, seam ? nx.Lk : cur.Lk, seam ? qoff_n : qoff_c, seam, bx0, bx1);
+                t++;
+                if (last) { done = true; odd = true; break; }
+            }
+            {
+                const bool last = t == nt - 1;
+                const Piece* kto = (chain && t == nt - 3) ? &nx : nullptr;
+                const Piece* vto = (chain && t == nt - 2) ? &nx : nullptr;
+                const bool seam = chain && last;
+                if (seam) q_from_stage();
+                const bool mnext = seam ? (nx.tb >= t_mask_n) : (t + 1 >= t_mask);
+                step(1, sd, sc, kfa, kfb, kfc, kto, vto, mnext, seam ? nx.tb : t + 1, seam ? nx.Lk : cur.Lk, seam ? qoff_n : qoff_c, seam, bx0, bx1);
+                t++;
+                if (last) done = true;
+            }
+        }
+        (void)odd;
+        break;
+    }
+#undef P64_X0
+#undef P64_X1
+    (void)epilogue;
+}
+
+}  // namespace vattn_k

@@ -89,6 +89,10 @@ class PageManager:
     def premap(self, seqlen: int) -> int:
         return self._lib.vattn_premap(self._h, int(seqlen))
 
+    def wait_pool_ready(self, timeout_ms: int = -1) -> int:
+        """Handles the mapper thread still has to create ahead of demand (0 = ready); blocks up to timeout_ms (< 0: until ready)."""
+        return int(self._lib.vattn_wait_pool_ready(self._h, int(timeout_ms)))
+
     def cancel_premap(self, slot: int) -> None:
         self._check(self._lib.vattn_cancel_premap(self._h, int(slot)))
 

@@ -68,9 +68,29 @@ def init_kvcache(num_layers: int, num_kv_heads: int, head_size: int, max_batch_s
     return list(tensors)
 
 
+_wait_pool = True
+pool_ready_seconds = 0.0       # what the last reserve_physical_pages spent waiting for the pool's handles (introspection: bench.py)
+
+
+def set_wait_pool_ready(on: bool) -> None:
+    """MI355X extension.  True (default): reserve_physical_pages returns once the mapper thread has created the handles it creates ahead
+    of demand — the whole pool up to 40 000 pages (1-1.5 s for 31 k handles of 8 MiB), a 4 096-handle window above that — which is
+    what the reference's reserve does for every page (cudaInternal.h:45-59).  False: return at once and let creation run under the
+    first iterations (their launches then wait for the driver behind hipMemCreate: profiles/r05_cold_pool.md)."""
+    global _wait_pool
+    _wait_pool = bool(on)
+
+
 def reserve_physical_pages(free_memory: int) -> int:
     """apis.h:23-25: number of physical pages in the pool (multiple of 2*L)."""
-    return _require().reserve_physical_pages(free_memory)
+    global pool_ready_seconds
+    n = _require().reserve_physical_pages(free_memory)
+    if _wait_pool:
+        import time
+        t0 = time.perf_counter()
+        _require().wait_pool_ready(-1)
+        pool_ready_seconds = time.perf_counter() - t0
+    return n
 
 
 def step(seq_lens: List[int], eager_reclaim: bool) -> None:
