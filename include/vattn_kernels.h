@@ -34,7 +34,7 @@ extern "C" {
 #define VATTN_DTYPE_F16 0
 #define VATTN_DTYPE_BF16 1
 
-#define VATTN_KERNELS_ABI 4u            /* bumped whenever vattn_attn_params changes */
+#define VATTN_KERNELS_ABI 5u            /* bumped whenever vattn_attn_params changes */
 
 typedef struct vattn_attn_params {
     /* sizeof(vattn_attn_params) and VATTN_KERNELS_ABI of the header the CALLER was built against.  The block grows between releases
@@ -108,7 +108,12 @@ typedef struct vattn_attn_params {
     const struct vattn_prefill_item* pf_blocks;    /* device: num_pf_blocks SPLIT query blocks (what the merge pass walks)      */
     int32_t num_pf_items, num_pf_blocks;
     int32_t pf_part_rows;                          /* fp32 partial rows of all split blocks (sizes the workspace)               */
-    int32_t pf_reserved;
+    /* PERSISTENT form of the work list (round 5; both zero: one workgroup per piece, in list order).  vattn_prefill_plan_wg also
+     * ASSIGNS the pieces: pf_items is grouped by workgroup, workgroup w owns pieces [pf_wg_first[w], pf_wg_first[w + 1]) and walks them
+     * in that order without stopping its K / V tile stream between them (csrc/prefill64p_kernels.hip: the next piece's Q block and
+     * first tiles are fetched under the current piece's last tiles; one workgroup per CU).  pf_wg_first has pf_num_wg + 1 entries. */
+    int32_t pf_num_wg;
+    const int32_t* pf_wg_first;                    /* device: int32[pf_num_wg + 1]                                              */
 } vattn_attn_params;
 
 typedef struct vattn_prefill_item {
@@ -151,6 +156,16 @@ int32_t vattn_decode_plan(const vattn_attn_params* p, const int32_t* cache_seqle
  * p->num_splits = -T forces pieces of at most T tiles (tests, A/B measurements).  Pure host arithmetic. */
 int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
                            int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* counts_out);
+
+/* The same plan for PERSISTENT workgroups (vattn_attn_params.pf_num_wg / pf_wg_first): pieces are priced with the chained overhead
+ * (a piece that follows another in a workgroup's queue pays its epilogue and a fragment of a tile, not a cold prologue), so finer cuts
+ * pay off, and are assigned to at most `max_wg` workgroups (<= 0: one per CU, 256) longest first, each to the least loaded one among
+ * the workgroups of its kv head's XCD class (workgroup w runs on XCD w % 8; class = kv head modulo the classes that divide 8, so that an
+ * XCD's L2 keeps seeing one kv head).  items_out comes back GROUPED by workgroup; wg_first_out receives num_wg + 1 offsets;
+ * counts_out[4] = {items, split blocks, partial rows, num_wg}.  Returns the number of items (0: default launch, as above). */
+int32_t vattn_prefill_plan_wg(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
+                              int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* wg_first_out, int32_t max_wg,
+                              int32_t* counts_out);
 
 /* What vattn_flash_attn_with_kvcache will launch for `p` — pure host arithmetic on the shapes (pointers are only tested for NULL), so a
  * test can pin the launch plans without a GPU and without a stopwatch (tests/test_plan_table.py; the reference's equivalents are the

@@ -97,3 +97,73 @@ def test_decode_plan_needs_no_host_lengths_and_the_grid_heuristics_stay_selectab
     assert K.describe(_params(300, 1, 2048, 8, 2, knew=1))["path"] == 0          # beyond the 256 sequences the plan prologue takes
     f = K.describe(_params(16, 1, 32768, 32, 4, knew=1, splits=-100))            # forced workgroup count (tests, A/B)
     assert f["path"] == 2 and f["workgroups"] == 400
+
+
+# ---- persistent work lists (vattn_prefill_plan_wg, round 5): pure host arithmetic ----
+def _plan_wg(b, q_lens, k_lens, h, h_k, max_wg=0, force_tiles=0):
+    import ctypes as C
+    from vattention_amd import kernels as K
+    p = K.AttnParams()
+    p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal = b, max(q_lens), h, h_k, 128, 1
+    if force_tiles:
+        p.num_splits = -force_tiles
+    nblk = sum((q + 255) // 256 for q in q_lens) * h
+    cap_i, cap_b = 17 * nblk + 16, nblk + 16
+    items, blocks = (K.PrefillItem * cap_i)(), (K.PrefillItem * cap_b)()
+    counts, wg_first = (C.c_int32 * 4)(), (C.c_int32 * 257)()
+    ql, kl = (C.c_int32 * b)(*q_lens), (C.c_int32 * b)(*k_lens)
+    n = K.klib().vattn_prefill_plan_wg(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, wg_first, max_wg, counts)
+    return n, [items[i] for i in range(max(n, 0))], [blocks[i] for i in range(counts[1])], list(wg_first[:counts[3] + 1]), list(counts)
+
+
+@pytest.mark.parametrize("case", [
+    dict(b=1, q=[9441], k=[9441], h=32, h_k=8),                       # one arxiv-length prompt, llama-3-8b heads: 1 184 blocks, several rounds
+    dict(b=1, q=[8192], k=[8192], h=8, h_k=1),                        # the TP8 rank's prompt: one underfilled round, blocks cut
+    dict(b=3, q=[23774, 5637, 1000], k=[23774, 5637, 1000], h=8, h_k=1),   # ragged batch
+    dict(b=1, q=[2048], k=[32768], h=8, h_k=1),                       # chunk on a long prefix
+    dict(b=2, q=[300, 70], k=[300, 70], h=4, h_k=2),                  # tiny: fewer pieces than XCDs
+], ids=["llama8b_9k", "tp8_8k", "ragged3", "chunk2k@30k", "tiny"])
+def test_persistent_work_list_covers_every_block_once_and_balances_the_queues(case):
+    b, q, k, h, h_k = case["b"], case["q"], case["k"], case["h"], case["h_k"]
+    n, items, blocks, wg_first, counts = _plan_wg(b, q, k, h, h_k)
+    assert n > 0 and counts[0] == n and counts[3] >= 1
+    nwg = counts[3]
+    assert nwg <= 256 and (nwg % 8 == 0 or nwg == n)
+    assert wg_first[0] == 0 and wg_first[-1] == n and all(x <= y for x, y in zip(wg_first, wg_first[1:]))
+    assert all(wg_first[w] < wg_first[w + 1] for w in range(nwg)), "an empty queue would be a workgroup without work"
+    # every (entry, head, query block) is covered exactly once by contiguous tile ranges that end open
+    cover = {}
+    for it in items:
+        cover.setdefault((it.b, it.h, it.qb), []).append((it.tile_begin, it.tile_end, it.nshares, it.part_row))
+    want = {(e, hh, qb) for e in range(b) for hh in range(h) for qb in range((q[e] + 255) // 256)}
+    assert set(cover) == want
+    for key, pcs in cover.items():
+        pcs.sort()
+        e, _, qb = key
+        tiles = (min(k[e], qb * 256 + 256 + (k[e] - q[e])) + 63) // 64
+        assert pcs[0][0] == 0 and pcs[-1][1] == 0x7fffffff and len(pcs) == pcs[0][2]
+        for (a0, a1, _, _), (b0, _, _, _) in zip(pcs, pcs[1:]):
+            assert a1 == b0 and a0 < a1 <= tiles
+        assert (len(pcs) == 1) == (pcs[0][3] == -1)
+    # queues: longest first inside a queue; the kv heads of a queue's pieces share its XCD class; loads within a piece of each other
+    G = h // h_k
+    ncls = h_k if (nwg >= 8 and h_k <= 8 and 8 % h_k == 0) else 1
+    length = lambda it, key: (min(it.tile_end, (min(k[key[0]], key[2] * 256 + 256 + (k[key[0]] - q[key[0]])) + 63) // 64) - it.tile_begin)
+    loads = []
+    for w in range(nwg):
+        mine = items[wg_first[w]:wg_first[w + 1]]
+        ls = [length(it, (it.b, it.h, it.qb)) for it in mine]
+        assert ls == sorted(ls, reverse=True)
+        assert all((it.h // G) % ncls == (w % 8) % ncls for it in mine)
+        loads.append(sum(2 * x + 2 + (3 if it.nshares > 1 else 0) for x, it in zip(ls, mine)))
+    longest = max(2 * length(it, (it.b, it.h, it.qb)) + 5 for it in items)
+    for c in range(ncls):
+        cl = [loads[w] for w in range(nwg) if (w % 8) % ncls == c]
+        assert max(cl) - min(cl) <= longest, "greedy longest-first leaves no queue more than one piece ahead of another"
+
+
+def test_persistent_work_list_respects_a_workgroup_cap_and_a_forced_piece_length():
+    n, items, blocks, wg_first, counts = _plan_wg(1, [8192], [8192], 8, 1, max_wg=64, force_tiles=16)
+    assert n > 0 and counts[3] == 64 and wg_first[-1] == n
+    assert all((it.tile_end if it.tile_end != 0x7fffffff else it.tile_begin + 16) - it.tile_begin <= 16 for it in items)
+    assert counts[1] == len(blocks) and all(bk.nshares > 1 for bk in blocks)

@@ -93,14 +93,14 @@ def prefill(variant):
         tag = ""
         if WORKLIST:          # host-planned work list (vattn_prefill_plan) where the planner wants one
             from vattention_amd import flash_attn as FA
-            pl = FA.prefill_plan(p, [n], [c + n], DEV, force_tiles=WL_TILES)
+            pl = FA.prefill_plan(p, [n], [c + n], DEV, force_tiles=WL_TILES, persistent=PERSIST)
             if pl.t is not None:
                 pl.attach(p)
                 need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
                 w = torch.empty(need // 4 + 1, dtype=torch.float32, device=DEV)
                 p.workspace = w.data_ptr()
                 keep += [pl, w]
-                tag = "  [work list: %d pieces, %d split blocks]" % (pl.n_items, pl.n_blocks)
+                tag = "  [work list: %d pieces, %d split blocks%s]" % (pl.n_items, pl.n_blocks, ", %d persistent workgroups" % pl.n_wg if pl.n_wg else ", one workgroup per piece")
         ms = time_ms(p, 1, 3 if n > 10000 else 10)
         fl = 4.0 * Hq * 128 * (n * c + n * (n + 1) / 2)
         print("  %-26s n=%6d c=%6d Hq=%2d Hkv=%d : %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)%s" % (name, n, c, Hq, Hkv, ms, fl / ms / 1e9, fl / ms / 1e9 / 25, tag))
@@ -168,6 +168,7 @@ def decode(variant):
 ONLY = None
 ROTATE = False
 WORKLIST = False
+PERSIST = True       # work lists walked by persistent workgroups (prefill64p_kernel); --per-piece: one workgroup per piece (prefill64_kernel)
 WL_TILES = 0
 MEGA = 1
 DTYPE = torch.float16
@@ -179,6 +180,10 @@ if __name__ == "__main__":
     if "--splits" in sys.argv:
         SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
     WORKLIST = "--worklist" in sys.argv
+    PERSIST = "--per-piece" not in sys.argv
+    if os.environ.get("KBENCH_PERSIST_MAX_BLOCKS"):      # A/B: let the big balanced grids take a persistent list too
+        from vattention_amd import flash_attn as _FA
+        _FA.PERSISTENT_MAX_BLOCKS = int(os.environ["KBENCH_PERSIST_MAX_BLOCKS"])
     ROTATE = "--rotate" in sys.argv      # decode: rotate over enough caches that the Infinity Cache cannot serve repeated launches
     WL_TILES = int(sys.argv[sys.argv.index("--wl-tiles") + 1]) if "--wl-tiles" in sys.argv else 0
     if "--mega" in sys.argv:      # decode only: K/V as one layer's view of a megacache tensor with this many layers

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "vattention_amd")
 CSRC = os.path.join(PKG, "csrc")
 ARCH = "gfx950"
-LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "vmm_selfcheck.hip", "attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "decode_kernels.hip",
+LIB_SOURCES = ("page_manager.cpp", "hip_backend.cpp", "capi.cpp", "vmm_selfcheck.hip", "attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "prefill64p_kernels.hip", "decode_kernels.hip",
                "cache_kernels.hip", "hybrid_kernels.hip")
 
 
@@ -36,7 +36,7 @@ def _run(cmd):
 # prefill64_kernel counts its own `vmcnt` around LDS-DMA issued by inline asm: a register spill (scratch access, compiler-inserted
 # waits the hand-placed ones do not know about) silently breaks it, and the kernel sits at the SGPR / VGPR limits.  Its translation unit
 # is therefore compiled with the resource-usage remarks on, and the build FAILS when any instantiation of a guarded kernel spills.
-NO_SPILL_KERNELS = {"prefill64_kernels.hip": "prefill64_kernel"}
+NO_SPILL_KERNELS = {"prefill64_kernels.hip": "prefill64_kernel", "prefill64p_kernels.hip": "prefill64p_kernel"}
 
 
 def _compile(hipcc, flags, src, obj):
@@ -67,7 +67,7 @@ def _compile(hipcc, flags, src, obj):
 def build_lib(force=False):
     out = os.path.join(PKG, "libvattn_amd.so")
     srcs = [os.path.join(CSRC, f) for f in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "page_manager.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
+    deps = srcs + [os.path.join(CSRC, "page_manager.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill64_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
                    os.path.join(ROOT, "include", "vattn.h"),
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
@@ -84,7 +84,7 @@ def build_lib(force=False):
     return out
 
 
-LAB_SOURCES = ("attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "decode_kernels.hip", "cache_kernels.hip", "hybrid_kernels.hip")
+LAB_SOURCES = ("attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "prefill64p_kernels.hip", "decode_kernels.hip", "cache_kernels.hip", "hybrid_kernels.hip")
 
 
 def build_lab(force=False):
@@ -96,7 +96,7 @@ def build_lab(force=False):
     os.makedirs(outdir, exist_ok=True)
     out = os.path.join(outdir, "libvattn_lab.so")
     srcs = [os.path.join(CSRC, f) for f in LAB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
+    deps = srcs + [os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill64_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -239,6 +239,8 @@ int validate(const vattn_attn_params* p) {
     if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
         return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
     if (p->pf_items && (p->seqlen_q == 1 || p->d != 128)) return fail(VATTN_K_ERR_INVALID, "pf_items (prefill work list) applies to the prefill form with head dimension 128");
+    if ((p->pf_num_wg != 0) != (p->pf_wg_first != nullptr) || p->pf_num_wg < 0 || (p->pf_num_wg && !p->pf_items))
+        return fail(VATTN_K_ERR_INVALID, "pf_num_wg and pf_wg_first (persistent work list) must be given together, with pf_items");
     if (p->split_items && p->seqlen_q != 1) return fail(VATTN_K_ERR_INVALID, "split_items (length-balanced plan) applies to the decode form only");
     if (!kLab) {
         const int til = (p->variant >> 1) & 7;
@@ -289,6 +291,13 @@ int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_hos
                            int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* counts_out) {
     if (!abi_ok(p)) return VATTN_K_ERR_INVALID;
     return prefill_worklist(p, q_lens_host, k_lens_host, items_out, cap_items, blocks_out, cap_blocks, counts_out);
+}
+
+int32_t vattn_prefill_plan_wg(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
+                              int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* wg_first_out, int32_t max_wg,
+                              int32_t* counts_out) {
+    if (!abi_ok(p) || !wg_first_out) return VATTN_K_ERR_INVALID;
+    return prefill_worklist(p, q_lens_host, k_lens_host, items_out, cap_items, blocks_out, cap_blocks, counts_out, wg_first_out, max_wg);
 }
 
 size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode) {

@@ -261,7 +261,8 @@ void launch_append(const vattn_attn_params* p, hipStream_t st);         // cache
 int launch_prefill_form(const vattn_attn_params* p, hipStream_t st);    // prefill_kernels.hip (seqlen_q > 1)
 size_t prefill_workspace_bytes(const vattn_attn_params* p);
 int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const int32_t* k_lens, vattn_prefill_item* items, int cap_items,
-                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts);   // prefill_kernels.hip
+                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts, int32_t* wg_first = nullptr, int max_wg = 0);   // prefill_kernels.hip
+void launch_prefill64p(const vattn_attn_params* p, hipStream_t st);      // prefill64p_kernels.hip: persistent workgroups over a grouped work list
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode);   // prefill64_kernels.hip (d = 128); done: counters of the single-launch merge or NULL
 int* merge_counters(hipStream_t st, size_t n_ints);                      // attn_api.hip: zeroed per-(device, stream) counters, NULL while capturing
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)

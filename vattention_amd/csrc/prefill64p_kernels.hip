@@ -27,12 +27,6 @@ namespace vattn_k {
 constexpr int kQStage = 87040;                 // LDS offset of the Q staging area: 4 waves x 16 KiB (K ring 36 864 + V ring 49 152 + 16, rounded up to 1 KiB)
 constexpr int kSmem64p = kQStage + 65536;      // 152 576 bytes: one workgroup per CU (160 KiB of LDS)
 
-// one 1-KiB piece of the next Q block: lane i's 16 bytes (row l31, d = 16 kk + 8 g ..) land at M0 + 16 i — the layout the fragment
-// registers want, so the read-back is lane-linear; OFF = 32 kk bytes rides in the instruction
-template <int OFF> __device__ __forceinline__ void dma_q_piece(unsigned lds_addr, u32x4 rsrc, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen offset:%3 lds" : : "s"(lds_addr), "s"(rsrc), "v"(voff), "i"(OFF) : "memory", "m0");
-}
-
 template <typename T, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3>
 __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p) {
     using X = Tr<T>;
@@ -59,62 +53,94 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
     const bool causal = p.is_causal != 0;
     const int G = p.h / p.h_k;
     const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
-    const unsigned q_rs_bytes = (unsigned)p.q_row_stride * 2u;
 
     // ---- this workgroup's queue: pieces [q_idx, q_end) of the list, in order ----
     int q_idx = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x]);
     const int q_end = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x + 1]);
     if (q_idx >= q_end) return;
 
-    // one piece, resolved against the DEVICE-side lengths (the list is a hint: include/vattn_kernels.h)
-    struct Piece {
-        int b, h, q_wg0, Sq, Lk, off, tb, nt, it_row;
-        long long q_first;
-        unsigned long long kbase, vbase;      // byte addresses of (slot, kv head) row 0
+    // One piece, resolved against the DEVICE-side lengths (the list is a hint: include/vattn_kernels.h).  Its fifteen scalars live in the
+    // LANES of one vector register (field i in lane i; v_writelane / v_readlane): the kernel sits at the SGPR limit, the steady state
+    // needs four of them (kept in scalars below), and the compiler's own spilling of thirty more put lane reads — and scratch reloads
+    // with their vmcnt(0) — into the tile step.
+    enum { F_B, F_H, F_QWG0, F_SQ, F_LK, F_OFF, F_TB, F_NT, F_ROW, F_QF_LO, F_QF_HI, F_KB_LO, F_KB_HI, F_VB_LO, F_VB_HI };
+#define PF(rec, i) ((int)__builtin_amdgcn_readlane((int)(rec), (i)))
+#define PF64(rec, i) (((unsigned long long)(unsigned)PF(rec, (i) + 1) << 32) | (unsigned)PF(rec, i))
+    // (The rare blocks read the kernel arguments through a laundered pointer: the forty dwords they need — strides, table pointers — are
+    // then loaded where they are used instead of once in front of the loop, where they would sit in SGPRs, be spilled to vector lanes
+    // and push the steady state's vector registers out.)
+    auto args = [&]() -> const vattn_attn_params& {
+        // the parameter block is the kernel's only argument: offset 0 of the kernarg segment (taking &p would copy it to scratch)
+        const vattn_attn_params* q = (const vattn_attn_params*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(q));
+        return *q;
     };
-    auto load_piece = [&](int idx, Piece& c) {
+    auto load_piece = [&](int idx) -> int {
+        const vattn_attn_params& p = args();
         const vattn_prefill_item it = p.pf_items[idx];
-        c.b = __builtin_amdgcn_readfirstlane(it.b);
-        c.h = __builtin_amdgcn_readfirstlane(it.h);
+        const int b = __builtin_amdgcn_readfirstlane(it.b), h = __builtin_amdgcn_readfirstlane(it.h);
         const int qb = __builtin_amdgcn_readfirstlane(it.qb);
         const int it_tb = __builtin_amdgcn_readfirstlane(it.tile_begin), it_te = __builtin_amdgcn_readfirstlane(it.tile_end);
-        c.it_row = __builtin_amdgcn_readfirstlane(it.nshares > 1 ? it.part_row : -1);
-        const int hk = c.h / G;
-        const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[c.b] : c.b);
-        int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[c.b] : p.seqlen_k) + p.seqlen_knew);
+        const int it_row = __builtin_amdgcn_readfirstlane(it.nshares > 1 ? it.part_row : -1);
+        const int hk = h / G;
+        const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+        int Lk = __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew);
         Lk = Lk > p.seqlen_k ? p.seqlen_k : Lk;
-        c.Lk = Lk;
-        c.Sq = p.q_lens ? __builtin_amdgcn_readfirstlane(p.q_lens[c.b]) : p.seqlen_q;
-        c.q_first = p.q_start ? (long long)__builtin_amdgcn_readfirstlane(p.q_start[c.b]) : 0;
-        c.off = Lk - c.Sq;
-        c.q_wg0 = qb * BM;
+        const int Sq = p.q_lens ? __builtin_amdgcn_readfirstlane(p.q_lens[b]) : p.seqlen_q;
+        const long long q_first = p.q_start ? (long long)__builtin_amdgcn_readfirstlane(p.q_start[b]) : 0;
+        const int off = Lk - Sq, q_wg0 = qb * BM;
         int n_end = Lk;
-        if (causal) n_end = min(Lk, c.q_wg0 + BM + c.off);
+        if (causal) n_end = min(Lk, q_wg0 + BM + off);
         if (n_end < 0) n_end = 0;
         int nt_all = (n_end + PF_BN - 1) / PF_BN;
-        if (c.q_wg0 >= c.Sq) nt_all = 0;                       // a block beyond its entry's rows: nothing to score, nothing to store
-        c.tb = min(nt_all, it_tb);
-        c.nt = min(nt_all, it_te);
-        c.kbase = (unsigned long long)((const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride);
-        c.vbase = (unsigned long long)((const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride);
+        if (q_wg0 >= Sq) nt_all = 0;                           // a block beyond its entry's rows: nothing to score, nothing to store
+        const unsigned long long kb = (unsigned long long)((const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride);
+        const unsigned long long vb = (unsigned long long)((const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride);
+        // (v_writelane_b32 by inline asm: this compiler has the readlane builtin only)
+        auto wl = [](int val, int ln, int rec) -> int {
+            const int sv = __builtin_amdgcn_readfirstlane(val);      // (a value the compiler holds in a vector register would be printed as one)
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(rec) : "s"(sv), "n"(ln));
+            return rec;
+        };
+        int r = 0;
+        r = wl(b, F_B, r);
+        r = wl(h, F_H, r);
+        r = wl(q_wg0, F_QWG0, r);
+        r = wl(Sq, F_SQ, r);
+        r = wl(Lk, F_LK, r);
+        r = wl(off, F_OFF, r);
+        r = wl(min(nt_all, it_tb), F_TB, r);
+        r = wl(min(nt_all, it_te), F_NT, r);
+        r = wl(it_row, F_ROW, r);
+        r = wl((int)(unsigned)q_first, F_QF_LO, r);
+        r = wl((int)(unsigned)((unsigned long long)q_first >> 32), F_QF_HI, r);
+        r = wl((int)(unsigned)kb, F_KB_LO, r);
+        r = wl((int)(unsigned)(kb >> 32), F_KB_HI, r);
+        r = wl((int)(unsigned)vb, F_VB_LO, r);
+        r = wl((int)(unsigned)(vb >> 32), F_VB_HI, r);
+        return r;
     };
     // first tile of a wave's rows that needs masking (ragged end of the sequence / causal diagonal), prefill64_kernel's rule
-    auto t_mask_of = [&](const Piece& c) -> int { return min(c.Lk >> 6, causal ? ((c.q_wg0 + wave * 64 + c.off - 63) >> 6) + 1 : 0x7fffffff); };
+    auto t_mask_of = [&](int rec) -> int { return min(PF(rec, F_LK) >> 6, causal ? ((PF(rec, F_QWG0) + wave * 64 + PF(rec, F_OFF) - 63) >> 6) + 1 : 0x7fffffff); };
+
+    // (The rare blocks of the persistent loop — masking, epilogue, cold start — take their lane ids through an empty asm: what they derive
+    // from them is then not loop-invariant, and LICM cannot hoist dozens of per-lane constants in front of the loop, where they would be
+    // spilled to scratch and reloaded — with a compiler-placed vmcnt(0) — inside the tile steps.)
+    auto opaque = [](int x) -> int {
+        asm volatile("" : "+v"(x));
+        return x;
+    };
 
     // ---- DMA addressing (tile-invariant per-lane offsets; prefill64_kernel's padded K image and V sub-tiles) ----
-    unsigned koff[4], voff[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int row = 4 * (4 * wave + j) + (lane & 3);
-        koff[j] = (unsigned)row * k_rs_bytes + (unsigned)((lane >> 2) << 4);
-        const int key = 16 * j + (lane >> 2);
-        voff[j] = (unsigned)key * v_rs_bytes + (unsigned)((4 * wave + (lane & 3)) << 4);
-    }
+    // K piece pc = 4*wave + j holds rows 4*pc .. 4*pc+3 (lane i -> row 4*pc + (i & 3), chunk i >> 2); V piece j = (d block wave, keys 16*j ..):
+    // lane i -> key 16*j + (i >> 2), global chunk 4*wave + (i & 3).  Piece j's offset = piece 0's + j x (4 K rows | 16 V keys).
+    unsigned koff[1], voff[1];
+    koff[0] = (unsigned)(16 * wave + (lane & 3)) * k_rs_bytes + (unsigned)((lane >> 2) << 4);
+    voff[0] = (unsigned)(lane >> 2) * v_rs_bytes + (unsigned)((4 * wave + (lane & 3)) << 4);
     using M = Mfma<T>;
     const unsigned k_lds_wave = (unsigned)(wave * 4 * KPIECE);
     const unsigned v_lds_wave = (unsigned)(VBASE + wave * 4096);
     const unsigned q_lds_wave = (unsigned)(kQStage + wave * 16384);
-    const unsigned qvoff = (unsigned)l31 * q_rs_bytes + (unsigned)(g << 4);      // row l31 of a 32-row block, d = 8 g .. (+ 32 kk bytes in the instruction)
     auto tile_desc = [&](unsigned long long base, int t, int Lk_, unsigned rs_bytes) -> u32x4 {
         int rem = Lk_ - t * PF_BN;
         rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
@@ -127,28 +153,31 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
         return r;
     };
     // cold start only: K(t) -> K slot `ks`, V(t) -> V slot `vs`
-    auto dma_k_all = [&](const Piece& c, int t, int ks) {
-        const u32x4 r = tile_desc(c.kbase, t, c.Lk, k_rs_bytes);
+    auto dma_k_all = [&](int rec, int t, int ks) {
+        const u32x4 r = tile_desc(PF64(rec, F_KB_LO), t, PF(rec, F_LK), k_rs_bytes);
         const unsigned l0 = k_lds_wave + (unsigned)(ks * KSLOT);
         dma_piece_first(l0, r, koff[0]);
-        dma_piece(l0 + KPIECE, r, koff[1]);
-        dma_piece(l0 + 2 * KPIECE, r, koff[2]);
-        dma_piece(l0 + 3 * KPIECE, r, koff[3]);
+        dma_piece(l0 + KPIECE, r, piece_off<4>(koff[0], k_rs_bytes));
+        dma_piece(l0 + 2 * KPIECE, r, piece_off<8>(koff[0], k_rs_bytes));
+        dma_piece(l0 + 3 * KPIECE, r, piece_off<12>(koff[0], k_rs_bytes));
     };
-    auto dma_v_all = [&](const Piece& c, int t, int vs) {
-        const u32x4 r = tile_desc(c.vbase, t, c.Lk, v_rs_bytes);
+    auto dma_v_all = [&](int rec, int t, int vs) {
+        const u32x4 r = tile_desc(PF64(rec, F_VB_LO), t, PF(rec, F_LK), v_rs_bytes);
         const unsigned l0 = v_lds_wave + (unsigned)(vs * S::kTileBytes);
         dma_piece_first(l0, r, voff[0]);
-        dma_piece(l0 + 1024, r, voff[1]);
-        dma_piece(l0 + 2048, r, voff[2]);
-        dma_piece(l0 + 3072, r, voff[3]);
+        dma_piece(l0 + 1024, r, piece_off<16>(voff[0], v_rs_bytes));
+        dma_piece(l0 + 2048, r, piece_off<32>(voff[0], v_rs_bytes));
+        dma_piece(l0 + 3072, r, piece_off<48>(voff[0], v_rs_bytes));
     };
     // this wave's 64 rows of piece c's Q block -> its staging area (16 pieces of 1 KiB); rows at or beyond Sq fetch nothing
-    auto dma_q_stage = [&](const Piece& c) {
-        const int qw0 = c.q_wg0 + wave * 64;
-        const unsigned long long a = (unsigned long long)((const T*)p.q + (p.q_start ? 0 : (int64_t)c.b * p.q_batch_stride) + (c.q_first + qw0) * p.q_row_stride +
-                                                          (int64_t)c.h * p.q_head_stride);
-        int rows = c.Sq - qw0;
+    auto dma_q_stage = [&](int rec) {
+        const vattn_attn_params& p = args();
+        const unsigned q_rs_bytes = (unsigned)p.q_row_stride * 2u;
+        const unsigned qvoff = (unsigned)opaque(lane & 31) * q_rs_bytes + (unsigned)(opaque(lane >> 5) << 4);      // row l31 of a 32-row block, d = 8 g .. (+ 32 kk bytes in the instruction)
+        const int qw0 = PF(rec, F_QWG0) + wave * 64;
+        const unsigned long long a = (unsigned long long)((const T*)p.q + (p.q_start ? 0 : (int64_t)PF(rec, F_B) * p.q_batch_stride) +
+                                                          ((long long)PF64(rec, F_QF_LO) + qw0) * p.q_row_stride + (int64_t)PF(rec, F_H) * p.q_head_stride);
+        int rows = PF(rec, F_SQ) - qw0;
         rows = rows < 0 ? 0 : (rows > 64 ? 64 : rows);
         u32x4 r;
         r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
@@ -156,10 +185,15 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
         r[2] = __builtin_amdgcn_readfirstlane(rows > 0 ? (unsigned)(rows - 1) * q_rs_bytes + 256u : 0u);
         r[3] = 0x00020000u;
         asm volatile("s_nop 4" ::: "memory");                  // descriptor SGPRs written by readfirstlane -> VMEM
+        // 16 pieces of 1 KiB: lane i's 16 bytes (row l31 of query block qc, d = 16 kk + 8 g ..) land at M0 + 16 i — the layout the fragment
+        // registers want, so the read-back is lane-linear.  (The 32 kk bytes ride in the lane offset, not in the instruction's offset
+        // field: that field also moves the LDS address.)
         const unsigned v1 = qvoff + 32u * q_rs_bytes;
-#define VATTN_QP(KKI) dma_q_piece<32 * (KKI)>(q_lds_wave + 1024u * (KKI), r, qvoff); dma_q_piece<32 * (KKI)>(q_lds_wave + 8192u + 1024u * (KKI), r, v1);
-        VATTN_QP(0) VATTN_QP(1) VATTN_QP(2) VATTN_QP(3) VATTN_QP(4) VATTN_QP(5) VATTN_QP(6) VATTN_QP(7)
-#undef VATTN_QP
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            dma_piece(q_lds_wave + 1024u * kk, r, qvoff + 32u * kk);
+            dma_piece(q_lds_wave + 8192u + 1024u * kk, r, v1 + 32u * kk);
+        }
     };
 
     const float escale = p.softmax_scale * kLog2e;
@@ -175,15 +209,18 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
             }
     };
     // cold start: Q straight from global memory (prefill64_kernel's prologue)
-    auto q_from_global = [&](const Piece& c) {
+    auto q_from_global = [&](int rec) {
+        const int c_sq = PF(rec, F_SQ);
+        const int l31 = opaque(lane & 31), g = opaque(lane >> 5);
 #pragma unroll
         for (int qc = 0; qc < 2; qc++) {
-            const int my_q = c.q_wg0 + wave * 64 + 32 * qc + l31;
-            const T* qptr = (const T*)p.q + (p.q_start ? 0 : (int64_t)c.b * p.q_batch_stride) + (c.q_first + my_q) * p.q_row_stride + (int64_t)c.h * p.q_head_stride;
+            const int my_q = PF(rec, F_QWG0) + wave * 64 + 32 * qc + l31;
+            const T* qptr = (const T*)p.q + (p.q_start ? 0 : (int64_t)PF(rec, F_B) * p.q_batch_stride) + ((long long)PF64(rec, F_QF_LO) + my_q) * p.q_row_stride +
+                            (int64_t)PF(rec, F_H) * p.q_head_stride;
 #pragma unroll
             for (int kk = 0; kk < KK; kk++) {
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (my_q < c.Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+                if (my_q < c_sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
                 qf[qc][kk] = as_v8<V8>(v);
                 asm volatile("" : "+a"(qf[qc][kk]));
             }
@@ -197,7 +234,13 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
 #pragma unroll
         for (int i = 0; i < DB; i++)
 #pragma unroll
-            for (int qc = 0; qc < 2; qc++) o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int qc = 0; qc < 2; qc++) {
+                o[i][qc] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                // the zeros are born in the accumulator file: O^T is carried around a loop that resets it here, and a zero that enters
+                // that cycle as an ordinary vector value makes the whole cycle ordinary — 128 copies into the accumulator file at
+                // the loop header of every iteration
+                asm volatile("" : "+a"(o[i][qc]));
+            }
 #pragma unroll
         for (int qc = 0; qc < 2; qc++)
 #pragma unroll
@@ -220,11 +263,15 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
         return join_tr<V8>(lo, hi);
     };
     // masks tile tt of the piece whose (visible keys, first row of this wave + bottom-right offset) are (Lk_, qoff_)
-    auto mask_tile = [&](int tt, f32x16 (&s)[2][2], int Lk_, int qoff_) {
+    // kend_: one past the last key of the PIECE (64 x its last tile + 64): a piece shorter than three tiles is stepped over three anyway
+    // (below), and the tiles behind its own — another share's keys, or nothing — must count for nothing
+    auto mask_tile = [&](int tt, f32x16 (&s)[2][2], int Lk_, int qoff_, int kend_) {
         const int n0 = tt * PF_BN;
+        const int l31 = opaque(lane & 31), g = opaque(lane >> 5);
+        const int cap = min(Lk_, kend_) - 1;
 #pragma unroll
         for (int qc = 0; qc < 2; qc++) {
-            const int lim = causal ? min(Lk_ - 1, qoff_ + 32 * qc + l31) : Lk_ - 1;
+            const int lim = causal ? min(cap, qoff_ + 32 * qc + l31) : cap;
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -291,23 +338,32 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
         k_rows_left = Lk_ - t * PF_BN;
         const unsigned bnd = bound(k_rows_left, k_rs_bytes);
         asm volatile("s_mov_b32 s92, %1\n\ts_and_b32 s93, %2, 0xffff\n\ts_mov_b32 s94, %3\n\ts_mov_b32 s95, 0x00020000"
-                     : "={s[92:95]}"(rk) : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(bnd) : "scc");
+                     : "=&{s[92:95]}"(rk) : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(bnd) : "scc");
     };
     auto v_rebase = [&](unsigned long long base, int t, int Lk_) {
         const unsigned long long a = base + (unsigned long long)t * v_tile_b;
         v_rows_left = Lk_ - t * PF_BN;
         const unsigned bnd = bound(v_rows_left, v_rs_bytes);
         asm volatile("s_mov_b32 s96, %1\n\ts_and_b32 s97, %2, 0xffff\n\ts_mov_b32 s98, %3\n\ts_mov_b32 s99, 0x00020000"
-                     : "={s[96:99]}"(rv) : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(bnd) : "scc");
+                     : "=&{s[96:99]}"(rv) : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(bnd) : "scc");
     };
     unsigned vs_cur = 0, vs_dma = 2 * S::kTileBytes;
 
-    // what a step does besides prefill64_kernel's: `rk_to` / `rv_to` != null: instead of moving the K / V descriptor one tile on, point it
-    // at the NEXT piece's first tile (wave-uniform); (Lk_n, qoff_n, mask_next, tn): mask parameters of the tile being scored, S'(tn);
-    // `seam`: that tile opens the next piece — no max-growth test against the finished piece's reference; mx0 / mx1 out: its row maxima
-    // (after masking), log2-domain growth aside.
-    auto step = [&](const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2, const Piece* rk_to, const Piece* rv_to, const bool mask_next,
-                    const int tn, const int Lk_n, const int qoff_n, const bool seam, float& mx0_out, float& mx1_out) {
+    // ---- the scalars of the steady state: tile t of `cur` (whose scores the coming step turns into probabilities), rem = its steps still
+    // to go, the first tile that needs masking, its visible keys, (first query row of this wave + bottom-right offset), one past its last
+    // key.  EVERY piece is stepped over at least three tiles — the re-base points of the seam need three steps; the tiles behind a
+    // shorter piece's own (even a piece without any: stale list, empty sequence) are masked out whole, P = 0 — so every piece chains
+    // into its successor and only the first piece of a queue starts cold.  rem_k / rem_v / rem_s: the values of rem at which a step
+    // re-bases the K / V descriptor to the NEXT piece's first tile / is the seam (3, 2, 1, or -1 on the queue's last piece: never). ----
+    int cur = load_piece(q_idx), nx = 0;          // lane records (load_piece)
+    int t = 0, rem = 0, t_mask = 0, Lk_c = 0, qoff_c = 0, kend_c = 0;
+    int rem_k = -1, rem_v = -1, rem_s = -1;
+    float bx0 = 0.f, bx1 = 0.f;                   // row maxima of the tile scored by the last step (after masking)
+
+    // What a step does besides prefill64_kernel's: at rem == rem_k / rem_v it points the K / V descriptor at the first tile of the next
+    // piece instead of moving it one tile on; `seam` (rem == rem_s on entry): the tile it scores opens the next piece — that piece's
+    // mask parameters, and no max-growth test against the finished piece's reference.
+    auto step = [&](const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2, const bool seam) {
         const int s_cur = par;
         const char* ksm = smem + (s_cur ^ 1) * KSLOT;
         const char* ksm_next = smem + s_cur * KSLOT;
@@ -334,13 +390,16 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
             if (i == 19) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
                                       : "+s"(vs_cur), "=&s"(vs_dma) : "i"(S::kTileBytes), "i"(3 * S::kTileBytes) : "scc");
             if (i == 21) {
-                if (rk_to) k_rebase(rk_to->kbase, rk_to->tb, rk_to->Lk);
+                if (__builtin_expect(rem == rem_k, 0)) k_rebase(PF64(nx, F_KB_LO), PF(nx, F_TB), PF(nx, F_LK));
                 else k_rsrc_advance(rk, k_rows_left, k_tile_b, k_rs_bytes);
             }
             if (i == 23) {
-                if (rv_to) v_rebase(rv_to->vbase, rv_to->tb, rv_to->Lk);
+                if (__builtin_expect(rem == rem_v, 0)) v_rebase(PF64(nx, F_VB_LO), PF(nx, F_TB), PF(nx, F_LK));
                 else v_rsrc_advance(rv, v_rows_left, v_tile_b, v_rs_bytes);
             }
+            // the piece's counters move on inside a gap (pinned: scalar C++ would be sunk behind the step's last MFMA, where nothing
+            // hides it): t = the tile being scored, rem = tiles left after this step
+            if (i == 25) asm volatile("s_add_u32 %0, %0, 1\n\ts_sub_u32 %1, %1, 1" : "+s"(t), "+s"(rem) : : "scc");
             SCHED_FENCE();
         }
         V8 vf[RING];
@@ -385,17 +444,18 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
             if (j == 29 && RING > 3) kf2 = kfrag(ksm_next, 2);
             SCHED_FENCE();
         }
-        if (mask_next) {
-            mask_tile(tn, nxt, Lk_n, qoff_n);
+        // the tile just scored may need masking (at the seam the mask scalars are already the next piece's: VATTN_STEP)
+        if (__builtin_expect(t >= t_mask, 0)) {
+            mask_tile(t, nxt, Lk_c, qoff_c, kend_c);
             mx0 = row_max(nxt, 0);
             mx1 = row_max(nxt, 1);
             g0 = __builtin_fmaf(mx0, escale, nmsub[0]);
             g1 = __builtin_fmaf(mx1, escale, nmsub[1]);
             grow = fmaxf(g0, g1);
         }
-        mx0_out = mx0;
-        mx1_out = mx1;
-        if (!seam && __builtin_amdgcn_ballot_w64(grow > kDeferLog2) != 0) {
+        bx0 = mx0;
+        bx1 = mx1;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(grow > kDeferLog2) != 0, 0) && !seam) {      // (at the seam `grow` compares two pieces: void)
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             SCHED_FENCE();
             raise_max(0, fmaxf(g0, 0.f));
@@ -406,9 +466,12 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
     };
 
     // ---- epilogue of a finished piece (prefill64_kernel's): O^T[d = 32*db + 8*(r>>2) + 4*g + (r&3)][query] ----
-    auto epilogue = [&](const Piece& c) {
+    auto epilogue = [&](int rec) {
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // last PV results readable
         SCHED_FENCE();
+        const vattn_attn_params& p = args();
+        const int l31 = opaque(lane & 31), g = opaque(lane >> 5);
+        struct { int b, h, q_wg0, Sq, it_row; long long q_first; } c = {PF(rec, F_B), PF(rec, F_H), PF(rec, F_QWG0), PF(rec, F_SQ), PF(rec, F_ROW), (long long)PF64(rec, F_QF_LO)};
         const bool partial = c.it_row >= 0;
 #pragma unroll
         for (int qc = 0; qc < 2; qc++) {
@@ -422,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
                 float* opart = (float*)p.workspace + row * HD;
                 float* lpart = (float*)p.workspace + (int64_t)p.pf_part_rows * HD;
 #pragma unroll
-                for (int db = 0; db < DB; db++)
+                for (int db = 0; db < DB; db++) {
 #pragma unroll
                     for (int tq = 0; tq < 4; tq++) {
                         f32x4 w;
@@ -430,12 +493,14 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
                         for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
                         *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
                     }
+                    SCHED_FENCE();      // one 16-register accumulator block at a time: the loop around this code has no registers to lend
+                }
                 if (g == 0) lpart[row] = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_log2 + __log2f(l_tot));
             } else if (my_q < c.Sq) {
                 T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)c.b * p.o_batch_stride) + (c.q_first + my_q) * p.o_row_stride + (int64_t)c.h * p.o_head_stride;
-                if (((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0) {
+                {      // 16-byte stores (the launch keeps prefill64_kernel for output strides that are not multiples of 8 elements)
 #pragma unroll
-                    for (int db = 0; db < DB; db++)
+                    for (int db = 0; db < DB; db++) {
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {
                             typename X::v4 we, wo;
@@ -451,16 +516,8 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
                             const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
                             *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                         }
-                } else {
-#pragma unroll
-                    for (int db = 0; db < DB; db++)
-#pragma unroll
-                        for (int tq = 0; tq < 4; tq++) {
-                            typename X::v4 w;
-#pragma unroll
-                            for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][qc][4 * tq + e] * inv);
-                            *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
-                        }
+                        SCHED_FENCE();
+                    }
                 }
                 if (p.softmax_lse && g == 0) {
                     const float lse = (l_tot == 0.f) ? INFINITY : (m_log2 + __log2f(l_tot)) * 0.6931471805599453f;
@@ -480,109 +537,129 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
         __syncthreads();
     }
 
-    Piece cur, nx;
-    load_piece(q_idx, cur);
-    bool cold = true;
-    bool have_next = false;
     V8 kfa, kfb, kfc;
-    int t = 0;                                    // tile of `cur` whose scores the buffer of the coming step holds
-    int t_mask = 0;
-    float bx0 = 0.f, bx1 = 0.f;                   // row maxima of the tile scored by the last step
+    bool have_next = false;
 
-    // one piece boundary: the epilogue of `cur`, then `nx` becomes current (chained: its S'(tb) is in the score buffer and its tiles are
-    // in flight; else cold).  Returns false when the queue is empty.
-    for (;;) {
-        if (cold) {
-            // ---- cold start of `cur` (prefill64_kernel's prologue); the ring is drained and every wave is past its LDS reads ----
-            reset_acc();
-            nmsub[0] = nmsub[1] = 0.f;
-            t = cur.tb;
-            t_mask = t_mask_of(cur);
-            vs_cur = 0;
-            vs_dma = 2 * S::kTileBytes;
-            if (cur.nt > cur.tb) {
-                dma_k_all(cur, cur.tb, 0);
-                dma_v_all(cur, cur.tb, 0);
-                dma_k_all(cur, cur.tb + 1, 1);
-                q_from_global(cur);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                {
-                    const char* ksm = smem;
-#pragma unroll
-                    for (int f = 0; f < 2 * KK; f++) {
-                        const V8 a = kfrag(ksm, f);
-#pragma unroll
-                        for (int qc = 0; qc < 2; qc++) {
-                            if (f < 2) M::qk_first(sc[f & 1][qc], a, qf[qc][f >> 1]);
-                            else M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
-                        }
-                    }
-                    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-                    SCHED_FENCE();
-                    if (cur.tb >= t_mask) mask_tile(cur.tb, sc, cur.Lk, cur.q_wg0 + wave * 64 + cur.off);
-#pragma unroll
-                    for (int qc = 0; qc < 2; qc++) {
-                        const float mx = row_max(sc, qc);
-                        nmsub[qc] = (mx == -INFINITY) ? 0.f : -mx * escale;
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                dma_k_all(cur, cur.tb + 2, 0);
-                dma_v_all(cur, cur.tb + 1, 1);
-                k_rebase(cur.kbase, cur.tb + 2, cur.Lk);
-                v_rebase(cur.vbase, cur.tb + 1, cur.Lk);
-                kfa = kfrag(smem + KSLOT, 0);
-                kfb = kfrag(smem + KSLOT, 1);
-                kfc = kfrag(smem + KSLOT, 2);
-            }
-            cold = false;
-        }
-        // ---- the next piece of the queue: resolve it, start its Q block on its way to the staging area ----
+    // the mask scalars of piece `rec`, whose first tile is t
+    auto piece_scalars = [&](int rec) {
+        const int nt_true = PF(rec, F_NT);
+        t_mask = min(t_mask_of(rec), nt_true);                  // (tiles behind the piece's own are masked whole)
+        Lk_c = PF(rec, F_LK);
+        qoff_c = PF(rec, F_QWG0) + wave * 64 + PF(rec, F_OFF);
+        kend_c = nt_true * PF_BN;
+    };
+    // start of a piece: its step count; resolve the next piece of the queue and start its Q block on its way to the staging area
+    auto begin_piece = [&]() {
+        rem = max(PF(cur, F_NT) - t, 3);
         have_next = q_idx + 1 < q_end;
-        if (have_next) load_piece(q_idx + 1, nx);
-        // chain into it iff this piece has the three steps the re-base points need and the next one has a tile to score
-        const bool chain = have_next && (cur.nt - t >= 3) && (nx.nt > nx.tb);
-        if (chain) dma_q_stage(nx);
-        const int nt = cur.nt;
-        const int qoff_c = cur.q_wg0 + wave * 64 + cur.off, qoff_n = nx.q_wg0 + wave * 64 + nx.off;
-        const int t_mask_n = chain ? t_mask_of(nx) : 0;
-        bool odd = false;                          // the piece ended after an even-parity step: its successor's first step has odd parity
-        // ---- the tile steps of `cur`: even stream positions score into sd, odd ones into sc ----
-        // (a piece entered at odd parity — chained after an even-length run — takes its first step from sd)
-        bool done = !(t < nt);
-        while (!done) {
-            // even position
-            {
-                const bool last = t == nt - 1;
-                const Piece* kto = (chain && t == nt - 3) ? &nx : nullptr;
-                const Piece* vto = (chain && t == nt - 2) ? &nx : nullptr;
-                const bool seam = chain && last;
-                if (seam) q_from_stage();
-                const bool mnext = seam ? (nx.tb >= t_mask_n) : (t + 1 >= t_mask);
-                step(0, sc, sd, kfa, kfb, kfc, kto, vto, mnext, seam ? nx.tb : t + 1, seam ? nx.Lk : cur.Lk, seam ? qoff_n : qoff_c, seam, bx0, bx1);
-                t++;
-                if (last) { done = true; odd = true; break; }
-            }
-            {
-                const bool last = t == nt - 1;
-                const Piece* kto = (chain && t == nt - 3) ? &nx : nullptr;
-                const Piece* vto = (chain && t == nt - 2) ? &nx : nullptr;
-                const bool seam = chain && last;
-                if (seam) q_from_stage();
-                const bool mnext = seam ? (nx.tb >= t_mask_n) : (t + 1 >= t_mask);
-                step(1, sd, sc, kfa, kfb, kfc, kto, vto, mnext, seam ? nx.tb : t + 1, seam ? nx.Lk : cur.Lk, seam ? qoff_n : qoff_c, seam, bx0, bx1);
-                t++;
-                if (last) done = true;
+        rem_k = rem_v = rem_s = -1;
+        if (have_next) {
+            nx = load_piece(q_idx + 1);
+            rem_k = 3;
+            rem_v = 2;
+            rem_s = 1;
+            dma_q_stage(nx);
+        }
+    };
+    // one tile step at stream parity `par` (a literal): scores of tile t in `a`, S' of the following tile goes to `b`.  At the seam the
+    // next piece's Q block (whose DMA the previous step's vmcnt(0) waited for) moves into the fragment registers first, and the tile
+    // the step scores is the next piece's first: its mask scalars from here on (t is incremented inside the step).
+#define VATTN_STEP(par, a, b)                                                                                                       \
+    {                                                                                                                               \
+        const bool seam = rem == rem_s;                                                                                             \
+        if (__builtin_expect(seam, 0)) {                                                                                            \
+            q_from_stage();                                                                                                         \
+            t = PF(nx, F_TB) - 1;                                                                                                   \
+            piece_scalars(nx);                                                                                                      \
+        }                                                                                                                           \
+        step(par, a, b, kfa, kfb, kfc, seam);                                                                                       \
+    }
+    // end of a piece, after its last step: its epilogue; then the next piece is current — the stream goes on: S'(its first tile) sits in
+    // the score buffer the last step wrote, its next tiles are in flight, t and the mask scalars are its own since the seam
+#define VATTN_END_PIECE()                                                                                                           \
+    if (__builtin_expect(rem <= 0, 0)) {                                                                                            \
+        epilogue(cur);                                                                                                              \
+        if (!have_next) break;                                                                                                      \
+        q_idx++;                                                                                                                    \
+        cur = nx;                                                                                                                   \
+        reset_acc();                                                                                                                \
+        nmsub[0] = (bx0 == -INFINITY) ? 0.f : -bx0 * escale;      /* softmax.h: a fully masked row keeps a zero reference */        \
+        nmsub[1] = (bx1 == -INFINITY) ? 0.f : -bx1 * escale;                                                                        \
+        begin_piece();                                                                                                              \
+    }
+
+    // ---- cold start of the queue's first piece (prefill64_kernel's prologue) ----
+    reset_acc();
+    t = PF(cur, F_TB);
+    piece_scalars(cur);
+    dma_k_all(cur, t, 0);
+    dma_v_all(cur, t, 0);
+    dma_k_all(cur, t + 1, 1);
+    q_from_global(cur);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  // this wave's pieces of K(tb) landed; V(tb), K(tb+1) may still fly
+    __builtin_amdgcn_s_barrier();
+    {
+        const char* ksm = smem;
+#pragma unroll
+        for (int f = 0; f < 2 * KK; f++) {
+            const V8 a = kfrag(ksm, f);
+#pragma unroll
+            for (int qc = 0; qc < 2; qc++) {
+                if (f < 2) M::qk_first(sc[f & 1][qc], a, qf[qc][f >> 1]);
+                else M::qk_acc(sc[f & 1][qc], a, qf[qc][f >> 1]);
             }
         }
-        (void)odd;
-        break;
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        SCHED_FENCE();
+        if (t >= t_mask) mask_tile(t, sc, Lk_c, qoff_c, kend_c);
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) {
+            const float mx = row_max(sc, qc);
+            nmsub[qc] = (mx == -INFINITY) ? 0.f : -mx * escale;
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                     // also: every wave is done with K(tb) (the prologue's S')
+    dma_k_all(cur, t + 2, 0);
+    dma_v_all(cur, t + 1, 1);
+    k_rebase(PF64(cur, F_KB_LO), t + 2, Lk_c);                        // the running descriptors at step entry: K(t+2), V(t+1)
+    v_rebase(PF64(cur, F_VB_LO), t + 1, Lk_c);
+    kfa = kfrag(smem + KSLOT, 0);
+    kfb = kfrag(smem + KSLOT, 1);
+    kfc = kfrag(smem + KSLOT, 2);
+    begin_piece();
+
+    for (;;) {
+        VATTN_STEP(0, sc, sd)      // even stream position: scores in sc, S' of the following tile into sd
+        VATTN_END_PIECE()
+        VATTN_STEP(1, sd, sc)      // odd stream position
+        VATTN_END_PIECE()
+    }
+#undef VATTN_END_PIECE
+#undef VATTN_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // trailing DMA retired: nothing may land in the LDS of a later workgroup
 #undef P64_X0
 #undef P64_X1
-    (void)epilogue;
+#undef PF
+#undef PF64
+}
+
+void launch_prefill64p(const vattn_attn_params* p, hipStream_t st) {
+    if (p->dtype == VATTN_DTYPE_BF16) {
+        static const bool once = [] {
+            (void)hipFuncSetAttribute((const void*)prefill64p_kernel<__bf16, 24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64p);
+            return true;
+        }();
+        (void)once;
+        hipLaunchKernelGGL((prefill64p_kernel<__bf16, 24, 4>), dim3((unsigned)p->pf_num_wg), dim3(256), kSmem64p, st, *p);
+    } else {
+        static const bool once = [] {
+            (void)hipFuncSetAttribute((const void*)prefill64p_kernel<_Float16, 24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64p);
+            return true;
+        }();
+        (void)once;
+        hipLaunchKernelGGL((prefill64p_kernel<_Float16, 24, 4>), dim3((unsigned)p->pf_num_wg), dim3(256), kSmem64p, st, *p);
+    }
 }
 
 }  // namespace vattn_k

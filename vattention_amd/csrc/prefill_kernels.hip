@@ -581,7 +581,10 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
         if (p->pf_items) {        // host-planned work list: prefill64 pieces longest first, then the merge of the split blocks
             if (p->num_pf_items <= 0 || (p->num_pf_blocks > 0 && (!p->pf_blocks || !p->workspace)))
                 return fail(VATTN_K_ERR_INVALID, "pf_items needs num_pf_items, and pf_blocks + a workspace when blocks are split");
-            launch_prefill64(p, st, 1, nullptr, 0);
+            // grouped by workgroup (vattn_prefill_plan_wg): persistent workgroups, continuous tile stream (prefill64p_kernels.hip);
+            // the fused-RoPE form and outputs without 16-byte rows keep one workgroup per piece (the queue order is a valid list order)
+            if (p->pf_num_wg > 0 && !p->rotary_cos_sin && ((p->o_row_stride | p->o_head_stride | p->o_batch_stride) & 7) == 0) launch_prefill64p(p, st);
+            else launch_prefill64(p, st, 1, nullptr, 0);
             if (p->num_pf_blocks > 0) hipLaunchKernelGGL((combine_blocks_kernel<T, 128>), dim3((unsigned)p->num_pf_blocks * 64), dim3(256), 0, st, *p);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
@@ -638,12 +641,21 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
 // plan whose piece count lands just above a round of 256 — 280 pieces of a 2 k chunk on a 30 k prefix — costs 0.371 ms against 0.279 for
 // 256 pieces: pricing whole rounds is what the replay is for.]  Short key walks (no block of 96 tiles = 6 k keys) keep the default
 // launch: their time is prologue and merge, and the 4-wave tiling's smaller blocks do better there (2 k prompt, 32 heads: 0.071 vs 0.089).
+// wg_first != NULL: the PERSISTENT form (include/vattn_kernels.h, vattn_prefill_plan_wg; csrc/prefill64p_kernels.hip).  A piece that follows
+// another one in a workgroup's queue costs its epilogue and a fragment of a tile (2 half-tile units instead of 6), so finer cuts pay off
+// (pieces down to 8 tiles) and every list is worth having — also the balanced several-round grids, whose blocks then chain instead of
+// being dispatched one by one; the pieces are ASSIGNED here (longest first, each to the least loaded workgroup of its kv head's XCD
+// class) and come back grouped by workgroup.
 int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const int32_t* k_lens, vattn_prefill_item* items, int cap_items,
-                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts) {
+                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts, int32_t* wg_first, int max_wg) {
     if (!p || !k_lens || !items || !blocks || !counts || p->b <= 0 || p->h <= 0 || p->seqlen_q <= 0) return VATTN_K_ERR_INVALID;
     counts[0] = counts[1] = counts[2] = 0;
+    if (wg_first) counts[3] = 0;
     if (p->d != 128 || p->seqlen_q == 1) return 0;
-    const long kSlots = 256;                           // one prefill64 workgroup per CU
+    const bool persist = wg_first != nullptr;
+    const long kSlots = persist && max_wg > 0 && max_wg < 256 ? max_wg : 256;      // one prefill64 workgroup per CU
+    const long kOvh = persist ? 2 : 6;                 // per-piece overhead in half-tile units (chained / cold prologue)
+    const long kMinPiece = persist ? 8 : 12;           // pieces shorter than this are all overhead
     long W = 0, longest = 0, nblk = 0;
     auto tiles_of = [&](int e, int qb) -> long {
         const long sq = q_lens ? q_lens[e] : p->seqlen_q, lk = k_lens[e];
@@ -680,12 +692,13 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
         }
         ragged = lo != hi;
     }
-    if (W <= 0 || nblk <= 0 || (!forced_T && !ragged && longest < 48)) return 0;
+    if (W <= 0 || nblk <= 0 || (!forced_T && !ragged && !persist && longest < 48)) return 0;
+    if (persist && nblk > cap_items) return 0;
     const long avg = (W + kSlots - 1) / kSlots;
     // grids of several rounds of workgroups whose longest is no longer than ~a round's share are balanced by the dispatcher's
     // longest-first order already (and, when not ragged, keep the XCD-grouped grid order)
     const bool balanced = nblk >= 4 * kSlots || (nblk >= kSlots && longest * 4 <= avg * 5);
-    if (!forced_T && !ragged && balanced) return 0;
+    if (!forced_T && !ragged && balanced && !persist) return 0;
     auto price = [&](long T, long* pieces_out, long* rows_out) -> double {
         std::vector<long> cost;
         long rows = 0;
@@ -699,7 +712,7 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
                     long tb = s_ * per, te = tb + per;
                     if (tb > t) tb = t;
                     if (te > t) te = t;
-                    cost.push_back(2 * (te - tb) + 6 + (ns > 1 ? 3 : 0));        // half-tile units
+                    cost.push_back(2 * (te - tb) + kOvh + (ns > 1 ? 3 : 0));     // half-tile units
                 }
                 if (ns > 1) rows += 256 * ns;
             }
@@ -729,17 +742,18 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
         if (price(T, &pieces, &best_rows) >= 1e30 || pieces > cap_items) return 0;
     }
     bool search = !forced_T;
-    if (!forced_T && (balanced || longest < 48)) { T = longest; search = false; }      // (ragged:) nothing to cut, only to compact
+    if (!forced_T && !persist && (balanced || longest < 48)) { T = longest; search = false; }      // (ragged:) nothing to cut, only to compact
+    if (!forced_T && persist && nblk >= 4 * kSlots) { T = longest; search = false; }               // several rounds of blocks: the assignment balances them
     for (long ns_max : kShares) {
         if (!search) break;
         const long t_c = (longest + ns_max - 1) / ns_max;
-        if (t_c < 12 && ns_max > 1) break;             // pieces shorter than ~12 tiles are all prologue
+        if (t_c < kMinPiece && ns_max > 1) break;      // pieces shorter than ~12 tiles are all prologue
         long pieces = 0, rows = 0;
         const double c = price(t_c, &pieces, &rows);
         if (pieces > cap_items) continue;
         if (c < best - 1e-9) { best = c; T = t_c; best_rows = rows; }
     }
-    if (T == 0 || (!forced_T && !ragged && T >= longest)) return 0;      // nothing worth cutting, nothing to compact: the default launch
+    if (T == 0 || (!forced_T && !ragged && !persist && T >= longest)) return 0;      // nothing worth cutting, nothing to compact: the default launch
     if (best_rows > 0x7fffffffL - 4096) return 0;
     int n = 0, nb = 0;
     long part_rows = 0;
@@ -783,11 +797,45 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
     // The list is a PERFORMANCE hint, never a statement about the data: the last share of every query block is open-ended (the kernel
     // clamps every range to the tiles the block really sees, computed from the device-side lengths), so a caller whose host-side lengths
     // are stale gets the right result at a worse balance instead of dropped keys.
-    for (int i = 0; i < n; i++)
+    std::vector<long> piece_tiles(n);
+    for (int i = 0; i < n; i++) {
+        piece_tiles[i] = (long)items[i].tile_end - items[i].tile_begin;
         if (items[i].reserved) items[i].tile_end = 0x7fffffff;
+    }
     counts[0] = n;
     counts[1] = nb;
     counts[2] = (int32_t)part_rows;
+    if (persist) {
+        // ---- assignment: at most kSlots workgroups; workgroup w runs on XCD w % 8 (a grid of at most one workgroup per CU is handed out
+        // round-robin), and an XCD's L2 should keep seeing ONE kv head: the pieces of kv head hk go to the workgroups of class
+        // hk % ncls, ncls = the kv heads when they divide the 8 XCDs.  Longest first, each to the least loaded workgroup of its class. ----
+        long nwg = n < kSlots ? n : kSlots;
+        if (nwg >= 8) nwg -= nwg % 8;
+        const int G = p->h / p->h_k;
+        const int ncls = (nwg >= 8 && p->h_k <= 8 && 8 % p->h_k == 0) ? p->h_k : 1;
+        typedef std::pair<long, int> LW;                                        // (load in half-tile units, workgroup)
+        std::vector<std::priority_queue<LW, std::vector<LW>, std::greater<LW>>> heaps(ncls);
+        for (int w = 0; w < nwg; w++) heaps[(w % 8) % ncls].push(LW(4, w));     // every queue starts cold: + 4 over the chained overhead
+        std::vector<int> owner(n);
+        std::vector<int> fill(nwg + 1, 0);
+        for (int i = 0; i < n; i++) {
+            const long tiles = piece_tiles[i];
+            auto& hp = heaps[(items[i].h / G) % ncls];
+            LW top = hp.top();
+            hp.pop();
+            owner[i] = top.second;
+            fill[top.second + 1]++;
+            top.first += 2 * tiles + kOvh + (items[i].nshares > 1 ? 3 : 0);
+            hp.push(top);
+        }
+        for (int w = 0; w < nwg; w++) fill[w + 1] += fill[w];
+        std::vector<vattn_prefill_item> grouped(n);
+        std::vector<int> pos(fill.begin(), fill.end() - 1);
+        for (int i = 0; i < n; i++) grouped[pos[owner[i]]++] = items[i];        // stable: a queue keeps the longest-first order
+        for (int i = 0; i < n; i++) items[i] = grouped[i];
+        for (int w = 0; w <= nwg; w++) wg_first[w] = fill[w];
+        counts[3] = (int32_t)nwg;
+    }
     return n;
 }
 
@@ -802,7 +850,7 @@ void prefill_describe(const vattn_attn_params* p, vattn_plan_desc* out) {
     if (p->pf_items && p->d == 128) {
         out->path = 1;
         out->tiling = 7;
-        out->workgroups = p->num_pf_items;
+        out->workgroups = p->pf_num_wg > 0 && !p->rotary_cos_sin && ((p->o_row_stride | p->o_head_stride | p->o_batch_stride) & 7) == 0 ? p->pf_num_wg : p->num_pf_items;
         out->merge_launch = p->num_pf_blocks > 0;
         return;
     }

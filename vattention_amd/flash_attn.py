@@ -352,10 +352,10 @@ class _PrefillPlan:
     """Device tables of a prefill work list (vattn_prefill_plan) — or the fact that the default launch is as good (tables None).  Built
     from host-side lengths only, so the attention wrapper builds it for layer 0 of an iteration and hands the same object to the
     other layers' calls (`_pf_plan`)."""
-    __slots__ = ("t", "n_items", "n_blocks", "part_rows")
+    __slots__ = ("t", "n_items", "n_blocks", "part_rows", "n_wg")
 
-    def __init__(self, t=None, n_items=0, n_blocks=0, part_rows=0):
-        self.t, self.n_items, self.n_blocks, self.part_rows = t, n_items, n_blocks, part_rows
+    def __init__(self, t=None, n_items=0, n_blocks=0, part_rows=0, n_wg=0):
+        self.t, self.n_items, self.n_blocks, self.part_rows, self.n_wg = t, n_items, n_blocks, part_rows, n_wg
 
     def attach(self, p):
         if self.t is not None:
@@ -363,17 +363,30 @@ class _PrefillPlan:
             p.pf_items, p.num_pf_items = base, self.n_items
             p.pf_blocks, p.num_pf_blocks = (base + 32 * self.n_items if self.n_blocks else None), self.n_blocks
             p.pf_part_rows = self.part_rows
+            # persistent form (vattn_prefill_plan_wg): the pieces are grouped by workgroup, the offsets follow the two tables
+            p.pf_num_wg = self.n_wg
+            p.pf_wg_first = base + 32 * (self.n_items + self.n_blocks) if self.n_wg else None
 
 
-def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0) -> _PrefillPlan:
+PERSISTENT = True          # work lists are assigned to persistent workgroups (csrc/prefill64p_kernels.hip); False: one workgroup per piece (A/B, tests)
+PERSISTENT_MAX_BLOCKS = 2048      # (entry, head, query block) triples up to which a launch gets a list at all in the persistent form
+
+
+def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0, persistent=None, max_wg: int = 0) -> _PrefillPlan:
     """q_lens_host: chunk length per entry (None: p.seqlen_q for all); k_lens_host: visible keys per entry; force_tiles: pieces of at
-    most this many 64-key tiles whatever the planner's own rules say (tests, A/B)."""
+    most this many 64-key tiles whatever the planner's own rules say (tests, A/B); persistent: None = the module default; max_wg: at
+    most this many persistent workgroups (0: one per CU)."""
     B = p.b
+    persist = PERSISTENT if persistent is None else bool(persistent)
+    if p.rotary_cos_sin or (p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7:
+        persist = False          # (the persistent kernel has neither the fused-RoPE form nor the 8-byte store path)
     q_of = q_lens_host if q_lens_host is not None else [p.seqlen_q] * B
     n_blk = sum((int(q) + 255) // 256 for q in q_of) * p.h          # (entry, head, 256-row query block) triples
     cap_i, cap_b = 17 * n_blk + 16, n_blk + 16
     ragged = q_lens_host is not None and len({(int(q) + 255) // 256 for q in q_lens_host}) > 1
-    if n_blk > 4 * 256 + 64 and not force_tiles and not ragged:      # (the planner keeps the default launch for balanced grids of several rounds)
+    if persist and n_blk > PERSISTENT_MAX_BLOCKS and not force_tiles and not ragged:
+        return _PrefillPlan()
+    if not persist and n_blk > 4 * 256 + 64 and not force_tiles and not ragged:      # (the planner keeps the default launch for balanced grids of several rounds)
         return _PrefillPlan()
     items, blocks = (K.PrefillItem * cap_i)(), (K.PrefillItem * cap_b)()
     counts = (C.c_int32 * 3)()
@@ -382,19 +395,27 @@ def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0) -> _Pre
     keep_ns = p.num_splits
     if force_tiles:
         p.num_splits = -int(force_tiles)
-    n = K.klib().vattn_prefill_plan(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, counts)
+    if persist:
+        counts = (C.c_int32 * 4)()
+        wg_first = (C.c_int32 * 257)()
+        n = K.klib().vattn_prefill_plan_wg(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, wg_first, int(max_wg), counts)
+    else:
+        n = K.klib().vattn_prefill_plan(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, counts)
     p.num_splits = keep_ns
     if n < 0:
         raise RuntimeError("vattn_prefill_plan: bad arguments")
     if n == 0:
         return _PrefillPlan()
     nb = int(counts[1])
+    nwg = int(counts[3]) if persist else 0
 
     def fill(dst):
         C.memmove(dst, items, 32 * n)
         if nb:
             C.memmove(dst + 32 * n, blocks, 32 * nb)
-    return _PrefillPlan(_Staging.upload(32 * (n + nb), fill, dev), n, nb, int(counts[2]))
+        if nwg:
+            C.memmove(dst + 32 * (n + nb), wg_first, 4 * (nwg + 1))
+    return _PrefillPlan(_Staging.upload(32 * (n + nb) + (4 * (nwg + 1) if nwg else 0), fill, dev), n, nb, int(counts[2]), nwg)
 
 
 def _decode_plan(p, lens_host, dev):

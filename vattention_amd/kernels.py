@@ -10,7 +10,7 @@ from . import _lib as L
 vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
 
 
-ABI_VERSION = 4      # VATTN_KERNELS_ABI of include/vattn_kernels.h
+ABI_VERSION = 5      # VATTN_KERNELS_ABI of include/vattn_kernels.h
 
 
 class AttnParams(C.Structure):
@@ -32,7 +32,7 @@ class AttnParams(C.Structure):
         ("max_seqlen_k_hint", i32),
         ("rotary_cos_sin", vp), ("rotary_row_stride", i64), ("rotary_dim", i32), ("rotary_reserved", i32),
         ("split_items", vp), ("split_seq", vp), ("num_split_items", i32), ("split_reserved", i32),
-        ("pf_items", vp), ("pf_blocks", vp), ("num_pf_items", i32), ("num_pf_blocks", i32), ("pf_part_rows", i32), ("pf_reserved", i32),
+        ("pf_items", vp), ("pf_blocks", vp), ("num_pf_items", i32), ("num_pf_blocks", i32), ("pf_part_rows", i32), ("pf_num_wg", i32), ("pf_wg_first", vp),
     ]
 
 
@@ -91,6 +91,9 @@ def _bind(lib):
     lib.vattn_prefill_plan.restype = i32
     lib.vattn_prefill_plan.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(i32), C.POINTER(PrefillItem), i32, C.POINTER(PrefillItem), i32,
                                        C.POINTER(i32)]
+    lib.vattn_prefill_plan_wg.restype = i32
+    lib.vattn_prefill_plan_wg.argtypes = [C.POINTER(AttnParams), C.POINTER(i32), C.POINTER(i32), C.POINTER(PrefillItem), i32, C.POINTER(PrefillItem), i32,
+                                          C.POINTER(i32), i32, C.POINTER(i32)]
     lib.vattn_attn_plan_describe.restype = i32
     lib.vattn_attn_plan_describe.argtypes = [C.POINTER(AttnParams), C.POINTER(PlanDesc)]
     lib.vattn_decode_plan.restype = i32
