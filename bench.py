@@ -35,9 +35,14 @@ Every line (every N, static or dynamic) carries:
   `cpu_baseline`      the CPU oracle (kind "port": oracle/attn.py, the reference kernel's numerics in torch fp32) timed on a bounded
                       sample of THIS workload's per-rank shapes on the host cores, scaled to the whole job by the counted
                       (query row, visible key) pairs of the timed steps.
+  `clock_mhz_mean` / `power_w_mean`  shader clock and board power sampled over the timed region by a side process
+                      (vattention_amd/telemetry.py): a power-capped MI355X runs this kernel between ~1.5 and 2.4 GHz, boxes differ.
 N = 1 adds, outside the timed region: `cold_wave`, `full_trace_50req`, `dynamic` (configs[2] shape, closed loop, time-weighted KV
 utilisation), `dynamic_tp8_rank` (the TP8 rank shape: 256 sequences resident at full depth, deferred reclamation on / off),
-`open_loop` (Poisson arrivals at qps = 6 on a virtual clock), `capacity` (grow until the reference's OOM error).
+`c4_rank_share_128k` (ONE rank's share of configs[3]'s 128 k request: Yi-34B TP2 heads, 16 k chunks — the metric's 128 k half on one
+GPU), `hybrid_sarathi` (Sarathi-scheduled hybrid batches: serial order vs prefill || decode on two streams), `open_loop` (Poisson
+arrivals at qps = 6 on a virtual clock), `capacity` (grow until the reference's OOM error).  `cpu_baseline.bookkeeping`: the
+reference's own allocator (oracle/_ref) beside this manager on one engine-shaped call sequence, driver calls free.
 """
 from __future__ import annotations
 
@@ -149,6 +154,21 @@ def cpu_baseline(dtype, L, Hq, Hkv, D, keys, world, tokens, prefill_pairs, decod
                       "pairs of the timed steps) = %.0f s of CPU time for %d tokens" % (
                           r["cores"], what, Hq, Hkv, D, r["rows"], r["keys"], r["t_prefill_sample"], r["prefill_head_pairs_per_s"], r["keys"],
                           r["t_decode_sample"], r["decode_head_pairs_per_s"], world, L, Hq, prefill_pairs, decode_pairs, t_job, tokens)}
+
+
+def bookkeeping_baseline() -> dict:
+    """SURVEY §8(d), bookkeeping half: microseconds per step_async of the REFERENCE's allocator (oracle/_ref = vattention.cu compiled
+    against a fake CUDA driver, kind "reference") and of this package's page manager (fake physical backend), same concrete call
+    sequence of an engine-shaped trace at configs[1]'s geometry, all driver calls free, one host thread.  ~1 s of CPU."""
+    try:
+        from tools import pagemgr_steps_bench as B
+        m = B.measure(iters=300)
+        ref, here = m.get("reference_us_per_step_async"), m.get("this_manager_inline_us_per_step_async")
+        m.update({"kind": "reference" if ref else "port", "cores": 1, "unit": "us per step_async (driver calls free)",
+                  "reference_over_this": round(ref / here, 2) if ref and here else None})
+        return m
+    except Exception as e:      # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def rooflines(detail: dict, traffic=None) -> dict:
@@ -272,6 +292,7 @@ def main():
         return
 
     runner = make_runner(w["model"], w["tp"], w["ctx"], w["page"], w["batch"], w["backend"], mem_for_kv, a.layers)
+    pool_ready_s = round(vattention.pool_ready_seconds, 3)      # reserve_physical_pages waited this long for the handles created ahead of demand
     Hq, Hkv, D, L = runner.Hq, runner.Hkv, runner.D, runner.L
     lengths = cap(lengths256, w["decode_cap"]) if w["mode"] == "dynamic" and w.get("decode_cap") else lengths256
 
@@ -335,13 +356,17 @@ def main():
     vm0 = vattention.stats()
     pairs["pf"] = pairs["dc"] = 0.0
     enable_op_timers(True, every=TIMER_EVERY[w["mode"]])      # HIP events on the launch stream, inside the timed region
+    from vattention_amd.telemetry import Sampler
+    sampler = Sampler(local, 0.1).__enter__() if rank == 0 else None      # a side process: shader clock and board power
     barrier()
+    wall0 = time.time()
     t0 = time.perf_counter()
     tokens = 0
     for _ in range(a.steps):
         tokens += one_step()
     barrier()
     dt = time.perf_counter() - t0
+    telemetry = sampler.window(wall0, time.time()) if sampler is not None else None
     detail = drain_op_timers_detail()
     enable_op_timers(False)
     vm1 = vattention.stats()
@@ -421,6 +446,8 @@ def main():
         leg("dynamic_tp8_rank", dynamic_leg, make_runner, mem_for_kv, cap(lengths256, 768), "llama-3-70b", 8,
             "one TP=8 rank of configs[4]: llama-3-70b, 8/1 heads, 80 layers (40 KB of KV per token: 256 sequences fit at full depth); decode "
             "lengths capped at 768", True, dtype, False)
+        leg("c4_rank_share_128k", c4_rank_share_leg, make_runner, mem_for_kv)
+        leg("hybrid_sarathi", hybrid_sarathi_leg, make_runner, mem_for_kv)
         leg("open_loop", open_loop_leg, make_runner, mem_for_kv, lengths256, 6.0, 256)
         leg("capacity", capacity_leg, dev, mem_for_kv)
 
@@ -453,7 +480,12 @@ def main():
                              "async_ms": round((vm1["async_ns"] - vm0["async_ns"]) / 1e6, 3),
                              "join_wait_ms": round((vm1["join_wait_ns"] - vm0["join_wait_ns"]) / 1e6, 3)},
             "op_ms": op_ms,
+            "pool_ready_s": pool_ready_s,
         }
+        if telemetry is not None:
+            out["clock_mhz_mean"] = telemetry.get("clock_mhz_mean")
+            out["power_w_mean"] = telemetry.get("power_w_mean")
+            out["telemetry"] = telemetry
         out.update(roofs)
         if "roofline" in out:
             # BOTH kernels' rooflines inside the object the driver keeps (`roofline`): the north_star's two bars — decode vs the HBM
@@ -473,6 +505,10 @@ def main():
                         other["%s_%s_frac" % (leg, kern)] = fr_w
                     if fr_c is not None:
                         other["%s_%s_frac_cold_pool" % (leg, kern)] = fr_c
+            e128 = extras.get("c4_rank_share_128k") or {}
+            if e128.get("prefill_frac") is not None:
+                other["c4_rank_share_128k_prefill_frac"] = e128.get("prefill_frac")
+                other["c4_rank_share_128k_decode_frac"] = e128.get("decode_frac")
             out["roofline"]["other"] = other
         if cold:
             out["cold_wave"] = cold
@@ -493,6 +529,7 @@ def main():
                                                    "configs[%d]" % {1: 1, 2: 3, 4: 3, 8: 4}[shard_of])
             except Exception as e:      # noqa: BLE001  (the line is printed either way)
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["cpu_baseline"]["bookkeeping"] = bookkeeping_baseline()
         # stdout carries ONE line, the bench line the contract asks for — compact, so that whoever reads the tail of stdout sees a whole
         # line: the contract's fields, `roofline` (with both kernels and the dynamic legs' fractions under `other`), `cpu_baseline`, and
         # a digest of the legs.  The details (every leg in full: tens of kilobytes) go to stderr as one {"details": ...} line.
@@ -521,6 +558,11 @@ def main():
                             "create_ms_on_critical_path": g(e, "handle_creation", "on_critical_path_ms"), "error": e.get("error")}
         if extras.get("full_trace_50req"):
             dig["full_trace_50req_tokens_per_s"] = extras["full_trace_50req"].get("tokens_per_s")
+        if extras.get("c4_rank_share_128k"):
+            dig["c4_rank_share_128k"] = {k: extras["c4_rank_share_128k"].get(k) for k in ("tokens_per_s", "seconds", "prefill_frac", "decode_frac", "kv_live_over_mapped_mean", "error")}
+        if extras.get("hybrid_sarathi"):
+            dig["hybrid_sarathi"] = {k: extras["hybrid_sarathi"].get(k) for k in ("tokens_per_s_serial", "tokens_per_s_streams", "streams_over_serial", "hybrid_iterations",
+                                                                                  "overlapped_iterations", "error")}
         if extras.get("open_loop"):
             dig["open_loop_qps6"] = {k: extras["open_loop"].get(k) for k in ("request_e2e_time_normalized_p50", "request_e2e_time_normalized_p99", "sync_map_ms_per_step_p99")}
         if extras.get("capacity"):
@@ -541,6 +583,7 @@ def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, 
 
     def run(deferred: bool, warm_pass: bool = False):
         r = make_runner(model, tp, 32768, 8 << 20, 256, "fa_vattn_megacache", mem_for_kv)
+        ready_s = round(vattention.pool_ready_seconds, 3)
         try:
             if not deferred:
                 r.engine.disable_deferred_reclamation()
@@ -550,6 +593,7 @@ def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, 
             det = drain_op_timers_detail()
             enable_op_timers(False)
             out["_stats"] = (r.stats.prefill_pairs, r.stats.decode_pairs, r.L, r.Hq, r.Hkv, r.D)
+            out["_pool_ready_s"] = ready_s
             out["_roof"] = rooflines(det)
             if warm_pass:
                 # the SAME replay again on the now-warm pool (every handle exists, finished slots kept their pages): what the cold
@@ -578,7 +622,8 @@ def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, 
              "kv_live_over_needed_at_peak": out["kv_live_over_needed_at_peak"],
              "kv_live_over_mapped_mean_per_iteration": round(out["kv_live_over_mapped_mean"], 4),
              "kv_util_time_weighted": out.get("kv_util_time_weighted"),
-             "external_fragmentation": 0.0, "map_calls": out["map_calls"], "unmap_calls": out["unmap_calls"],
+             "external_fragmentation": out.get("external_fragmentation_max"), "external_fragmentation_samples": out.get("external_fragmentation_samples"),
+             "map_calls": out["map_calls"], "unmap_calls": out["unmap_calls"],
              "handles_created": out.get("handles_created"), "create_ms": out.get("create_ms"),
              "sync_map_ms": round(sync_calls_ms, 1), "sync_fence_wait_ms": round(fence_ms, 1),
              "mapper_thread_map_ms": round(out["async_map_ms"], 1),
@@ -590,8 +635,12 @@ def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, 
 
     first = run(True, warm_pass=True)
     res = {"workload": what + "; 256 arxiv-length requests (tests/golden/c3_arxiv_lengths_256.json) closed loop, vLLM scheduler, max_batch_size 256, "
-                              "megacache 8 MiB pages, pool = 0.9 x HBM - 12 GiB, cold pool"}
+                              "megacache 8 MiB pages, pool = 0.9 x HBM - 12 GiB; first pass on a fresh pool whose handles were created inside "
+                              "reserve_physical_pages (pool_ready_s), second pass warm"}
     res.update(digest(first))
+    # the pool's handles exist before the first admission (vattention.reserve_physical_pages waits for the mapper thread: what the
+    # reference's reserve commits, cudaInternal.h:45-59); "cold" below = the first pass on that fresh pool, "warm" = the second pass
+    res["pool_ready_s"] = first.get("_pool_ready_s")
     warm = digest(first["_warm"])
     sbw = first["_warm"].get("sync_breakdown") or {}
     sbc = first.get("sync_breakdown") or {}
@@ -610,6 +659,84 @@ def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, 
                                                                   "kv_live_over_mapped_mean_per_iteration", "map_calls", "unmap_calls",
                                                                   "sync_map_ms", "sync_fence_wait_ms", "mapper_thread_map_ms")}
     return res
+
+
+def c4_rank_share_leg(make_runner, mem_for_kv) -> dict:
+    """The 128 k half of BASELINE.json's metric on ONE GPU: one rank's share of configs[3] (Yi-34B TP = 2: 28 query / 4 kv heads, 60
+    layers, 2 MiB pages), static trace @ 131 072 ctx, P:D = 500, Sarathi 16 k chunks (scripts/benchmark_e2e_static_trace.py:6-57,
+    artifact_asplos25/run_figure_6.sh:32-33), ONE request end to end: 8 prefill chunks against a growing prefix, then 262 decode steps
+    of the single sequence.  The same code path as `bench.py --gpus 2` minus the control-plane exchange; a tensor-parallel job's
+    tokens/s equals one rank's (every rank processes the same tokens with its head shard)."""
+    import torch
+    from vattention_amd import vattention
+    from vattention_amd.attention.timers import drain_op_timers_detail, enable_op_timers
+    r = make_runner("yi-34b", 2, 131072, 2 << 20, 4, "fa_vattn", mem_for_kv)
+    try:
+        r.run_static_trace(1, 16384, 500.0, 16384)                   # warm-up: one 16 k request (kernels, plans, first handles)
+        torch.cuda.synchronize()
+        r.stats.__init__()
+        enable_op_timers(True, every=1)
+        t0 = time.perf_counter()
+        r.run_static_trace(1, 131072, 500.0, 16384)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        det = drain_op_timers_detail()
+        enable_op_timers(False)
+        roofs = rooflines(det)
+        tk = r.stats.prefill_tokens + r.stats.decode_tokens
+        u = r.stats.kv_util_samples
+        return {"workload": "one TP=2 rank's share of configs[3]: yi-34b (28/4 heads per rank, 60 layers), 2 MiB pages, static trace @ 131072 ctx, P:D=500, "
+                            "Sarathi 16 k chunks, ONE request (130810 prefill + 262 decode tokens)",
+                "tokens": tk, "seconds": round(dt, 3), "tokens_per_s": round(tk / dt, 1),
+                "prefill_frac": (roofs.get("roofline_prefill") or {}).get("frac"), "decode_frac": (roofs.get("roofline_decode") or {}).get("frac"),
+                "roofline_prefill": roofs.get("roofline_prefill"), "roofline_decode": roofs.get("roofline_decode"),
+                "kv_live_over_mapped_mean": round(sum(u) / max(1, len(u)), 4), "kv_live_over_mapped_min": round(min(u), 4) if u else None,
+                "external_fragmentation": r.stats.ext_frag_max}
+    finally:
+        r.close()
+
+
+def hybrid_sarathi_leg(make_runner, mem_for_kv) -> dict:
+    """SURVEY §8 f1 on the reference's own scheduler shape (vattention_flashattention_pod_wrapper.py:121-203, pod_attn/tests/
+    attn_sweep.py:82-97): Yi-6B, 64 requests of 8 192 tokens (P:D = 15: 7 680 prefill + 512 decode), Sarathi 4 k chunks — every prefill
+    chunk rides with the decode batch of the sequences already running (up to 63).  The SAME trace twice: backend fa_vattn (prefill
+    launch, then decode launch) and fa_streams (this package's hybrid policy: decode on a side stream beside an unsplit prefill when
+    a host-side estimate says so).  A fused prefill || decode launch does not exist in the product (three measured designs lose to
+    the serial order)."""
+    import torch
+    out = {"workload": "yi-6b TP=1, 64 requests x 8192 tokens (7680 prefill + 512 decode), Sarathi 4096-token chunks with piggy-backed decodes, 32 layers"}
+    for name, backend in (("serial", "fa_vattn"), ("streams", "fa_streams")):
+        r = make_runner("yi-6b", 1, 8192, 2 << 20, 64, backend, min(mem_for_kv, 40 << 30))
+        try:
+            r.run_static_trace(2, 8192, 15.0, 4096)                      # warm-up
+            torch.cuda.synchronize()
+            r.stats.__init__()
+            hyb = {"n": 0, "ov": 0}
+            wr = r.wrapper
+            if hasattr(wr, "_plan_overlap"):
+                orig = wr._plan_overlap
+
+                def counted(orig=orig):
+                    v = orig()
+                    hyb["n"] += bool(wr.prefill_query_lens and wr.decode_batch_size)
+                    hyb["ov"] += bool(v)
+                    return v
+                wr._plan_overlap = counted
+            t0 = time.perf_counter()
+            r.run_static_trace(64, 8192, 15.0, 4096)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tk = r.stats.prefill_tokens + r.stats.decode_tokens
+            out["tokens_per_s_" + name] = round(tk / dt, 1)
+            out["seconds_" + name] = round(dt, 3)
+            out["iterations_" + name] = r.stats.iterations
+            if name == "streams":
+                out["hybrid_iterations"], out["overlapped_iterations"] = hyb["n"], hyb["ov"]
+                wr._plan_overlap = orig
+        finally:
+            r.close()
+    out["streams_over_serial"] = round(out["tokens_per_s_streams"] / out["tokens_per_s_serial"], 4)
+    return out
 
 
 def open_loop_leg(make_runner, mem_for_kv, lengths, qps, requests) -> dict:

@@ -187,9 +187,11 @@ def test_prefill_work_list_matches_the_oracle(Hq, Hkv, chunks, dtype):
     # (launches this small keep the default plan on their own: pieces of at most 9 tiles are forced, as a long prompt would get)
     plan = FA.prefill_plan(p, q_lens, k_lens, torch.device(DEV), force_tiles=9)
     assert plan.t is not None and plan.n_items > 0 and plan.n_blocks > 0, "no work list"
-    natural = FA.prefill_plan(p, q_lens, k_lens, torch.device(DEV))      # the planner's own choice: a compact, uncut list for ragged batches
+    natural = FA.prefill_plan(p, q_lens, k_lens, torch.device(DEV))      # the planner's own choice: always a list for ragged batches (valid blocks only)
     if P > 1 and len({(n + 255) // 256 for n in q_lens}) > 1:
-        assert natural.t is not None and natural.n_blocks == 0 and natural.n_items == sum((n + 255) // 256 for n in q_lens) * Hq
+        assert natural.t is not None and natural.n_items >= sum((n + 255) // 256 for n in q_lens) * Hq
+        per_piece = FA.prefill_plan(p, q_lens, k_lens, torch.device(DEV), persistent=False)      # one workgroup per piece: compact and uncut
+        assert per_piece.t is not None and per_piece.n_blocks == 0 and per_piece.n_items == sum((n + 255) // 256 for n in q_lens) * Hq
     outs = []
     for pl in (plan, None) + ((natural,) if natural.t is not None else ()):
         out = torch.full((T, Hq, D), float("nan"), dtype=dtype, device=DEV)

@@ -50,6 +50,32 @@ def run(impl, ops):
     return time.perf_counter() - t0, t_step, n_step, errs
 
 
+def measure(geom="configs[1] yi-6b TP1, 2 MiB pages", iters=400):
+    """One geometry, as a dict (bench.py's cpu_baseline.bookkeeping): microseconds inside a step_async call for the reference's
+    allocator (oracle/_ref, None when it is not built) and for this package's manager, same concrete call sequence, driver calls free."""
+    cfg = GEOMS[geom]
+    tr = T.gen_serving_trace(cfg, 7, iters=iters, pool_groups=pool_groups(cfg), use_async=True, max_new_per_iter=2, chunk=0, p_finish=0.01)
+    ops = T.resolve(tr, T.OracleImpl)
+    recs = T.replay(T.OracleImpl(cfg), ops)
+    ops = T.truncate_for_reference(ops, recs)
+    out = {"geometry": geom, "engine_iterations": iters, "ops": len(ops), "step_async_calls": sum(1 for o in ops if o[0] in ("step", "step_async")),
+           "reference_us_per_step_async": None}
+    if ref_adapter.available():
+        r = ref_adapter.RefImpl(cfg)
+        r.lib.fakecuda_enable_log(0)
+        sec, t_step, n, _ = run(r, ops)
+        r.lib.fakecuda_enable_log(1)
+        out["reference_us_per_step_async"] = round(1e6 * t_step / max(n, 1), 2)
+    for flags, key in ((4, "this_manager_inline_us_per_step_async"), (0, "this_manager_mapper_thread_us_per_step_async")):
+        p = ProductImpl(cfg, flags=flags)
+        fake().vattn_fake_set_validate(0)
+        sec, t_step, n, _ = run(p, ops)
+        p.pm.close()
+        out[key] = round(1e6 * t_step / max(n, 1), 2)
+    fake().vattn_fake_set_validate(1)
+    return out
+
+
 def main():
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 400
     print("# allocator steps/s with free driver calls, %d engine iterations per trace, %d host cores" % (iters, os.cpu_count()))

@@ -347,6 +347,20 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
         asm volatile("s_mov_b32 s96, %1\n\ts_and_b32 s97, %2, 0xffff\n\ts_mov_b32 s98, %3\n\ts_mov_b32 s99, 0x00020000"
                      : "=&{s[96:99]}"(rv) : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(bnd) : "scc");
     };
+    // one tile before tile t of a piece, so that the step's own advance lands on tile t (the previous fetch through the descriptor was issued
+    // a step ago; the descriptor is not read again before that advance)
+    auto k_prebase = [&](unsigned long long base, int t, int Lk_) {
+        const unsigned long long a = base + (unsigned long long)t * k_tile_b - k_tile_b;
+        k_rows_left = Lk_ - t * PF_BN + PF_BN;
+        asm volatile("s_mov_b32 s92, %1\n\ts_and_b32 s93, %2, 0xffff\n\ts_mov_b32 s94, 0\n\ts_mov_b32 s95, 0x00020000"
+                     : "=&{s[92:95]}"(rk) : "s"((unsigned)a), "s"((unsigned)(a >> 32)) : "scc");
+    };
+    auto v_prebase = [&](unsigned long long base, int t, int Lk_) {
+        const unsigned long long a = base + (unsigned long long)t * v_tile_b - v_tile_b;
+        v_rows_left = Lk_ - t * PF_BN + PF_BN;
+        asm volatile("s_mov_b32 s96, %1\n\ts_and_b32 s97, %2, 0xffff\n\ts_mov_b32 s98, 0\n\ts_mov_b32 s99, 0x00020000"
+                     : "=&{s[96:99]}"(rv) : "s"((unsigned)a), "s"((unsigned)(a >> 32)) : "scc");
+    };
     unsigned vs_cur = 0, vs_dma = 2 * S::kTileBytes;
 
     // ---- the scalars of the steady state: tile t of `cur` (whose scores the coming step turns into probabilities), rem = its steps still
@@ -358,12 +372,14 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
     int cur = load_piece(q_idx), nx = 0;          // lane records (load_piece)
     int t = 0, rem = 0, t_mask = 0, Lk_c = 0, qoff_c = 0, kend_c = 0;
     int rem_k = -1, rem_v = -1, rem_s = -1;
-    float bx0 = 0.f, bx1 = 0.f;                   // row maxima of the tile scored by the last step (after masking)
+    float bx0 = 0.f, bx1 = 0.f;                   // row maxima of the tile a seam scored (after masking)
+    bool seam_now = false;                        // the step in flight scores the NEXT piece's first tile
 
-    // What a step does besides prefill64_kernel's: at rem == rem_k / rem_v it points the K / V descriptor at the first tile of the next
-    // piece instead of moving it one tile on; `seam` (rem == rem_s on entry): the tile it scores opens the next piece — that piece's
-    // mask parameters, and no max-growth test against the finished piece's reference.
-    auto step = [&](const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2, const bool seam) {
+    // The step is prefill64_kernel's but for three things: the piece's counters move inside a gap, the row maxima of the tile scored are
+    // left where a seam can take them, and a seam's max-growth test is void.  The re-base of the K / V descriptors costs the step
+    // nothing: the glue in front of a re-base step sets the descriptor to ONE TILE BEFORE the next piece's first tile, and the step's
+    // ordinary one-tile move (groups 21 / 23) lands on it.
+    auto step = [&](const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2) {
         const int s_cur = par;
         const char* ksm = smem + (s_cur ^ 1) * KSLOT;
         const char* ksm_next = smem + s_cur * KSLOT;
@@ -389,14 +405,9 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
             if (i == 17) lv0 = v_lds_wave + vs_dma;
             if (i == 19) asm volatile("s_mov_b32 %1, %0\n\ts_add_u32 %0, %0, %2\n\ts_cmp_eq_u32 %0, %3\n\ts_cselect_b32 %0, 0, %0"
                                       : "+s"(vs_cur), "=&s"(vs_dma) : "i"(S::kTileBytes), "i"(3 * S::kTileBytes) : "scc");
-            if (i == 21) {
-                if (__builtin_expect(rem == rem_k, 0)) k_rebase(PF64(nx, F_KB_LO), PF(nx, F_TB), PF(nx, F_LK));
-                else k_rsrc_advance(rk, k_rows_left, k_tile_b, k_rs_bytes);
-            }
-            if (i == 23) {
-                if (__builtin_expect(rem == rem_v, 0)) v_rebase(PF64(nx, F_VB_LO), PF(nx, F_TB), PF(nx, F_LK));
-                else v_rsrc_advance(rv, v_rows_left, v_tile_b, v_rs_bytes);
-            }
+            // (at a re-base point the descriptor was set back by one tile before the step: the same move lands on the next piece's first tile)
+            if (i == 21) k_rsrc_advance(rk, k_rows_left, k_tile_b, k_rs_bytes);
+            if (i == 23) v_rsrc_advance(rv, v_rows_left, v_tile_b, v_rs_bytes);
             // the piece's counters move on inside a gap (pinned: scalar C++ would be sunk behind the step's last MFMA, where nothing
             // hides it): t = the tile being scored, rem = tiles left after this step
             if (i == 25) asm volatile("s_add_u32 %0, %0, 1\n\ts_sub_u32 %1, %1, 1" : "+s"(t), "+s"(rem) : : "scc");
@@ -453,9 +464,11 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
             g1 = __builtin_fmaf(mx1, escale, nmsub[1]);
             grow = fmaxf(g0, g1);
         }
-        bx0 = mx0;
-        bx1 = mx1;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(grow > kDeferLog2) != 0, 0) && !seam) {      // (at the seam `grow` compares two pieces: void)
+        if (__builtin_expect(seam_now, 0)) {      // the row maxima of the next piece's first tile (after masking): its reference
+            bx0 = mx0;
+            bx1 = mx1;
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(grow > kDeferLog2) != 0, 0) && !seam_now) {      // (at the seam `grow` compares two pieces: void)
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             SCHED_FENCE();
             raise_max(0, fmaxf(g0, 0.f));
@@ -561,31 +574,33 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
             dma_q_stage(nx);
         }
     };
-    // one tile step at stream parity `par` (a literal): scores of tile t in `a`, S' of the following tile goes to `b`.  At the seam the
-    // next piece's Q block (whose DMA the previous step's vmcnt(0) waited for) moves into the fragment registers first, and the tile
-    // the step scores is the next piece's first: its mask scalars from here on (t is incremented inside the step).
-#define VATTN_STEP(par, a, b)                                                                                                       \
-    {                                                                                                                               \
-        const bool seam = rem == rem_s;                                                                                             \
-        if (__builtin_expect(seam, 0)) {                                                                                            \
+    // The glue in front of a step.  Steady state: ONE compare.  The last three steps of a piece (rem <= 3) and the step after its last
+    // (rem <= 0): first the finished piece's epilogue — then its successor is current: the stream goes on, S'(its first tile) sits in
+    // the score buffer the last step wrote, its next tiles are in flight, t and the mask scalars are its own since the seam —; then the
+    // re-base points (descriptor one tile before the next piece's first: the step's own advance lands on it); at the seam the next
+    // piece's Q block (whose DMA the previous step's vmcnt(0) waited for) moves into the fragment registers, and the tile the step
+    // scores is the next piece's first: its mask scalars from here on (t is incremented inside the step).
+#define VATTN_GLUE()                                                                                                                \
+    if (__builtin_expect(rem <= 3, 0)) {                                                                                            \
+        if (rem <= 0) {                                                                                                             \
+            epilogue(cur);                                                                                                          \
+            if (!have_next) break;                                                                                                  \
+            q_idx++;                                                                                                                \
+            cur = nx;                                                                                                               \
+            reset_acc();                                                                                                            \
+            nmsub[0] = (bx0 == -INFINITY) ? 0.f : -bx0 * escale;      /* softmax.h: a fully masked row keeps a zero reference */    \
+            nmsub[1] = (bx1 == -INFINITY) ? 0.f : -bx1 * escale;                                                                    \
+            seam_now = false;                                                                                                       \
+            begin_piece();                                                                                                          \
+        }                                                                                                                           \
+        if (rem == rem_k) k_prebase(PF64(nx, F_KB_LO), PF(nx, F_TB), PF(nx, F_LK));                                                 \
+        if (rem == rem_v) v_prebase(PF64(nx, F_VB_LO), PF(nx, F_TB), PF(nx, F_LK));                                                 \
+        if (rem == rem_s) {                                                                                                         \
+            seam_now = true;                                                                                                        \
             q_from_stage();                                                                                                         \
             t = PF(nx, F_TB) - 1;                                                                                                   \
             piece_scalars(nx);                                                                                                      \
         }                                                                                                                           \
-        step(par, a, b, kfa, kfb, kfc, seam);                                                                                       \
-    }
-    // end of a piece, after its last step: its epilogue; then the next piece is current — the stream goes on: S'(its first tile) sits in
-    // the score buffer the last step wrote, its next tiles are in flight, t and the mask scalars are its own since the seam
-#define VATTN_END_PIECE()                                                                                                           \
-    if (__builtin_expect(rem <= 0, 0)) {                                                                                            \
-        epilogue(cur);                                                                                                              \
-        if (!have_next) break;                                                                                                      \
-        q_idx++;                                                                                                                    \
-        cur = nx;                                                                                                                   \
-        reset_acc();                                                                                                                \
-        nmsub[0] = (bx0 == -INFINITY) ? 0.f : -bx0 * escale;      /* softmax.h: a fully masked row keeps a zero reference */        \
-        nmsub[1] = (bx1 == -INFINITY) ? 0.f : -bx1 * escale;                                                                        \
-        begin_piece();                                                                                                              \
     }
 
     // ---- cold start of the queue's first piece (prefill64_kernel's prologue) ----
@@ -630,13 +645,12 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
     begin_piece();
 
     for (;;) {
-        VATTN_STEP(0, sc, sd)      // even stream position: scores in sc, S' of the following tile into sd
-        VATTN_END_PIECE()
-        VATTN_STEP(1, sd, sc)      // odd stream position
-        VATTN_END_PIECE()
+        VATTN_GLUE()
+        step(0, sc, sd, kfa, kfb, kfc);      // even stream position: scores in sc, S' of the following tile into sd
+        VATTN_GLUE()
+        step(1, sd, sc, kfa, kfb, kfc);      // odd stream position
     }
-#undef VATTN_END_PIECE
-#undef VATTN_STEP
+#undef VATTN_GLUE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // trailing DMA retired: nothing may land in the LDS of a later workgroup
 #undef P64_X0
 #undef P64_X1

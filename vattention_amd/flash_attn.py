@@ -252,7 +252,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     # step_async(seq_lens) — resolve the row-block's address to its slot and take the length from there.  No device-to-host copy, no
     # extra argument; a tensor that is not one of the page manager's leaves the view's row count as the bound (FlashAttention's own rule).
     klens = _cache_seqlens_host
-    if Sq > 1 and hint == 0 and klens is None and cache_seqlens is not None and cache_batch_idx is None and k is None:
+    if USE_PAGE_MANAGER_LENGTHS and Sq > 1 and hint == 0 and klens is None and cache_seqlens is not None and cache_batch_idx is None and k is None:
         klens = _lengths_from_page_manager(k_cache, B)
         if klens is not None:
             hint = max(klens)
@@ -304,12 +304,19 @@ def _lengths_from_page_manager(k_cache, B: int):
     return out
 
 
-_plan_cache = {}      # (shapes, lengths, device) -> _PrefillPlan; a few dozen entries, dropped wholesale when full
+_plan_cache = {}      # (shapes, lengths, device, stream) -> _PrefillPlan; a few dozen entries, dropped wholesale when full
+# Prefill calls WITHOUT a host-side length take it from the page manager's last step (vattention.resolve_view).  The
+# lengths only size launch plans — the kernels clamp to cache_seqlens on the device — but a caller that steps the manager and attends
+# with other lengths in between gets plans sized for the wrong lengths; False switches the lookup off (the view's row count then bounds
+# the plan, FlashAttention's own rule).
+USE_PAGE_MANAGER_LENGTHS = True
 counters = {"prefill_calls": 0, "lengths_from_page_manager": 0, "plan_built": 0, "plan_cache_hit": 0, "work_list_attached": 0}      # introspection (tools/, tests)
 
 
 def _cached_prefill_plan(p, klens, dev):
-    key = (p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal, tuple(klens), dev.index)
+    # keyed on the STREAM too: the tables travel by a copy queued on the stream current at build time, and nothing orders a launch on
+    # another stream behind that copy
+    key = (p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal, tuple(klens), dev.index, torch.cuda.current_stream(dev).cuda_stream)
     pl = _plan_cache.get(key)
     if pl is None:
         if len(_plan_cache) >= 64:

@@ -119,6 +119,11 @@ class ReplayStats:
     iter_events: List[object] = field(default_factory=list)         # one HIP event per iteration end (time_iterations)
     iter_phase: List[int] = field(default_factory=list)             # 0 = requests still waiting (steady state), 1 = drain tail
     iter_util: List[tuple] = field(default_factory=list)            # per iteration: (live/mapped, live/needed, active slots, mapped/pool)
+    # external fragmentation, sampled every iteration: free pool pages that NO request can use / all physical pages.  A page-group is
+    # one page in each of the 2L tensors (megacache: 2), any free page serves any slot and any position, so the only unusable free
+    # pages are those left over when the pool holds no whole group (pool_pages mod pages_per_group)
+    ext_frag_max: float = 0.0
+    ext_frag_samples: int = 0
 
 
 class HotPathRunner:
@@ -244,6 +249,10 @@ class HotPathRunner:
             u_needed = live / (c["needed_groups"] * tpp)
             self.stats.kv_needed_samples.append((u_needed, c["active_slots"]))
         pages_per_group = 2 if self.engine.vattn_mega_cache else 2 * self.L
+        total_pages = c["pool_pages"] + c["mapped_groups"] * pages_per_group
+        if total_pages:
+            self.stats.ext_frag_max = max(self.stats.ext_frag_max, (c["pool_pages"] % pages_per_group) / total_pages)
+            self.stats.ext_frag_samples += 1
         reserved_tokens = (c["pool_pages"] // pages_per_group) * tpp + mapped_tokens
         if reserved_tokens:
             self.stats.mapped_over_reserved.append(mapped_tokens / reserved_tokens)
@@ -408,6 +417,7 @@ class HotPathRunner:
             "kv_live_over_needed_at_peak": min((x for x, a in self.stats.kv_needed_samples if a >= 0.9 * out["peak_running"]), default=None),
             "slack_tokens_per_seq_at_peak_max": max(((1 - x) * 1.0 for x, a in self.stats.kv_needed_samples if a >= 0.9 * out["peak_running"]), default=None),
             "tokens_per_page": tpp,
+            "external_fragmentation_max": self.stats.ext_frag_max, "external_fragmentation_samples": self.stats.ext_frag_samples,
             "map_calls": vm1["map_calls"] - vm0["map_calls"], "unmap_calls": vm1["unmap_calls"] - vm0["unmap_calls"],
             "sync_map_ms": (vm1["sync_ns"] - vm0["sync_ns"]) / 1e6, "async_map_ms": (vm1["async_ns"] - vm0["async_ns"]) / 1e6,
             "join_wait_ms": (vm1["join_wait_ns"] - vm0["join_wait_ns"]) / 1e6,
