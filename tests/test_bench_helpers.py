@@ -61,3 +61,31 @@ def test_stdout_carries_the_bench_line_only():
     assert r.stdout.count("\n") == 1 and json.loads(r.stdout) == {"metric": 1}, r.stdout
     for noise in ("python noise", "native noise", "raw fd noise"):
         assert noise in r.stderr
+
+
+def test_bookkeeping_baseline_times_the_reference_allocator_beside_this_manager():
+    """cpu_baseline.bookkeeping: the reference's own allocator (oracle/_ref, when built) and this manager on one call
+    sequence; microseconds per step_async, driver calls free."""
+    m = bench.bookkeeping_baseline()
+    assert "error" not in m, m
+    assert m["this_manager_inline_us_per_step_async"] > 0 and m["step_async_calls"] >= 100 and m["cores"] == 1
+    if m["reference_us_per_step_async"] is not None:
+        assert m["kind"] == "reference" and m["reference_over_this"] > 1.0      # the plan-then-execute manager does less host work per step
+
+
+def test_telemetry_sampler_never_fails_the_benchmark_where_no_gpu_answers():
+    import time
+    from vattention_amd.telemetry import Sampler
+    t0 = time.time()
+    with Sampler(0, 0.02) as s:
+        time.sleep(0.1)
+    w = s.window(t0, time.time())
+    assert set(w) >= {"source", "samples", "interval_s"}
+    if w["source"] is None:
+        assert w["samples"] == 0 and "clock_mhz_mean" not in w
+
+
+def test_external_fragmentation_is_what_the_pool_cannot_hand_out_as_whole_groups():
+    from vattention_amd.replay import ReplayStats
+    st = ReplayStats()
+    assert st.ext_frag_max == 0.0 and st.ext_frag_samples == 0
