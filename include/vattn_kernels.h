@@ -111,7 +111,10 @@ typedef struct vattn_attn_params {
     /* PERSISTENT form of the work list (round 5; both zero: one workgroup per piece, in list order).  vattn_prefill_plan_wg also
      * ASSIGNS the pieces: pf_items is grouped by workgroup, workgroup w owns pieces [pf_wg_first[w], pf_wg_first[w + 1]) and walks them
      * in that order without stopping its K / V tile stream between them (csrc/prefill64p_kernels.hip: the next piece's Q block and
-     * first tiles are fetched under the current piece's last tiles; one workgroup per CU).  pf_wg_first has pf_num_wg + 1 entries. */
+     * first tiles are fetched under the current piece's last tiles; one workgroup per CU).  pf_wg_first has pf_num_wg + 1 entries.
+     * pf_num_wg > 0 with pf_wg_first == NULL: DRAWN queues — pf_items stays in longest-first order, workgroup w starts with piece w and
+     * draws further pieces of its XCD's sub-sequence from a library-owned counter, which balances what a static assignment cannot (the
+     * workgroups differ in speed by a few per cent).  What vattn_prefill_plan_wg(wg_first_out = NULL) prepares. */
     int32_t pf_num_wg;
     const int32_t* pf_wg_first;                    /* device: int32[pf_num_wg + 1]                                              */
 } vattn_attn_params;
@@ -162,7 +165,8 @@ int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_hos
  * pay off, and are assigned to at most `max_wg` workgroups (<= 0: one per CU, 256) longest first, each to the least loaded one among
  * the workgroups of its kv head's XCD class (workgroup w runs on XCD w % 8; class = kv head modulo the classes that divide 8, so that an
  * XCD's L2 keeps seeing one kv head).  items_out comes back GROUPED by workgroup; wg_first_out receives num_wg + 1 offsets;
- * counts_out[4] = {items, split blocks, partial rows, num_wg}.  Returns the number of items (0: default launch, as above). */
+ * counts_out[4] = {items, split blocks, partial rows, num_wg}.  wg_first_out == NULL: no assignment (drawn queues, see pf_num_wg):
+ * items_out stays longest first, only num_wg is chosen.  Returns the number of items (0: default launch, as above). */
 int32_t vattn_prefill_plan_wg(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
                               int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* wg_first_out, int32_t max_wg,
                               int32_t* counts_out);

@@ -1,7 +1,9 @@
 """prefill64p_kernel (round 5): work lists walked by PERSISTENT workgroups — one per CU, each a queue of (entry, head, query block,
 key-tile range) pieces whose K / V tile stream does not stop between pieces — against the oracle, against the one-workgroup-per-piece
 launch of the same pieces (bit for bit), with few long queues (every seam kind: pieces of one, two, three and many tiles, pieces
-without tiles, partial and direct outputs following each other), stale host lengths, strided cache views and the varlen form."""
+without tiles, partial and direct outputs following each other), stale host lengths, strided cache views and the varlen form; both
+queue forms: host-assigned (`drawn=False`) and drawn from the device counter (`drawn=True`, the default), whose counters must be
+back at zero after every launch."""
 import ctypes as C
 
 import pytest
@@ -90,14 +92,17 @@ SHAPES = [
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("name,Hq,Hkv,chunks", SHAPES, ids=[s[0] for s in SHAPES])
 def test_persistent_work_list_matches_the_oracle_and_the_per_piece_launch(name, Hq, Hkv, chunks, dtype):
-    plans = [("persistent", dict(persistent=True)), ("persistent_t9", dict(persistent=True, force_tiles=9)),
+    plans = [("persistent", dict(persistent=True)), ("drawn_t9", dict(persistent=True, force_tiles=9, drawn=True)),
+             ("assigned_t9", dict(persistent=True, force_tiles=9, drawn=False)), ("drawn_t9_again", dict(persistent=True, force_tiles=9, drawn=True)),
              ("per_piece_t9", dict(persistent=False, force_tiles=9)), ("default", None)]
     outs, ref64, ref32, info = _run(chunks, Hq, Hkv, dtype, plans)
     for k, o in outs.items():
         _check(o, ref64, ref32, dtype, "%s / %s %s" % (name, k, info.get(k)))
-    # the SAME pieces through both kernels: same tile arithmetic in the same order (a padded step adds P = 0), same merge
-    assert info["persistent_t9"][:2] == info["per_piece_t9"][:2]
-    assert torch.equal(outs["persistent_t9"], outs["per_piece_t9"]), "%s: persistent and per-piece launches of one list differ" % name
+    # the SAME pieces through both kernels, whoever walks them in whatever order: same tile arithmetic in the same order inside a piece
+    # (a padded step adds P = 0), same merge.  The second drawn launch finds the counters the first one left: zero.
+    assert info["drawn_t9"][:2] == info["per_piece_t9"][:2] == info["assigned_t9"][:2]
+    for k in ("drawn_t9", "assigned_t9", "drawn_t9_again"):
+        assert torch.equal(outs[k], outs["per_piece_t9"]), "%s: %s and per-piece launches of one list differ" % (name, k)
 
 
 @pytest.mark.parametrize("max_wg", [1, 8, 24])
@@ -106,19 +111,22 @@ def test_long_queues_of_short_pieces(max_wg, tiles):
     """Few workgroups, many pieces each, cut to `tiles` key tiles: one-, two- and three-tile pieces are stepped over three tiles with the
     tiles behind their own masked whole; every piece but a queue's first starts at a seam."""
     chunks = [(0, 700), (300, 260), (0, 1), (0, 1030)]
-    plans = [("q", dict(persistent=True, force_tiles=tiles, max_wg=max_wg)), ("ref_list", dict(persistent=False, force_tiles=tiles))]
+    plans = [("q", dict(persistent=True, force_tiles=tiles, max_wg=max_wg, drawn=True)), ("qa", dict(persistent=True, force_tiles=tiles, max_wg=max_wg, drawn=False)),
+             ("q2", dict(persistent=True, force_tiles=tiles, max_wg=max_wg, drawn=True)), ("ref_list", dict(persistent=False, force_tiles=tiles))]
     outs, ref64, ref32, info = _run(chunks, 4, 2, torch.float16, plans, seed=tiles * 31 + max_wg)
     assert info["q"][2] == min(max_wg, info["q"][0]) or info["q"][2] % 8 == 0
     _check(outs["q"], ref64, ref32, torch.float16, "queues of %d, pieces of %d tiles %s" % (max_wg, tiles, info["q"]))
-    assert torch.equal(outs["q"], outs["ref_list"])
+    for k in ("q", "qa", "q2"):
+        assert torch.equal(outs[k], outs["ref_list"]), k
 
 
 def test_non_causal_and_strided_views():
     for causal, strided in ((False, False), (True, True), (False, True)):
-        plans = [("p", dict(persistent=True, force_tiles=7, max_wg=16)), ("l", dict(persistent=False, force_tiles=7))]
+        plans = [("p", dict(persistent=True, force_tiles=7, max_wg=16)), ("pa", dict(persistent=True, force_tiles=7, max_wg=16, drawn=False)),
+                 ("l", dict(persistent=False, force_tiles=7))]
         outs, ref64, ref32, info = _run([(500, 300), (0, 900)], 8, 2, torch.float16, plans, causal=causal, strided=strided, seed=11)
         _check(outs["p"], ref64, ref32, torch.float16, "causal=%s strided=%s %s" % (causal, strided, info["p"]))
-        assert torch.equal(outs["p"], outs["l"])
+        assert torch.equal(outs["p"], outs["l"]) and torch.equal(outs["pa"], outs["l"])
 
 
 @pytest.mark.parametrize("delta", [-900, -64, -1, 70], ids=["much_shorter", "one_tile_shorter", "one_key_shorter", "longer"])
@@ -129,9 +137,10 @@ def test_stale_host_lengths_cost_balance_never_keys(delta):
     k_host = [c + n for c, n in chunks]
     k_dev = [max(n, kl + delta) for kl, (c, n) in zip(k_host, chunks)]
     k_dev = [min(kd, kl + 70) for kd, kl in zip(k_dev, k_host)]
-    plans = [("p", dict(persistent=True, force_tiles=4, max_wg=8)), ("d", None)]
+    plans = [("p", dict(persistent=True, force_tiles=4, max_wg=8)), ("pa", dict(persistent=True, force_tiles=4, max_wg=8, drawn=False)), ("d", None)]
     outs, ref64, ref32, info = _run(chunks, 8, 2, torch.float16, plans, klens_dev=k_dev, seed=3)
-    _check(outs["p"], ref64, ref32, torch.float16, "host lengths %s, device lengths %s %s" % (k_host, k_dev, info["p"]))
+    for k in ("p", "pa"):
+        _check(outs[k], ref64, ref32, torch.float16, "%s: host lengths %s, device lengths %s %s" % (k, k_host, k_dev, info[k]))
 
 
 def test_plan_describe_reports_the_persistent_launch():

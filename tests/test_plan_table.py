@@ -167,3 +167,24 @@ def test_persistent_work_list_respects_a_workgroup_cap_and_a_forced_piece_length
     assert n > 0 and counts[3] == 64 and wg_first[-1] == n
     assert all((it.tile_end if it.tile_end != 0x7fffffff else it.tile_begin + 16) - it.tile_begin <= 16 for it in items)
     assert counts[1] == len(blocks) and all(bk.nshares > 1 for bk in blocks)
+
+
+def test_drawn_queues_keep_the_list_longest_first_and_only_choose_the_workgroup_count():
+    """vattn_prefill_plan_wg(wg_first_out = NULL): nothing is assigned — the persistent workgroups draw their pieces on the device."""
+    import ctypes as C
+    from vattention_amd import kernels as K
+    p = K.AttnParams()
+    q = [6526, 14505, 5364]
+    p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal = 3, max(q), 8, 1, 128, 1
+    nblk = sum((x + 255) // 256 for x in q) * 8
+    items, blocks = (K.PrefillItem * (17 * nblk + 16))(), (K.PrefillItem * (nblk + 16))()
+    counts = (C.c_int32 * 4)()
+    ql = (C.c_int32 * 3)(*q)
+    n = K.klib().vattn_prefill_plan_wg(C.byref(p), ql, ql, items, 17 * nblk + 16, blocks, nblk + 16, None, 0, counts)
+    assert n == nblk and counts[3] == 256 and counts[1] == 0          # a balanced ragged batch: compacted, not cut
+    lens = [(min(q[items[i].b], items[i].qb * 256 + 256) + 63) // 64 for i in range(n)]
+    assert lens == sorted(lens, reverse=True)
+    ref = (K.PrefillItem * (17 * nblk + 16))()
+    c3 = (C.c_int32 * 3)()
+    assert K.klib().vattn_prefill_plan(C.byref(p), ql, ql, ref, 17 * nblk + 16, blocks, nblk + 16, c3) == n
+    assert all((items[i].b, items[i].h, items[i].qb) == (ref[i].b, ref[i].h, ref[i].qb) for i in range(n)), "same list as the per-piece launch takes"

@@ -196,6 +196,26 @@ int* merge_counters(hipStream_t st, size_t n_ints) {
 }
 
 
+// Counters of the DRAWN queues of the persistent prefill launch (csrc/prefill64p_kernels.hip): 8 ints per (device, stream), zeroed once —
+// every launch leaves them zero (the last draw of a queue resets its counter).  Created on first use; never while the stream is being
+// captured into a graph (NULL then: the caller launches one workgroup per piece; a warm-up call before capture creates them).
+int* queue_counters(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int*> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    auto it = bufs.find(std::make_pair(dev, st));
+    if (it != bufs.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    int* np = nullptr;
+    if (hipMalloc((void**)&np, 16 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemsetAsync(np, 0, 16 * sizeof(int), st) != hipSuccess) { (void)hipFree(np); return nullptr; }
+    bufs[std::make_pair(dev, st)] = np;
+    return np;
+}
+
 thread_local std::string g_err;
 int fail(int code, const char* msg) {
     g_err = msg;
@@ -239,8 +259,8 @@ int validate(const vattn_attn_params* p) {
     if (p->o_row_stride % 4 != 0 || p->o_head_stride % 4 != 0 || p->o_batch_stride % 4 != 0)
         return fail(VATTN_K_ERR_UNSUPPORTED, "output strides must be multiples of 4 elements");
     if (p->pf_items && (p->seqlen_q == 1 || p->d != 128)) return fail(VATTN_K_ERR_INVALID, "pf_items (prefill work list) applies to the prefill form with head dimension 128");
-    if ((p->pf_num_wg != 0) != (p->pf_wg_first != nullptr) || p->pf_num_wg < 0 || (p->pf_num_wg && !p->pf_items))
-        return fail(VATTN_K_ERR_INVALID, "pf_num_wg and pf_wg_first (persistent work list) must be given together, with pf_items");
+    if (p->pf_num_wg < 0 || (p->pf_wg_first && !p->pf_num_wg) || (p->pf_num_wg && (!p->pf_items || p->pf_num_wg > p->num_pf_items)))
+        return fail(VATTN_K_ERR_INVALID, "pf_num_wg (persistent work list) needs pf_items and at most one workgroup per piece; pf_wg_first needs pf_num_wg");
     if (p->split_items && p->seqlen_q != 1) return fail(VATTN_K_ERR_INVALID, "split_items (length-balanced plan) applies to the decode form only");
     if (!kLab) {
         const int til = (p->variant >> 1) & 7;
@@ -296,8 +316,8 @@ int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_hos
 int32_t vattn_prefill_plan_wg(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,
                               int32_t cap_items, vattn_prefill_item* blocks_out, int32_t cap_blocks, int32_t* wg_first_out, int32_t max_wg,
                               int32_t* counts_out) {
-    if (!abi_ok(p) || !wg_first_out) return VATTN_K_ERR_INVALID;
-    return prefill_worklist(p, q_lens_host, k_lens_host, items_out, cap_items, blocks_out, cap_blocks, counts_out, wg_first_out, max_wg);
+    if (!abi_ok(p)) return VATTN_K_ERR_INVALID;
+    return prefill_worklist(p, q_lens_host, k_lens_host, items_out, cap_items, blocks_out, cap_blocks, counts_out, wg_first_out, max_wg, wg_first_out ? 1 : 2);
 }
 
 size_t vattn_hybrid_workspace_bytes(const vattn_attn_params* prefill, const vattn_attn_params* decode) {

@@ -27,8 +27,15 @@ namespace vattn_k {
 constexpr int kQStage = 87040;                 // LDS offset of the Q staging area: 4 waves x 16 KiB (K ring 36 864 + V ring 49 152 + 16, rounded up to 1 KiB)
 constexpr int kSmem64p = kQStage + 65536;      // 152 576 bytes: one workgroup per CU (160 KiB of LDS)
 
-template <typename T, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3>
-__global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p) {
+// DYN = false: workgroup w walks its own queue, pieces [pf_wg_first[w], pf_wg_first[w + 1]) of a list GROUPED by workgroup (the host assigned
+// them: vattn_prefill_plan_wg).  DYN = true: the list is in longest-first order and the workgroups DRAW their pieces — workgroup w starts
+// with piece w and takes further pieces of its XCD's sub-sequence (positions = w mod 8, when the grid is a multiple of 8: an XCD's L2 keeps
+// seeing the kv heads the list order gives it) from a counter in device memory, one ticket ahead of need: a static assignment cannot
+// absorb the few per cent by which workgroups differ in speed (profiles/r05_p64p_legs_ab_static_queues.txt: 6-8 % slower than the
+// hardware's own greedy dispatch of one workgroup per piece on the ragged tensor-parallel batches), a drawn one does what the dispatcher
+// does.  `ctr`: 8 zero-initialised counters owned by the library (one set per device and stream); the last draw of a queue resets it.
+template <typename T, bool DYN, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3>
+__global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p, int* ctr) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int HD = 128;
@@ -54,10 +61,37 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
     const int G = p.h / p.h_k;
     const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
 
-    // ---- this workgroup's queue: pieces [q_idx, q_end) of the list, in order ----
-    int q_idx = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x]);
-    const int q_end = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x + 1]);
-    if (q_idx >= q_end) return;
+    // ---- this workgroup's queue ----
+    // static: pieces [q_idx, q_end) of the grouped list, in order.  drawn: piece blockIdx.x first, then positions qx + nq * (gq + ticket)
+    int q_idx, q_end = 0;
+    int next_idx = -1;                                    // drawn: the piece after `cur` (-1: none)
+    const int n_items = p.num_pf_items;
+    const int nq = (gridDim.x & 7) == 0 ? 8 : 1, qx = (int)blockIdx.x % nq, gq = (int)gridDim.x / nq;
+    const int n_q = (n_items - qx + nq - 1) / nq;        // positions of this queue; its tickets are 0 .. n_q - 1 (gq of them draw nothing)
+    int* const lds_word = (int*)(smem + 86016);           // the 16 spare bytes behind the V ring: wave 0 hands the drawn piece to the others
+    unsigned tk = 0;                                      // wave 0, lane 0: the ticket in flight
+    if (DYN) {
+        q_idx = (int)blockIdx.x;
+        if (q_idx >= n_items) return;
+    } else {
+        q_idx = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x]);
+        q_end = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x + 1]);
+        if (q_idx >= q_end) return;
+    }
+    // one draw from this queue's counter by lane 0 of the calling wave (wave 0 calls it); the old value arrives in `tk` — behind a
+    // vmcnt wait the caller provides: the compiler does not see this instruction
+    auto draw = [&]() {
+        unsigned long long save;
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                     : "=&v"(tk), "=&s"(save) : "v"((unsigned)(qx * 4)), "v"(1u), "s"(ctr) : "memory");
+    };
+    // the ticket that arrived -> the piece it stands for (or -1), into the LDS word; the queue's last ticket zeroes the counter for the next launch
+    auto publish = [&]() {
+        const int tv = (int)__builtin_amdgcn_readfirstlane(tk);
+        const int pos = qx + nq * (gq + tv);
+        if (tv == n_q - 1 && lane == 0) ctr[qx] = 0;
+        if (lane == 0) *lds_word = pos < n_items ? pos : -1;
+    };
 
     // One piece, resolved against the DEVICE-side lengths (the list is a hint: include/vattn_kernels.h).  Its fifteen scalars live in the
     // LANES of one vector register (field i in lane i; v_writelane / v_readlane): the kernel sits at the SGPR limit, the steady state
@@ -544,6 +578,11 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
     // ---- kernel start: the V ring holds FINITE data from here on (a key row past a sequence's end has probability exactly 0, and
     // 0 x NaN would poison O; later pieces find the previous pieces' tiles there — finite) ----
     {
+        if (DYN && wave == 0) {      // the first ticket, synchronously (nothing else is in flight yet), in front of the barrier below
+            draw();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish();
+        }
         const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < (3 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + VBASE + (i * 256 + tid) * 16) = z;
@@ -564,14 +603,17 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
     // start of a piece: its step count; resolve the next piece of the queue and start its Q block on its way to the staging area
     auto begin_piece = [&]() {
         rem = max(PF(cur, F_NT) - t, 3);
-        have_next = q_idx + 1 < q_end;
+        if (DYN) next_idx = __builtin_amdgcn_readfirstlane(*lds_word);      // published two barriers ago (kernel start / the glue at rem == 2)
+        else next_idx = q_idx + 1 < q_end ? q_idx + 1 : -1;
+        have_next = next_idx >= 0;
         rem_k = rem_v = rem_s = -1;
         if (have_next) {
-            nx = load_piece(q_idx + 1);
+            nx = load_piece(next_idx);
             rem_k = 3;
             rem_v = 2;
             rem_s = 1;
             dma_q_stage(nx);
+            if (DYN && wave == 0) draw();      // the ticket after next: arrives under the coming step, published at rem == 2
         }
     };
     // The glue in front of a step.  Steady state: ONE compare.  The last three steps of a piece (rem <= 3) and the step after its last
@@ -585,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
         if (rem <= 0) {                                                                                                             \
             epilogue(cur);                                                                                                          \
             if (!have_next) break;                                                                                                  \
-            q_idx++;                                                                                                                \
+            q_idx = next_idx;                                                                                                       \
             cur = nx;                                                                                                               \
             reset_acc();                                                                                                            \
             nmsub[0] = (bx0 == -INFINITY) ? 0.f : -bx0 * escale;      /* softmax.h: a fully masked row keeps a zero reference */    \
@@ -594,7 +636,10 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
             begin_piece();                                                                                                          \
         }                                                                                                                           \
         if (rem == rem_k) k_prebase(PF64(nx, F_KB_LO), PF(nx, F_TB), PF(nx, F_LK));                                                 \
-        if (rem == rem_v) v_prebase(PF64(nx, F_VB_LO), PF(nx, F_TB), PF(nx, F_LK));                                                 \
+        if (rem == rem_v) {                                                                                                         \
+            v_prebase(PF64(nx, F_VB_LO), PF(nx, F_TB), PF(nx, F_LK));                                                               \
+            if (DYN && wave == 0) publish();      /* (drawn at the start of this piece; the step in between waited vmcnt(0)) */      \
+        }                                                                                                                           \
         if (rem == rem_s) {                                                                                                         \
             seam_now = true;                                                                                                        \
             q_from_stage();                                                                                                         \
@@ -658,21 +703,24 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p)
 #undef PF64
 }
 
-void launch_prefill64p(const vattn_attn_params* p, hipStream_t st) {
-    if (p->dtype == VATTN_DTYPE_BF16) {
-        static const bool once = [] {
-            (void)hipFuncSetAttribute((const void*)prefill64p_kernel<__bf16, 24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64p);
-            return true;
-        }();
-        (void)once;
-        hipLaunchKernelGGL((prefill64p_kernel<__bf16, 24, 4>), dim3((unsigned)p->pf_num_wg), dim3(256), kSmem64p, st, *p);
+template <typename T, bool DYN> static void launch64p_t(const vattn_attn_params* p, hipStream_t st, int* ctr) {
+    static const bool once = [] {
+        (void)hipFuncSetAttribute((const void*)prefill64p_kernel<T, DYN, 24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64p);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((prefill64p_kernel<T, DYN, 24, 4>), dim3((unsigned)p->pf_num_wg), dim3(256), kSmem64p, st, *p, ctr);
+}
+
+// pf_wg_first given: the host-assigned queues; else the drawn ones (ctr: queue_counters(st), attn_api.hip)
+void launch_prefill64p(const vattn_attn_params* p, hipStream_t st, int* ctr) {
+    const bool bf = p->dtype == VATTN_DTYPE_BF16;
+    if (p->pf_wg_first) {
+        if (bf) launch64p_t<__bf16, false>(p, st, nullptr);
+        else launch64p_t<_Float16, false>(p, st, nullptr);
     } else {
-        static const bool once = [] {
-            (void)hipFuncSetAttribute((const void*)prefill64p_kernel<_Float16, 24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64p);
-            return true;
-        }();
-        (void)once;
-        hipLaunchKernelGGL((prefill64p_kernel<_Float16, 24, 4>), dim3((unsigned)p->pf_num_wg), dim3(256), kSmem64p, st, *p);
+        if (bf) launch64p_t<__bf16, true>(p, st, ctr);
+        else launch64p_t<_Float16, true>(p, st, ctr);
     }
 }
 

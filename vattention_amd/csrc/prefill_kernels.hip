@@ -583,7 +583,13 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
                 return fail(VATTN_K_ERR_INVALID, "pf_items needs num_pf_items, and pf_blocks + a workspace when blocks are split");
             // grouped by workgroup (vattn_prefill_plan_wg): persistent workgroups, continuous tile stream (prefill64p_kernels.hip);
             // the fused-RoPE form and outputs without 16-byte rows keep one workgroup per piece (the queue order is a valid list order)
-            if (p->pf_num_wg > 0 && !p->rotary_cos_sin && ((p->o_row_stride | p->o_head_stride | p->o_batch_stride) & 7) == 0) launch_prefill64p(p, st);
+            int* ctr = nullptr;
+            bool persistent = p->pf_num_wg > 0 && !p->rotary_cos_sin && ((p->o_row_stride | p->o_head_stride | p->o_batch_stride) & 7) == 0;
+            if (persistent && !p->pf_wg_first) {      // drawn queues need the library's counters (none while a graph is being captured before they exist)
+                ctr = queue_counters(st);
+                persistent = ctr != nullptr;
+            }
+            if (persistent) launch_prefill64p(p, st, ctr);
             else launch_prefill64(p, st, 1, nullptr, 0);
             if (p->num_pf_blocks > 0) hipLaunchKernelGGL((combine_blocks_kernel<T, 128>), dim3((unsigned)p->num_pf_blocks * 64), dim3(256), 0, st, *p);
             hipError_t e = hipGetLastError();
@@ -647,12 +653,12 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
 // being dispatched one by one; the pieces are ASSIGNED here (longest first, each to the least loaded workgroup of its kv head's XCD
 // class) and come back grouped by workgroup.
 int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const int32_t* k_lens, vattn_prefill_item* items, int cap_items,
-                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts, int32_t* wg_first, int max_wg) {
+                     vattn_prefill_item* blocks, int cap_blocks, int32_t* counts, int32_t* wg_first, int max_wg, int persist_mode) {
     if (!p || !k_lens || !items || !blocks || !counts || p->b <= 0 || p->h <= 0 || p->seqlen_q <= 0) return VATTN_K_ERR_INVALID;
     counts[0] = counts[1] = counts[2] = 0;
-    if (wg_first) counts[3] = 0;
+    if (persist_mode) counts[3] = 0;
     if (p->d != 128 || p->seqlen_q == 1) return 0;
-    const bool persist = wg_first != nullptr;
+    const bool persist = persist_mode != 0;
     const long kSlots = persist && max_wg > 0 && max_wg < 256 ? max_wg : 256;      // one prefill64 workgroup per CU
     const long kOvh = persist ? 2 : 6;                 // per-piece overhead in half-tile units (chained / cold prologue)
     const long kMinPiece = persist ? 8 : 12;           // pieces shorter than this are all overhead
@@ -742,8 +748,7 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
         if (price(T, &pieces, &best_rows) >= 1e30 || pieces > cap_items) return 0;
     }
     bool search = !forced_T;
-    if (!forced_T && !persist && (balanced || longest < 48)) { T = longest; search = false; }      // (ragged:) nothing to cut, only to compact
-    if (!forced_T && persist && nblk >= 4 * kSlots) { T = longest; search = false; }               // several rounds of blocks: the assignment balances them
+    if (!forced_T && (balanced || longest < 48)) { T = longest; search = false; }      // nothing to cut, only to compact (persistent: to chain)
     for (long ns_max : kShares) {
         if (!search) break;
         const long t_c = (longest + ns_max - 1) / ns_max;
@@ -805,7 +810,13 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
     counts[0] = n;
     counts[1] = nb;
     counts[2] = (int32_t)part_rows;
-    if (persist) {
+    if (persist_mode == 2) {
+        // drawn queues: the list stays in longest-first order (its head enumeration already deals the kv heads to the XCDs by position);
+        // the workgroups take piece w first and draw the rest (csrc/prefill64p_kernels.hip)
+        long nwg = n < kSlots ? n : kSlots;
+        if (nwg >= 8) nwg -= nwg % 8;
+        counts[3] = (int32_t)nwg;
+    } else if (persist) {
         // ---- assignment: at most kSlots workgroups; workgroup w runs on XCD w % 8 (a grid of at most one workgroup per CU is handed out
         // round-robin), and an XCD's L2 should keep seeing ONE kv head: the pieces of kv head hk go to the workgroups of class
         // hk % ncls, ncls = the kv heads when they divide the 8 XCDs.  Longest first, each to the least loaded workgroup of its class. ----

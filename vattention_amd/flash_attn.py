@@ -359,10 +359,10 @@ class _PrefillPlan:
     """Device tables of a prefill work list (vattn_prefill_plan) — or the fact that the default launch is as good (tables None).  Built
     from host-side lengths only, so the attention wrapper builds it for layer 0 of an iteration and hands the same object to the
     other layers' calls (`_pf_plan`)."""
-    __slots__ = ("t", "n_items", "n_blocks", "part_rows", "n_wg")
+    __slots__ = ("t", "n_items", "n_blocks", "part_rows", "n_wg", "drawn")
 
-    def __init__(self, t=None, n_items=0, n_blocks=0, part_rows=0, n_wg=0):
-        self.t, self.n_items, self.n_blocks, self.part_rows, self.n_wg = t, n_items, n_blocks, part_rows, n_wg
+    def __init__(self, t=None, n_items=0, n_blocks=0, part_rows=0, n_wg=0, drawn=False):
+        self.t, self.n_items, self.n_blocks, self.part_rows, self.n_wg, self.drawn = t, n_items, n_blocks, part_rows, n_wg, drawn
 
     def attach(self, p):
         if self.t is not None:
@@ -372,14 +372,15 @@ class _PrefillPlan:
             p.pf_part_rows = self.part_rows
             # persistent form (vattn_prefill_plan_wg): the pieces are grouped by workgroup, the offsets follow the two tables
             p.pf_num_wg = self.n_wg
-            p.pf_wg_first = base + 32 * (self.n_items + self.n_blocks) if self.n_wg else None
+            p.pf_wg_first = base + 32 * (self.n_items + self.n_blocks) if self.n_wg and not self.drawn else None
 
 
-PERSISTENT = True          # work lists are assigned to persistent workgroups (csrc/prefill64p_kernels.hip); False: one workgroup per piece (A/B, tests)
+PERSISTENT = True          # work lists are walked by persistent workgroups (csrc/prefill64p_kernels.hip); False: one workgroup per piece (A/B, tests)
+PERSISTENT_DRAWN = True    # ... which DRAW their pieces from a device counter (balances like the hardware dispatcher); False: host-assigned queues
 PERSISTENT_MAX_BLOCKS = 2048      # (entry, head, query block) triples up to which a launch gets a list at all in the persistent form
 
 
-def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0, persistent=None, max_wg: int = 0) -> _PrefillPlan:
+def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0, persistent=None, max_wg: int = 0, drawn=None) -> _PrefillPlan:
     """q_lens_host: chunk length per entry (None: p.seqlen_q for all); k_lens_host: visible keys per entry; force_tiles: pieces of at
     most this many 64-key tiles whatever the planner's own rules say (tests, A/B); persistent: None = the module default; max_wg: at
     most this many persistent workgroups (0: one per CU)."""
@@ -404,7 +405,8 @@ def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0, persist
         p.num_splits = -int(force_tiles)
     if persist:
         counts = (C.c_int32 * 4)()
-        wg_first = (C.c_int32 * 257)()
+        dyn = PERSISTENT_DRAWN if drawn is None else bool(drawn)
+        wg_first = None if dyn else (C.c_int32 * 257)()
         n = K.klib().vattn_prefill_plan_wg(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, wg_first, int(max_wg), counts)
     else:
         n = K.klib().vattn_prefill_plan(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, counts)
@@ -420,9 +422,10 @@ def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0, persist
         C.memmove(dst, items, 32 * n)
         if nb:
             C.memmove(dst + 32 * n, blocks, 32 * nb)
-        if nwg:
+        if nwg and wg_first is not None:
             C.memmove(dst + 32 * (n + nb), wg_first, 4 * (nwg + 1))
-    return _PrefillPlan(_Staging.upload(32 * (n + nb) + (4 * (nwg + 1) if nwg else 0), fill, dev), n, nb, int(counts[2]), nwg)
+    return _PrefillPlan(_Staging.upload(32 * (n + nb) + (4 * (nwg + 1) if nwg and wg_first is not None else 0), fill, dev), n, nb, int(counts[2]), nwg,
+                        drawn=bool(nwg and wg_first is None))
 
 
 def _decode_plan(p, lens_host, dev):
