@@ -94,8 +94,8 @@ def parse():
                     "without the collectives (checks the tensor-parallel workloads where only one GPU is visible; NOT a bench line)")
     ap.add_argument("--leg", default="", help="run ONLY one of the legs outside the timed region (dynamic, dynamic_tp8_rank, capacity) and print it: "
                     "what tools/prof_round.sh profiles (NOT a bench line)")
-    ap.add_argument("--per-piece-prefill", action="store_true", help="A/B: prefill work lists launched one workgroup per piece (prefill64_kernel) instead "
-                    "of through persistent workgroups (prefill64p_kernel); NOT the bench line")
+    ap.add_argument("--per-piece-prefill", action="store_true", help="A/B: NO persistent workgroups anywhere (prefill64p_kernel off); NOT the bench line")
+    ap.add_argument("--persistent-prefill", action="store_true", help="A/B: EVERY prefill work list through persistent workgroups; NOT the bench line")
     ap.add_argument("--qps", type=float, default=0.0, help="run ONLY the open-loop replay (Poisson arrivals, reference recipe) at this rate and print it")
     return ap.parse_args()
 
@@ -252,9 +252,9 @@ def main():
     from vattention_amd import vattention
     from vattention_amd.attention.timers import drain_op_timers_detail, enable_op_timers
     from vattention_amd.replay import CacheConfig, HotPathRunner, ModelConfig, ParallelConfig
-    if a.per_piece_prefill:
+    if a.per_piece_prefill or a.persistent_prefill:
         from vattention_amd import flash_attn as _FA
-        _FA.PERSISTENT = False
+        _FA.PERSISTENT = "never" if a.per_piece_prefill else "always"
 
     if a.rank_of and (world != 1 or a.rank_of not in WORKLOADS):
         raise SystemExit("--rank-of needs --gpus 1 and one of %s" % sorted(WORKLOADS))
@@ -265,7 +265,7 @@ def main():
     if a.requests:
         w["requests"] = a.requests
     dtype = torch.float16                                    # benchmark_runner.py:81
-    valid = not (a.layers or a.ctx or a.rank_of or a.requests or a.per_piece_prefill)
+    valid = not (a.layers or a.ctx or a.rank_of or a.requests or a.per_piece_prefill or a.persistent_prefill)
 
     def make_runner(model_name, tp, ctx, page, batch, backend_name, mem_bytes, layers=0):
         model = ModelConfig.named(model_name, dtype=dtype, max_model_len=ctx, attention_backend=backend_name)

@@ -149,8 +149,24 @@ def test_plan_describe_reports_the_persistent_launch():
     p = K.AttnParams()
     p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d, p.is_causal = 1, 8192, 8192, 8, 1, 128, 1
     p.o_row_stride, p.o_head_stride = 8 * 128, 128
-    pl = FA.prefill_plan(p, None, [8192], torch.device(DEV))
+    pl = FA.prefill_plan(p, None, [8192], torch.device(DEV), persistent=True)
     assert pl.t is not None and pl.n_wg == 256
     pl.attach(p)
     d = K.describe(p)
     assert d["path"] == 1 and d["tiling"] == 7 and d["workgroups"] == 256 and d["merge_launch"] == int(pl.n_blocks > 0)
+
+
+def test_default_policy_takes_persistent_workgroups_for_a_chunk_on_a_long_prefix_only():
+    """flash_attn.PERSISTENT = "chunks" (measured: profiles/r05_p64p_*): one entry whose prefix is at least four times its chunk gets the
+    persistent queues; whole prompts and ragged batches keep one workgroup per piece."""
+    from vattention_amd import flash_attn as FA
+    from vattention_amd import kernels as K
+    assert FA.PERSISTENT == "chunks"
+
+    def plan(q, k):
+        p = K.AttnParams()
+        p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal = len(q), max(q), 8, 1, 128, 1
+        return FA.prefill_plan(p, q, k, torch.device(DEV))
+    assert plan([2048], [32768]).n_wg > 0                    # Sarathi chunk on a prefix
+    assert plan([8192], [8192]).n_wg == 0                    # whole prompt
+    assert plan([2048, 2048], [32768, 32768]).n_wg == 0      # batch

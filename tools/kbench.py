@@ -93,7 +93,7 @@ def prefill(variant):
         tag = ""
         if WORKLIST:          # host-planned work list (vattn_prefill_plan) where the planner wants one
             from vattention_amd import flash_attn as FA
-            pl = FA.prefill_plan(p, [n], [c + n], DEV, force_tiles=WL_TILES, persistent=PERSIST)
+            pl = FA.prefill_plan(p, [n], [c + n], DEV, force_tiles=WL_TILES, persistent=PERSIST, drawn=DRAWN)
             if pl.t is not None:
                 pl.attach(p)
                 need = K.klib().vattn_attn_workspace_bytes(C.byref(p))
@@ -168,6 +168,7 @@ def decode(variant):
 ONLY = None
 ROTATE = False
 WORKLIST = False
+DRAWN = False
 PERSIST = True       # work lists walked by persistent workgroups (prefill64p_kernel); --per-piece: one workgroup per piece (prefill64_kernel)
 WL_TILES = 0
 MEGA = 1
@@ -181,6 +182,7 @@ if __name__ == "__main__":
         SPLITS = tuple(int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(","))
     WORKLIST = "--worklist" in sys.argv
     PERSIST = "--per-piece" not in sys.argv
+    DRAWN = "--drawn" in sys.argv        # persistent workgroups draw their pieces (default: host-assigned queues)
     if os.environ.get("KBENCH_PERSIST_MAX_BLOCKS"):      # A/B: let the big balanced grids take a persistent list too
         from vattention_amd import flash_attn as _FA
         _FA.PERSISTENT_MAX_BLOCKS = int(os.environ["KBENCH_PERSIST_MAX_BLOCKS"])

@@ -39,6 +39,33 @@ def _run(cmd):
 NO_SPILL_KERNELS = {"prefill64_kernels.hip": "prefill64_kernel", "prefill64p_kernels.hip": "prefill64p_kernel"}
 
 
+# prefill64p_kernel receives its queue tickets in v255 asynchronously (an atomic issued by inline asm, read a tile step later): no other
+# instruction of the kernel may touch that register.  Checked on the generated device assembly.
+RESERVED_VGPR = {"prefill64p_kernels.hip": (255, (r"^global_atomic_add v255, ", r"^v_readfirstlane_b32 s\d+, v255$"))}
+
+
+def _check_reserved_vgpr(hipcc, flags, src, index, allowed):
+    import re
+    r = subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", src, "-o", "-"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("could not produce the device assembly of %s for the reserved-register check" % src)
+    single, tuples = re.compile(r"\bv%d\b" % index), re.compile(r"\bv\[(\d+):(\d+)\]")
+    bad, hits = [], 0
+    for line in r.stdout.splitlines():
+        t = line.split(";")[0].strip()
+        if not t or t.startswith("."):
+            continue
+        if not (single.search(t) or any(int(a) <= index <= int(b) for a, b in tuples.findall(t))):
+            continue
+        if any(re.match(a, t) for a in allowed):
+            hits += 1
+        else:
+            bad.append(t)
+    if bad or not hits:
+        raise RuntimeError("%s: v%d is reserved for the asynchronous queue ticket, but it %s" % (
+            os.path.basename(src), index, ("is also used by: " + "; ".join(bad[:4])) if bad else "is never used"))
+
+
 def _compile(hipcc, flags, src, obj):
     guard = NO_SPILL_KERNELS.get(os.path.basename(src))
     if not guard:
@@ -60,6 +87,8 @@ def _compile(hipcc, flags, src, obj):
                 bad.append("%s: %s" % (name, line.split("remark:")[1].split("[-R")[0].strip()))
     if not seen:
         raise RuntimeError("no resource remarks for %s in %s: the spill guard saw nothing" % (guard, src))
+    if os.path.basename(src) in RESERVED_VGPR:
+        _check_reserved_vgpr(hipcc, flags, src, *RESERVED_VGPR[os.path.basename(src)])
     if bad:
         raise RuntimeError("register spills in a kernel that counts its own vmcnt:\n  " + "\n  ".join(bad))
 

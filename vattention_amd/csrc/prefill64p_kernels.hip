@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p,
     const int nq = (gridDim.x & 7) == 0 ? 8 : 1, qx = (int)blockIdx.x % nq, gq = (int)gridDim.x / nq;
     const int n_q = (n_items - qx + nq - 1) / nq;        // positions of this queue; its tickets are 0 .. n_q - 1 (gq of them draw nothing)
     int* const lds_word = (int*)(smem + 86016);           // the 16 spare bytes behind the V ring: wave 0 hands the drawn piece to the others
-    unsigned tk = 0;                                      // wave 0, lane 0: the ticket in flight
     if (DYN) {
         q_idx = (int)blockIdx.x;
         if (q_idx >= n_items) return;
@@ -78,16 +77,20 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p,
         q_end = __builtin_amdgcn_readfirstlane(p.pf_wg_first[blockIdx.x + 1]);
         if (q_idx >= q_end) return;
     }
-    // one draw from this queue's counter by lane 0 of the calling wave (wave 0 calls it); the old value arrives in `tk` — behind a
-    // vmcnt wait the caller provides: the compiler does not see this instruction
+    // One draw from this queue's counter by lane 0 of the calling wave (wave 0 calls it).  The old value arrives in v255 a memory round trip
+    // LATER — behind a vmcnt wait the caller provides (a tile step's) — so it must not be an output of the statement: the compiler would
+    // take the register's content at the statement for the value and might copy it away (park it in the accumulator file across the
+    // step) before it has arrived.  v255 is named only here and in publish(); the allocator hands registers out from v0 upward and this
+    // kernel needs fewer than 250: vattention_amd/build.py checks on the generated assembly that nothing else touches it.
     auto draw = [&]() {
         unsigned long long save;
-        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
-                     : "=&v"(tk), "=&s"(save) : "v"((unsigned)(qx * 4)), "v"(1u), "s"(ctr) : "memory");
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
+                     : "=&s"(save) : "v"((unsigned)(qx * 4)), "v"(1u), "s"(ctr) : "memory", "v255");
     };
     // the ticket that arrived -> the piece it stands for (or -1), into the LDS word; the queue's last ticket zeroes the counter for the next launch
     auto publish = [&]() {
-        const int tv = (int)__builtin_amdgcn_readfirstlane(tk);
+        int tv;
+        asm volatile("v_readfirstlane_b32 %0, v255" : "=s"(tv) : : "memory");
         const int pos = qx + nq * (gq + tv);
         if (tv == n_q - 1 && lane == 0) ctr[qx] = 0;
         if (lane == 0) *lds_word = pos < n_items ? pos : -1;

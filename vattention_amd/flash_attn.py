@@ -375,8 +375,13 @@ class _PrefillPlan:
             p.pf_wg_first = base + 32 * (self.n_items + self.n_blocks) if self.n_wg and not self.drawn else None
 
 
-PERSISTENT = True          # work lists are walked by persistent workgroups (csrc/prefill64p_kernels.hip); False: one workgroup per piece (A/B, tests)
-PERSISTENT_DRAWN = True    # ... which DRAW their pieces from a device counter (balances like the hardware dispatcher); False: host-assigned queues
+# Work lists walked by PERSISTENT workgroups (csrc/prefill64p_kernels.hip) — where that measured faster on every box it was tried on
+# (profiles/r05_p64p_kbench_ab.txt, r05_p64p_legs_ab_*.txt): ONE entry, a chunk on a prefix of at least 4 x its length (Sarathi chunks:
+# equal pieces, several per workgroup: +1 ... +4 %).  Whole prompts and ragged batches keep one workgroup per piece: the persistent
+# queues measured -7 ... -10 % on the tensor-parallel rank's batched prompts inside the replay (either queue form) and +-0 on Llama-3-8B's.
+# "always" / "never": every list / none (tests, tools/kbench.py, bench.py --per-piece-prefill).
+PERSISTENT = "chunks"
+PERSISTENT_DRAWN = False   # True: the workgroups DRAW their pieces from a device counter; False: host-assigned queues (measured better: see above)
 PERSISTENT_MAX_BLOCKS = 2048      # (entry, head, query block) triples up to which a launch gets a list at all in the persistent form
 
 
@@ -385,7 +390,11 @@ def prefill_plan(p, q_lens_host, k_lens_host, dev, force_tiles: int = 0, persist
     most this many 64-key tiles whatever the planner's own rules say (tests, A/B); persistent: None = the module default; max_wg: at
     most this many persistent workgroups (0: one per CU)."""
     B = p.b
-    persist = PERSISTENT if persistent is None else bool(persistent)
+    if persistent is None:
+        q0 = int(q_lens_host[0]) if q_lens_host is not None else p.seqlen_q
+        persist = PERSISTENT == "always" or (PERSISTENT == "chunks" and B == 1 and int(k_lens_host[0]) >= 5 * q0)
+    else:
+        persist = bool(persistent)
     if p.rotary_cos_sin or (p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7:
         persist = False          # (the persistent kernel has neither the fused-RoPE form nor the 8-byte store path)
     q_of = q_lens_host if q_lens_host is not None else [p.seqlen_q] * B
