@@ -288,8 +288,12 @@ def main():
             res = dynamic_leg(make_runner, mem_for_kv, cap(lengths256, 768), "llama-3-70b", 8, "one TP=8 rank of configs[4]", None, dtype, False)
         elif a.leg == "capacity":
             res = capacity_leg(dev, mem_for_kv)
+        elif a.leg == "c4_rank_share_128k":
+            res = c4_rank_share_leg(make_runner, mem_for_kv)
+        elif a.leg == "hybrid_sarathi":
+            res = hybrid_sarathi_leg(make_runner, mem_for_kv)
         else:
-            raise SystemExit("--leg must be dynamic, dynamic_tp8_rank or capacity")
+            raise SystemExit("--leg must be dynamic, dynamic_tp8_rank, c4_rank_share_128k, hybrid_sarathi or capacity")
         _emit(json.dumps({a.leg: res}))
         return
     if a.qps:       # stand-alone open-loop replay (not a bench line)
@@ -394,15 +398,25 @@ def main():
     # ---- roofline of the attention kernels, from events recorded inside the timed region ----
     traffic = None
     try:       # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 note); configs[1] only
-        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        # (PMC counters cannot be collected inside the timed run: they come from the newest committed separate pass over the SAME two
+        # launches, tools/prof_round.sh -> tools/traffic_json.py; `traffic_source` names the file)
+        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             pth = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pth) and world == 1 and valid:
                 tj = json.load(open(pth))
-                traffic = {"prefill": tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"], "decode": tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"]}
+                traffic = {"prefill": tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"], "decode": tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"],
+                           "source": "profiles/" + name}
                 break
     except Exception:
         traffic = None
     roofs = rooflines(detail, traffic)
+    for key in ("roofline", "roofline_prefill", "roofline_decode"):
+        if key in roofs and traffic:
+            roofs[key]["traffic_source"] = traffic["source"] + " (separate --pmc pass over the same launch, not this run)"
+    if "roofline" in roofs:
+        # how the launches were timed: per-launch HIP event pairs, except decode-only iterations: ONE pair around the
+        # iteration's L back-to-back decode launches (an event pair costs microseconds of its own on 60-150 us launches)
+        roofs["roofline"]["timing"] = "HIP events on the launch stream; prefill per launch, decode-only iterations one pair per %d launches" % L
     if dist is not None and "roofline" in roofs:      # the same kernel's mean launch time on every rank
         for key in ("roofline_prefill", "roofline_decode"):
             mine = roofs.get(key, {}).get("ms_per_launch", 0.0)
