@@ -704,7 +704,9 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
     // grids of several rounds of workgroups whose longest is no longer than ~a round's share are balanced by the dispatcher's
     // longest-first order already (and, when not ragged, keep the XCD-grouped grid order)
     const bool balanced = nblk >= 4 * kSlots || (nblk >= kSlots && longest * 4 <= avg * 5);
-    if (!forced_T && !ragged && balanced && !persist) return 0;
+    // (round 5: a "balanced" launch of fewer than four rounds is still priced below — greedy longest-first leaves a one-prompt launch on a
+    // tensor-parallel shard 10-20 % above its average load, and cutting only its LONGEST blocks in two brings that back)
+    if (!forced_T && !ragged && balanced && !persist && nblk >= 4 * kSlots) return 0;
     auto price = [&](long T, long* pieces_out, long* rows_out) -> double {
         std::vector<long> cost;
         long rows = 0;
@@ -738,8 +740,24 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
         // merge pass: every partial row is written once and read once (516 B each way) at ~3 TB/s, in half-tile units of ~0.9 us
         return (double)makespan + (double)rows * 1032.0 / 3.0e12 / 0.9e-6;
     };
+    // candidate piece lengths T: the longest block cut in {1 .. 16} equal shares, and FRACTIONS of the longest block in between — T = 0.9 x
+    // longest cuts only the top tenth of the blocks (in two), which is what evens out the tail of a greedy longest-first schedule at the
+    // price of few partials (modelled on the replay's tensor-parallel batches: 4-7 % on one-prompt launches, tools/)
     static const long kShares[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
-    double best = 1e30;
+    static const double kFractions[] = {0.95, 0.9, 0.85, 0.8, 0.75, 0.7, 0.65, 0.6, 0.55, 0.45, 0.4, 0.36, 0.3};
+    std::vector<long> cands;
+    for (long ns_max : kShares) {
+        const long t_c = (longest + ns_max - 1) / ns_max;
+        if (t_c < kMinPiece && ns_max > 1) break;      // pieces shorter than ~12 tiles are all prologue
+        cands.push_back(t_c);
+    }
+    for (double f : kFractions) {
+        const long t_c = (long)(longest * f);
+        if (t_c >= kMinPiece && t_c * 16 >= longest) cands.push_back(t_c);
+    }
+    std::sort(cands.begin(), cands.end(), std::greater<long>());
+    cands.erase(std::unique(cands.begin(), cands.end()), cands.end());
+    double best = 1e30, uncut = 1e30;
     long T = 0, best_rows = 0;
     if (forced_T) {
         long pieces = 0;
@@ -747,17 +765,18 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
         if (longest > 16 * T) T = (longest + 15) / 16;
         if (price(T, &pieces, &best_rows) >= 1e30 || pieces > cap_items) return 0;
     }
-    bool search = !forced_T;
-    if (!forced_T && (balanced || longest < 48)) { T = longest; search = false; }      // nothing to cut, only to compact (persistent: to chain)
-    for (long ns_max : kShares) {
+    const bool search = !forced_T && nblk < 4 * kSlots && longest >= 48;      // several rounds of blocks / short key walks: nothing to cut
+    if (!forced_T && !search) T = longest;
+    for (long t_c : cands) {
         if (!search) break;
-        const long t_c = (longest + ns_max - 1) / ns_max;
-        if (t_c < kMinPiece && ns_max > 1) break;      // pieces shorter than ~12 tiles are all prologue
         long pieces = 0, rows = 0;
         const double c = price(t_c, &pieces, &rows);
+        if (t_c == longest) uncut = c;
         if (pieces > cap_items) continue;
         if (c < best - 1e-9) { best = c; T = t_c; best_rows = rows; }
     }
+    // a launch the dispatcher balances on its own keeps its blocks whole unless cutting buys at least 2 %
+    if (search && balanced && T < longest && best > 0.98 * uncut) { T = longest; best_rows = 0; }
     if (T == 0 || (!forced_T && !ragged && !persist && T >= longest)) return 0;      // nothing worth cutting, nothing to compact: the default launch
     if (best_rows > 0x7fffffffL - 4096) return 0;
     int n = 0, nb = 0;
