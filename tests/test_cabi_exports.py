@@ -275,7 +275,7 @@ def test_prefill_plan_lists_every_key_tile_once_and_cuts_only_long_blocks():
 
     # one TP=8 rank of Llama-3-70B (8 query heads): whole prompts of 8 k / 4 k / 2 k, a 7 k prompt, a batch of three prompts
     n, lens, counts = check([8192], [8192], 8, 1)
-    assert 256 < n < 700 and max(lens) <= 67                   # the short blocks stay whole, the long ones are cut in two or three
+    assert 256 < n < 700 and max(lens) <= 90                   # the short blocks stay whole, the long ones are cut (round 5: in two, at 0.7 x the longest)
     check([7344], [7344], 8, 1)
     check([4096], [4096], 8, 1)
     assert plan([2048], [2048], 8, 1)[0] == 0                   # no key walk of 48 tiles: default launch
