@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-prompt and batched prefill launches of a TP8 rank (8 query / 1 kv head) through whatever work list the loaded library's planner
-builds (one workgroup per piece), timed alone on resident tensors.  Used by tools/r05_planner_ab.sh to A/B two planners."""
+builds (one workgroup per piece), timed alone on resident tensors.  Used by tools/r05/r05_planner_ab.sh to A/B two planners."""
 import os
 import sys
 

@@ -3,7 +3,7 @@
 # launch gap of the prefill launches while the mapper thread creates the pool's handles (rocprofv3 --kernel-trace --hip-trace, no
 # counters); (c) two waves per SIMD (8 waves x 32 rows, prefill_kernel) against one wave per SIMD (prefill64) on the configs[1] prompt,
 # times alternating + one --pmc pass for the matrix-pipe duty of both.
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=gpurun_out/r05c1; mkdir -p $O; R=$PWD
 echo "== (a) telemetry =="
 python -m vattention_amd.telemetry --probe 2>&1 | tail -4 | tee $O/telemetry_probe.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, GPU call 2: the persistent work-list kernel (prefill64p_kernel) — parity first, then same-box A/B against the one-workgroup-
 # per-piece launch of the same planner family (tools/kbench.py --worklist [--per-piece]).
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=gpurun_out/r05c2; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_prefill_persistent.py -m gpu -q -x --timeout 300 > $O/tests_persistent.log 2>&1; echo "persistent tests rc=$?" | tee -a $O/tests_persistent.log; tail -15 $O/tests_persistent.log
 if grep -q "rc=0" $O/tests_persistent.log; then

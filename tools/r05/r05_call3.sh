@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, GPU call 3: persistent kernel with the pre-based descriptors (no re-base code inside the step) — parity, A/B, then the g1
 # table and one short bench run with the new legs.
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=gpurun_out/r05c3; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_prefill_persistent.py -m gpu -q -x --timeout 300 > $O/tests_persistent.log 2>&1; echo "persistent tests rc=$?" | tee -a $O/tests_persistent.log; tail -4 $O/tests_persistent.log | cut -c1-300
 timeout 900 python -m pytest tests/test_gpu_attention.py tests/test_gpu_fuzz.py -m gpu -q --timeout 600 -k "work_list or fuzz" > $O/tests_more.log 2>&1; echo "more tests rc=$?" | tee -a $O/tests_more.log; tail -4 $O/tests_more.log | cut -c1-300

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, GPU call 4: persistent work lists inside the dynamic legs, same box, alternating (bench.py --leg X [--per-piece-prefill])
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=gpurun_out/r05c4; mkdir -p $O
 for i in 1 2; do
   for leg in dynamic_tp8_rank dynamic; do

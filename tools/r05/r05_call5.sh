@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, GPU call 5: persistent workgroups with DRAWN queues — parity, kbench A/B, then the two dynamic legs persistent vs per piece, alternating
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=gpurun_out/r05c5; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_prefill_persistent.py -m gpu -q -x --timeout 300 > $O/tests_persistent.log 2>&1; echo "persistent tests rc=$?" | tee -a $O/tests_persistent.log; tail -4 $O/tests_persistent.log | cut -c1-300
 grep -q "rc=0" $O/tests_persistent.log || exit 0

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, GPU call 7: the "chunks" policy of the persistent queues inside a replay (one TP2 rank's 128 k request in 16 k chunks), alternating
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=gpurun_out/r05c7; mkdir -p $O
 for i in 1 2; do
   for mode in "" "--per-piece-prefill" "--persistent-prefill"; do

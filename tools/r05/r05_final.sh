@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, final GPU call: the whole -m gpu suite, the bench line, the round's rocprofv3 evidence (kernel stats of the bench workload and of
 # both dynamic legs, PMC traffic and SQ counters), the N = 2 stdout check over the gloo hook, the plan gate, the reference-wrapper bench.
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=gpurun_out/r05final; mkdir -p $O
 t0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -q -rs --timeout 900 > $O/tests.log 2>&1; echo "tests rc=$?" | tee -a $O/tests.log; tail -5 $O/tests.log | cut -c1-300
