@@ -33,6 +33,7 @@ int main(void) {
     printf("tensors %d ndim %u\n", vattn_num_tensors(m), lay.ndim);
     pages = vattn_reserve_physical_pages(m, 64ull * 65536);
     printf("pool %lld\n", (long long)pages);
+    printf("pool_ready %lld\n", (long long)vattn_wait_pool_ready(m, 1000));      /* 0: nothing left to create ahead of demand (inline mode) */
     slot = vattn_alloc_new_batch_idx(m, 300);
     printf("slot %d\n", slot);
     lens[slot] = 300;
@@ -87,6 +88,18 @@ int main(void) {
                /* (a block's last share is open-ended: causal whole prompt, query block qb sees 4 (qb + 1) tiles of 64 keys) */
                (pitems[0].tile_end < 4 * (pitems[0].qb + 1) ? pitems[0].tile_end : 4 * (pitems[0].qb + 1)) - pitems[0].tile_begin,
                (pitems[n > 0 ? n - 1 : 0].tile_end < 4 * (pitems[n > 0 ? n - 1 : 0].qb + 1) ? pitems[n > 0 ? n - 1 : 0].tile_end : 4 * (pitems[n > 0 ? n - 1 : 0].qb + 1)) - pitems[n > 0 ? n - 1 : 0].tile_begin);
+        {   /* the same prompt for PERSISTENT workgroups (round 5): pieces assigned to at most 64 queues, grouped by queue */
+            static int32_t wg_first[257];
+            int32_t c4[4];
+            int nw, w, ok = 1;
+            n = vattn_prefill_plan_wg(&p, qlen, klen, pitems, 4096, pblocks, 512, wg_first, 64, c4);
+            nw = c4[3];
+            for (w = 0; w < nw; w++) ok &= wg_first[w] < wg_first[w + 1];
+            printf("prefill_plan_wg items %d queues %d first %d last %d nonempty %d\n", n, nw, wg_first[0], wg_first[nw], ok);
+            /* ... and with drawn queues: nothing assigned, the list stays longest first */
+            n = vattn_prefill_plan_wg(&p, qlen, klen, pitems, 4096, pblocks, 512, NULL, 0, c4);
+            printf("prefill_plan_drawn items %d queues %d\n", n, c4[3]);
+        }
         {   /* what WILL be launched, asked on the host (no GPU): configs[1]'s whole prompt and its batch-16 decode step */
             vattn_attn_params d;
             vattn_plan_desc desc;

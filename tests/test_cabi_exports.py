@@ -108,6 +108,12 @@ def test_plain_c_client_drives_the_boundary(tmp_path):
     assert m and 64 < int(m.group(1)) <= 768 and int(m.group(2)) == 1 and int(m.group(3)) > 4 and int(m.group(4)) < 902 // 3, text
     m = re.search(r"prefill_plan items (\d+) split_blocks (\d+) partial_rows (\d+) first_piece_tiles (\d+) last_piece_tiles (\d+)", text)
     assert m and int(m.group(1)) > 256 and int(m.group(2)) > 0 and int(m.group(3)) % 256 == 0 and int(m.group(4)) >= int(m.group(5)), text
+    m2 = re.search(r"prefill_plan_wg items (\d+) queues (\d+) first (\d+) last (\d+) nonempty (\d+)", text)
+    # (priced for 64 queues and the chained per-piece overhead: its own cuts) every queue non-empty, the offsets span the list
+    assert m2 and int(m2.group(1)) >= 256 and int(m2.group(2)) == 64 and int(m2.group(3)) == 0 and int(m2.group(4)) == int(m2.group(1)) and m2.group(5) == "1", text
+    m3 = re.search(r"prefill_plan_drawn items (\d+) queues (\d+)", text)
+    assert m3 and int(m3.group(1)) >= 256 and int(m3.group(2)) == 256, text
+    assert "pool_ready 0" in text
     assert "lab_variant -11" in text and "measurement build" in text
     # vattn_attn_plan_describe from plain C: configs[1]'s prompt = prefill64 over a 4096-workgroup grid, its batch-16 decode step = the
     # device-planned stream decomposition on 768 workgroups + a merge launch; another header's block is refused
