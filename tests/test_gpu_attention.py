@@ -28,9 +28,9 @@ def _check(out_gpu, ref64, ref32, dtype, what):
         "%s: kernel err %.3e vs reference-numerics err %.3e" % (what, err.max().item(), e_ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1 << 20, 1 << 19, 1, 65536, 131072, 262144, 1 << 24, 1 << 25],
+@pytest.mark.parametrize("variant", [0, 1 << 20, 1 << 19, 1, 65536, 131072, 262144, 1 << 24, 1 << 25, 1 << 27, (1 << 27) | (1 << 20)],
                          ids=["stream", "stream_in_launch_merge", "grid_heuristics", "plain_read", "wg512", "wg1024", "two_register_sets",
-                              "striped_everywhere", "single_sequence_contiguous"])
+                              "striped_everywhere", "single_sequence_contiguous", "xcd_consecutive_ranges", "xcd_local_merge"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("B,G,Hkv,lens", [
     (1, 8, 4, [777]),                    # Yi-6B group size
@@ -59,7 +59,7 @@ def test_decode_parity(B, G, Hkv, lens, dtype, variant):
     kc2, vc2 = kc.clone(), vc.clone()
     ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :max_len], vc2[:, :max_len], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     kg, vg = kc.to(DEV), vc.to(DEV)
-    stream = variant in (0, 1 << 20, 1 << 24, 1 << 25)
+    stream = variant in (0, 1 << 20, 1 << 24, 1 << 25, 1 << 27, (1 << 27) | (1 << 20))
     for splits in (0, 1, 3) + ((-1, -2, -5, -37, -300) if stream else ()):
         kgi, vgi = kg.clone(), vg.clone()
         for rep in range(2 if stream else 1):          # (the in-launch merge's tickets reset themselves: a second call must work too)
@@ -422,7 +422,7 @@ def test_decode_stream_plan(Hq, Hkv, B, lo, hi, nwg, append):
     ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :ml], vc2[:, :ml], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     dev = lambda t: t.to(DEV) if t is not None else None
     outs = {}
-    for variant in (0, 1 << 20):
+    for variant in (0, 1 << 20, 1 << 27, (1 << 27) | (1 << 20)):      # bit 27 (lab): the ranges of one XCD are consecutive; with bit 20 a sequence inside one XCD is handed over in its L2
         kg, vg = kc.to(DEV), vc.to(DEV)
         for rep in range(2):
             out, lse = flash_attn_with_kvcache(dev(q), kg[:, :ml], vg[:, :ml], dev(kn), dev(vn), cache_seqlens=dev(cl), cache_batch_idx=dev(idx),
@@ -432,7 +432,8 @@ def test_decode_stream_plan(Hq, Hkv, B, lo, hi, nwg, append):
         assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)
         outs[variant] = (out.cpu(), lse.cpu())
     # (the two merges fold the records in chunks of 16 / 8: the same sum up to the order of a few fp32 multiply-adds)
-    assert (outs[0][0].float() - outs[1 << 20][0].float()).abs().max().item() <= 1e-3 and torch.allclose(outs[0][1], outs[1 << 20][1], atol=1e-4, rtol=1e-5)
+    for v in (1 << 20, 1 << 27, (1 << 27) | (1 << 20)):
+        assert (outs[0][0].float() - outs[v][0].float()).abs().max().item() <= 1e-3 and torch.allclose(outs[0][1], outs[v][1], atol=1e-4, rtol=1e-5), v
     if not append:      # an empty sequence attends to nothing: zeros, LSE = +inf as FlashAttention reports it
         for b, l in enumerate(lens):
             if l == 0:

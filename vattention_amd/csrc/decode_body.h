@@ -779,7 +779,8 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     // grid (workgroups per head, kv heads): consecutive workgroup ids — consecutive XCDs — stream consecutive ranges of ONE kv head.  [The
     // kv head as the fastest index (the heads of one range dispatched together) measured 5-7 % slower on every shape, profiles/r04_decode_stream.txt.]
     const int hk = blockIdx.y / gblocks, gb = blockIdx.y % gblocks;
-    const int nwg = gridDim.x, w = blockIdx.x;
+    const int nwg = gridDim.x;
+    int w = blockIdx.x;
     const int X = stream_switch_tiles(p);
     constexpr unsigned RB = StreamRec<NB, HD>::kFloats * 4u;
     // LAB instrumentation (tools/decode_skew_probe.py, variant bit 22): the buffer behind softmax_lse receives, from its 32 KiB mark on,
@@ -798,15 +799,37 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     if (kLab && ts && tid == 0) ts[3 * wg_id + 1] = wall_clock64();
     const StreamGeom geo = stream_geom(pl.total, pl.maxt, p.b, nwg);
     const bool striped = decode_striped_all(p) && geo.uniform && geo.S > 1;      // (lab; the product stripes the single-sequence launch only)
+    // LAB (variant bit 27): the ranges of ONE XCD are consecutive — physical workgroup x (XCD x % 8: the
+    // dispatcher deals consecutive workgroup ids round-robin over the XCDs) takes logical range (x % 8) * n8 + x / 8, n8 = ranges per XCD —
+    // so a sequence's pieces share an L2 unless the sequence straddles one of the seven seams.  With the in-launch merge (bit 20) such a
+    // sequence is handed over INSIDE that L2: plain (write-back) record stores, a ticket that is an L2 atomic (workgroup scope: no sc1,
+    // performed in this XCD's L2, not at the memory side), record loads that only skip the vL1D; a straddling sequence keeps the
+    // device-scope protocol.  Only the active ranges are dealt (a short tile space uses a third of the grid: see stream_geom).
+    int n8 = 0;
+    if (kLab && (p.variant & (1 << 27)) && (nwg & 7) == 0) {
+        const int nact = geo.uniform ? p.b * geo.S : (pl.total + geo.T - 1) / geo.T;
+        n8 = (nact + 7) >> 3;
+        w = ((int)blockIdx.x & 7) * n8 + ((int)blockIdx.x >> 3);
+        if (((int)blockIdx.x >> 3) >= n8 || w >= nact) return;
+    }
+    auto seq_is_xcd_local = [&](const int b, const int first_rec, const int cnt) -> bool {
+        const int fw = first_rec - b;
+        return n8 > 0 && fw / n8 == (fw + cnt - 1) / n8;
+    };
     auto publish_and_merge = [&](const int b, const int first_rec, const int cnt) {      // LAB: in-launch merge
-        // publish: this workgroup's record stores have left the CU (write-through), then ONE device-scope ticket
+        // publish: this workgroup's record stores have left the CU (write-through, or into the XCD's L2), then ONE ticket
+        const bool local = seq_is_xcd_local(b, first_rec, cnt);
+        int* const c = counters + ((int64_t)b * p.h_k + hk) * gblocks + gb;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) s_ticket = atomicAdd(counters + ((int64_t)b * p.h_k + hk) * gblocks + gb, 1);
+        if (tid == 0) s_ticket = local ? __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicAdd(c, 1);
         __syncthreads();
         if (s_ticket == cnt - 1) {
             decode_stream_merge<T, HD, NB>(p, first_rec, cnt, hk, gb, gblocks, b);
-            if (tid == 0) __hip_atomic_store(counters + ((int64_t)b * p.h_k + hk) * gblocks + gb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                if (local) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     };
     // the current piece (all wave-uniform): sequence, its slot and visible length, tiles [tb, te), the sequence's records
@@ -877,7 +900,8 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     for (;;) {
         const unsigned blk = stream_table_bytes(p.b) + (((unsigned)(w + b) * p.h_k + hk) * gblocks + gb) * RB;
         if (tb == 0 && hk == 0 && gb == 0 && tid == 0) stream_publish_seq(p, b, first_rec, cnt);      // (the owner of the sequence's first piece)
-        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, 0, tb, te, cnt == 1 ? 1 : (kLab && counters) ? 3 : 2, slot, lk, blk,
+        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, 0, tb, te,
+                                       cnt == 1 ? 1 : (kLab && counters && !seq_is_xcd_local(b, first_rec, cnt)) ? 3 : 2, slot, lk, blk,
                                        done, total, striped ? geo.S : 1);
         done += te - tb;
         if (kLab && cnt > 1 && counters != nullptr) publish_and_merge(b, first_rec, cnt);      // product: the records are merged by decode_stream_combine_kernel

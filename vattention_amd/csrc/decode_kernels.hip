@@ -206,7 +206,11 @@ int stream_nwg(const vattn_attn_params* p) {
     if (kLab && (decode_shape(p) || decode_pf2(p) || (p->variant & (1 | 256)) || decode_inline_merge(p, 2, 1))) return 0;      // lab shapes / protocols keep the old grid
     const long slots = decode_nb(p) == 2 ? 512 : 768;      // resident workgroups of decode_stream_kernel (its launch bounds)
     const long gps = p->h_k;
-    if (p->num_splits < 0) return (int)std::min<long>(-(long)p->num_splits, 65535);
+    const bool xcd_ranges = kLab && (p->variant & (1 << 27)) != 0;      // lab (XCD-consecutive ranges, decode_stream_kernel): whole rounds of the 8 XCDs
+    if (p->num_splits < 0) {
+        const long forced = std::min<long>(-(long)p->num_splits, 65535);
+        return (int)(xcd_ranges ? std::min(65528L, (forced + 7) & ~7L) : forced);
+    }
     // ONE sequence has nothing to balance, and the two-block workgroups of wide GQA groups (16 < G <= 32) measure 16 % slower on this path
     // (mqa G32 B16 @ 16 k: 42.5 vs 36.5 us): both keep the grid heuristics
     if (p->b < 2 || decode_nb(p) == 2) return 0;
@@ -214,7 +218,9 @@ int stream_nwg(const vattn_attn_params* p) {
     // pieces per sequence, on average: at least one tile per wave and piece, at most 48 (pick_splits' measurements: a piece shorter than
     // ~700 keys costs more in prologue and merge than it returns once the chip is full, short contexts still want every CU busy)
     const long per_seq = std::min(48L, std::max(1L, max_tiles / 4));
-    return (int)std::min(std::max(1L, slots / gps), (long)p->b * per_seq);
+    const long nwg = std::min(std::max(1L, slots / gps), (long)p->b * per_seq);
+    if (xcd_ranges) return (int)std::max(8L, nwg & ~7L);
+    return (int)nwg;
 }
 static size_t stream_workspace_bytes(const vattn_attn_params* p, int nwg) {
     const size_t rf = decode_nb(p) == 2 ? (size_t)(32 * p->d + 32) : (size_t)(16 * p->d + 32);
