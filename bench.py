@@ -77,7 +77,12 @@ WORKLOADS = {
                   "thousands of batch-1 iterations at the end of every step), max_batch_size 256, pool = 0.9 x HBM - 12 GiB per rank, "
                   "megacache layout with 8 MiB pages (stands in for 256 KiB pages)"),
 }
-TIMER_EVERY = {"static": 1, "dynamic": 8}       # time every k-th launch of each attention operation
+# time every k-th launch of each attention operation.  The stride of the replay legs is COPRIME with every model's layer count: a replay
+# issues one prefill launch per layer and iteration, so a stride of 8 on 80 (or 32) layers samples layer 0 in every iteration and seven
+# layers never — and layer 0's event pair opens on an idle GPU, before the host has built and uploaded the iteration's plan, so it reads
+# host latency + kernel.  Rounds 4-5 (stride 8) therefore under-read the replay legs' prefill fractions by the planner's host time x 10 / 8
+# (profiles/r05_timer_stride.txt: same box, same library: stride 8 vs 7); whole-leg tokens/s never depended on it.
+TIMER_EVERY = {"static": 1, "dynamic": 7}
 
 
 def parse():
@@ -94,6 +99,7 @@ def parse():
                     "without the collectives (checks the tensor-parallel workloads where only one GPU is visible; NOT a bench line)")
     ap.add_argument("--leg", default="", help="run ONLY one of the legs outside the timed region (dynamic, dynamic_tp8_rank, capacity) and print it: "
                     "what tools/prof_round.sh profiles (NOT a bench line)")
+    ap.add_argument("--timer-every", type=int, default=0, help="A/B: event-pair stride of the replay legs (default 7; rounds 4-5 used 8); NOT the bench line")
     ap.add_argument("--per-piece-prefill", action="store_true", help="A/B: NO persistent workgroups anywhere (prefill64p_kernel off); NOT the bench line")
     ap.add_argument("--persistent-prefill", action="store_true", help="A/B: EVERY prefill work list through persistent workgroups; NOT the bench line")
     ap.add_argument("--qps", type=float, default=0.0, help="run ONLY the open-loop replay (Poisson arrivals, reference recipe) at this rate and print it")
@@ -252,6 +258,8 @@ def main():
     from vattention_amd import vattention
     from vattention_amd.attention.timers import drain_op_timers_detail, enable_op_timers
     from vattention_amd.replay import CacheConfig, HotPathRunner, ModelConfig, ParallelConfig
+    if a.timer_every > 0:
+        TIMER_EVERY["dynamic"] = a.timer_every
     if a.per_piece_prefill or a.persistent_prefill:
         from vattention_amd import flash_attn as _FA
         _FA.PERSISTENT = "never" if a.per_piece_prefill else "always"
@@ -265,7 +273,7 @@ def main():
     if a.requests:
         w["requests"] = a.requests
     dtype = torch.float16                                    # benchmark_runner.py:81
-    valid = not (a.layers or a.ctx or a.rank_of or a.requests or a.per_piece_prefill or a.persistent_prefill)
+    valid = not (a.layers or a.ctx or a.rank_of or a.requests or a.per_piece_prefill or a.persistent_prefill or a.timer_every)
 
     def make_runner(model_name, tp, ctx, page, batch, backend_name, mem_bytes, layers=0):
         model = ModelConfig.named(model_name, dtype=dtype, max_model_len=ctx, attention_backend=backend_name)
@@ -657,6 +665,8 @@ def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, 
                               "megacache 8 MiB pages, pool = 0.9 x HBM - 12 GiB; first pass on a fresh pool whose handles were created inside "
                               "reserve_physical_pages (pool_ready_s), second pass warm"}
     res.update(digest(first))
+    res["timing"] = ("HIP events on the launch stream; hybrid iterations: every %d-th launch of each operation (a stride coprime with the layer count: every layer is "
+                     "sampled equally often), decode-only iterations: one pair around the iteration's launches, every %d-th iteration" % (TIMER_EVERY["dynamic"], TIMER_EVERY["dynamic"]))
     # the pool's handles exist before the first admission (vattention.reserve_physical_pages waits for the mapper thread: what the
     # reference's reserve commits, cudaInternal.h:45-59); "cold" below = the first pass on that fresh pool, "warm" = the second pass
     res["pool_ready_s"] = first.get("_pool_ready_s")

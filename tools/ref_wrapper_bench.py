@@ -63,7 +63,7 @@ def run(which: str, impl: str, layers: int, mem: int, lengths):
             r.sample_kv_util = False
             step()                                       # warm-up (cold pool, plan caches)
             torch.cuda.synchronize()
-            enable_op_timers(True, every=1 if which == "static" else 8)
+            enable_op_timers(True, every=1 if which == "static" else 7)
             t0 = time.perf_counter()
             tokens = step()
             torch.cuda.synchronize()
