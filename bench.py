@@ -424,7 +424,8 @@ def main():
     if "roofline" in roofs:
         # how the launches were timed: per-launch HIP event pairs, except decode-only iterations: ONE pair around the
         # iteration's L back-to-back decode launches (an event pair costs microseconds of its own on 60-150 us launches)
-        roofs["roofline"]["timing"] = "HIP events on the launch stream; prefill per launch, decode-only iterations one pair per %d launches" % L
+        roofs["roofline"]["timing"] = ("HIP events on the launch stream; prefill per launch, decode-only iterations one pair per %d launches; replay legs (other.dynamic_*): "
+                                       "every %d-th launch / iteration, a stride coprime with the layer count" % (L, TIMER_EVERY["dynamic"]))
     if dist is not None and "roofline" in roofs:      # the same kernel's mean launch time on every rank
         for key in ("roofline_prefill", "roofline_decode"):
             mine = roofs.get(key, {}).get("ms_per_launch", 0.0)

@@ -89,3 +89,18 @@ def test_external_fragmentation_is_what_the_pool_cannot_hand_out_as_whole_groups
     from vattention_amd.replay import ReplayStats
     st = ReplayStats()
     assert st.ext_frag_max == 0.0 and st.ext_frag_samples == 0
+
+
+def test_replay_timer_stride_samples_every_layer_equally_often():
+    """bench.py times every k-th launch of each attention operation in the replay legs; a replay issues one prefill launch per layer and
+    iteration, so k must be coprime with every model's layer count (k = 8 on 80 / 32 layers timed layer 0 of every iteration — whose
+    event pair also holds the host's planning — and seven of eight layers never: profiles/r05_timer_stride.txt)."""
+    from vattention_amd.replay import ModelConfig
+    k = bench.TIMER_EVERY["dynamic"]
+    for name in ("yi-6b", "llama-3-8b", "yi-34b", "llama-3-70b"):
+        L = ModelConfig.named(name).num_layers
+        assert math.gcd(k, L) == 1, (name, L, k)
+        # over L consecutive iterations (L x L launches) every layer is timed, and equally often
+        timed = [n % L for n in range(L * L * k) if n % k == 0]
+        counts = [timed.count(layer) for layer in range(L)]
+        assert min(counts) == max(counts) > 0, (name, counts[:4])

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p,
             if (j == 29 && RING > 3) kf2 = kfrag(ksm_next, 2);
             SCHED_FENCE();
         }
-        // the tile just scored may need masking (at the seam the mask scalars are already the next piece's: VATTN_STEP)
+        // the tile just scored may need masking (at the seam the mask scalars are already the next piece's: VATTN_GLUE)
         if (__builtin_expect(t >= t_mask, 0)) {
             mask_tile(t, nxt, Lk_c, qoff_c, kend_c);
             mx0 = row_max(nxt, 0);
