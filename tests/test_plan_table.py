@@ -188,3 +188,58 @@ def test_drawn_queues_keep_the_list_longest_first_and_only_choose_the_workgroup_
     c3 = (C.c_int32 * 3)()
     assert K.klib().vattn_prefill_plan(C.byref(p), ql, ql, ref, 17 * nblk + 16, blocks, nblk + 16, c3) == n
     assert all((items[i].b, items[i].h, items[i].qb) == (ref[i].b, ref[i].h, ref[i].qb) for i in range(n)), "same list as the per-piece launch takes"
+
+
+def _work_list_digest(Hq, Hkv, q_lens, k_lens, mode, max_wg):
+    import ctypes as C
+    import hashlib
+    from vattention_amd import kernels as K
+    p = K.AttnParams()
+    B = len(q_lens)
+    p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal, p.seqlen_k = B, max(q_lens), Hq, Hkv, 128, 1, max(k_lens)
+    n_blk = sum((q + 255) // 256 for q in q_lens) * Hq
+    cap_i, cap_b = 17 * n_blk + 16, n_blk + 16
+    items, blocks = (K.PrefillItem * cap_i)(), (K.PrefillItem * cap_b)()
+    ql, kl = (C.c_int32 * B)(*q_lens), (C.c_int32 * B)(*k_lens)
+    if mode == 0:
+        counts = (C.c_int32 * 3)()
+        n = K.klib().vattn_prefill_plan(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, counts)
+        wf = b""
+    else:
+        counts = (C.c_int32 * 4)()
+        wg = (C.c_int32 * 257)()
+        n = K.klib().vattn_prefill_plan_wg(C.byref(p), ql, kl, items, cap_i, blocks, cap_b, wg, max_wg, counts)
+        wf = bytes(wg)
+    h = hashlib.sha256()
+    h.update(bytes(items)[:max(n, 0) * C.sizeof(K.PrefillItem)] + bytes(blocks)[:counts[1] * C.sizeof(K.PrefillItem)] + wf)
+    return [n] + list(counts) + [h.hexdigest()[:16]]
+
+
+def _work_list_cases():
+    import random
+    rnd = random.Random(20260926)
+    out = []
+    for _ in range(48):
+        Hq, Hkv = rnd.choice([(8, 1), (32, 4), (32, 8), (28, 4), (14, 2)])
+        B = rnd.choice([1, 1, 2, 3, 4])
+        q_lens = [rnd.randint(300, rnd.choice([5000, 12000, 30000])) for _ in range(B)]
+        k_lens = [q + (rnd.randint(0, 100000) if rnd.random() < 0.3 else 0) for q in q_lens]
+        mode = rnd.choice([0, 0, 1])
+        out.append((Hq, Hkv, q_lens, k_lens, mode, rnd.choice([0, 64, 256]) if mode else 0))
+    return out
+
+
+def test_work_lists_are_the_pinned_ones():
+    """The planner's output on 48 seeded launches (one to four prompts, with and without a prefix, per-piece and host-assigned queues) against
+    tests/golden/prefill_work_lists.json: the candidate pricing was re-implemented in round 5 (count-per-load replay instead of a sort and a
+    heap per candidate — 6 000 random launches compared list for list against the previous build) and must keep choosing the same lists, which
+    are the ones the GPU timings of profiles/r05_planner_ab.txt were taken on.  Regenerate with VATTN_REGEN_PLAN_GOLDEN=1 after a DELIBERATE change."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "prefill_work_lists.json")
+    got = [_work_list_digest(*c) for c in _work_list_cases()]
+    if os.environ.get("VATTN_REGEN_PLAN_GOLDEN") == "1":
+        json.dump({"cases": [list(c) for c in _work_list_cases()], "lists": got}, open(path, "w"))
+    want = json.load(open(path))["lists"]
+    assert got == want
+    assert sum(1 for g in got if g[2] > 0) >= 10          # (a fair share of them cut blocks)

@@ -707,35 +707,54 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
     // (round 5: a "balanced" launch of fewer than four rounds is still priced below — greedy longest-first leaves a one-prompt launch on a
     // tensor-parallel shard 10-20 % above its average load, and cutting only its LONGEST blocks in two brings that back)
     if (!forced_T && !ragged && balanced && !persist && nblk >= 4 * kSlots) return 0;
+    // The replay of the dispatcher, priced per candidate.  Every head repeats a block's pieces, so the piece costs are kept as (cost,
+    // multiplicity) pairs — a few dozen for a one-prompt launch.  Costs and loads are small integers (half-tile units) and the least
+    // loaded CU's load never decreases, so the CUs' loads are a COUNT PER LOAD VALUE with a pointer at the smallest occupied one: k
+    // pieces of one cost move k CUs from load m to m + cost in one step.  The loads after every assignment are the same multiset that
+    // sorting all pieces and a std::priority_queue of 256 loads produce (equal costs, equal loads are interchangeable), for a
+    // twentieth of the host time: the plan is built once per engine iteration in front of layer 0's launch, with the GPU idle (round 5:
+    // 0.9-2.7 ms -> 0.05-0.15 ms for one to three prompts on a TP8 rank, tools/plan_time.py).
+    std::vector<std::pair<long, long>> cm;             // (cost in half-tile units, how many pieces have it)
+    std::vector<int> at_load;                          // CUs per load value
     auto price = [&](long T, long* pieces_out, long* rows_out) -> double {
-        std::vector<long> cost;
-        long rows = 0;
+        cm.clear();
+        long rows = 0, pieces = 0, total = 0, maxc = 0;
         for (long t : blk_tiles) {
             long ns = (t + T - 1) / T;
             if (ns < 1) ns = 1;
             if (ns > 16) return 1e30;
             const long per = (t + ns - 1) / ns;
-            for (int h = 0; h < p->h; h++) {
-                for (long s_ = 0; s_ < ns; s_++) {
-                    long tb = s_ * per, te = tb + per;
-                    if (tb > t) tb = t;
-                    if (te > t) te = t;
-                    cost.push_back(2 * (te - tb) + kOvh + (ns > 1 ? 3 : 0));     // half-tile units
-                }
-                if (ns > 1) rows += 256 * ns;
+            for (long s_ = 0; s_ < ns; s_++) {
+                long tb = s_ * per, te = tb + per;
+                if (tb > t) tb = t;
+                if (te > t) te = t;
+                const long c = 2 * (te - tb) + kOvh + (ns > 1 ? 3 : 0);
+                cm.emplace_back(c, (long)p->h);
+                total += c * p->h;
+                maxc = c > maxc ? c : maxc;
+            }
+            pieces += ns * p->h;
+            if (ns > 1) rows += 256 * ns * p->h;
+        }
+        std::sort(cm.begin(), cm.end(), std::greater<std::pair<long, long>>());      // longest first
+        // (the least loaded CU is never above the final average, total / kSlots: no load exceeds that + the largest cost)
+        at_load.assign((size_t)(total / kSlots + maxc + 2), 0);
+        at_load[0] = (int)kSlots;
+        size_t mn = 0;
+        long makespan = 0;
+        for (const auto& cmi : cm) {
+            long left = cmi.second;
+            while (left > 0) {
+                while (at_load[mn] == 0) mn++;
+                const long k = left < at_load[mn] ? left : at_load[mn];
+                at_load[mn] -= (int)k;
+                at_load[mn + (size_t)cmi.first] += (int)k;
+                const long l = (long)mn + cmi.first;
+                makespan = l > makespan ? l : makespan;
+                left -= k;
             }
         }
-        std::sort(cost.begin(), cost.end(), std::greater<long>());
-        std::priority_queue<long, std::vector<long>, std::greater<long>> cu;   // load of every CU, least loaded on top
-        for (long i = 0; i < kSlots; i++) cu.push(0);
-        long makespan = 0;
-        for (long c : cost) {
-            const long l = cu.top() + c;
-            cu.pop();
-            cu.push(l);
-            makespan = l > makespan ? l : makespan;
-        }
-        *pieces_out = (long)cost.size();
+        *pieces_out = pieces;
         *rows_out = rows;
         // merge pass: every partial row is written once and read once (516 B each way) at ~3 TB/s, in half-tile units of ~0.9 us
         return (double)makespan + (double)rows * 1032.0 / 3.0e12 / 0.9e-6;
