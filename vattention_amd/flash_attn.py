@@ -377,9 +377,10 @@ class _PrefillPlan:
 
 # Work lists walked by PERSISTENT workgroups (csrc/prefill64p_kernels.hip) — where that measured faster on every box it was tried on
 # (profiles/r05_p64p_kbench_ab.txt, r05_p64p_legs_ab_*.txt): ONE entry, a chunk on a prefix of at least 4 x its length (Sarathi chunks:
-# equal pieces, several per workgroup: +1 ... +4 %).  Whole prompts and ragged batches keep one workgroup per piece: the persistent
-# queues measured -7 ... -10 % on the tensor-parallel rank's batched prompts inside the replay (either queue form) and +-0 on Llama-3-8B's.
-# "always" / "never": every list / none (tests, tools/kbench.py, bench.py --per-piece-prefill).
+# equal pieces, several per workgroup: +1 ... +4 %).  Whole prompts and ragged batches keep one workgroup per piece: there the host-assigned
+# queues measure EQUAL to it, alone and inside the replay (TP8-rank leg 0.411 always / 0.413 this policy / 0.412 never,
+# profiles/r05_timer_stride.txt), the drawn queues 8-13 % slower alone, and the assignment costs host time in front of layer 0's launch.
+# "always" / "never": every list / none (tests, tools/kbench.py, bench.py --persistent-prefill / --per-piece-prefill).
 PERSISTENT = "chunks"
 PERSISTENT_DRAWN = False   # True: the workgroups DRAW their pieces from a device counter; False: host-assigned queues (measured better: see above)
 PERSISTENT_MAX_BLOCKS = 2048      # (entry, head, query block) triples up to which a launch gets a list at all in the persistent form
