@@ -26,7 +26,7 @@ from the reference's own file by oracle/gen_golden_attn_intree.py and committed 
 mask of its own): it pins softmax(q.k^T/sqrt(d) + mask).v and the LSE, not the operator's semantics — hence still
 "unpinned" in the task's sense.
 
-What pins what (round 4 — "partial" made as tight as the tree allows; there is still no fixture of the OPERATOR itself):
+What pins what (rounds 4 and 6 — "partial" made as tight as the tree allows; there is still no fixture of the OPERATOR itself):
 
     semantic of flash_attn_with_kvcache            pinned by                                                          how
     ---------------------------------------------  -----------------------------------------------------------------  ---------------------------
@@ -36,9 +36,13 @@ What pins what (round 4 — "partial" made as tight as the tree allows; there is
     cache_batch_idx (slot of batch entry b)        op_* cases with permuted / partial slot lists                       composition (row selection)
     cache_seqlens (+ seqlen_new) visible keys      op_* cases, Lk in {1, 5, 63, 64, 65, 300, 4097}                     composition (cut)
     strided [:, :max_len] cache views              op_strided_view                                                     composition
-    bottom-right causal alignment                  op_* chunk cases (mask handed to ref_mha_bmhk)                      OURS, following mask.h:164-196
-    GQA head mapping h -> h // (Hq / Hkv)          op_* cases, groups 1 / 3(MHA) / 4 / 7 / 8                            OURS, following the docstring :1180-1184
-    rows that see no key -> 0, LSE = +inf          op_chunk_longer_than_keys                                           OURS (ref_mha_bmhk gives NaN)
+    bottom-right causal alignment                  the docstring's literal 2 x 5 AND 5 x 2 keep / mask matrices        DOCSTRING flash_attn_interface.py:1192-1202,
+                                                   read back from the operator's output (tests/test_docstring_pins.py,  asserted on this file and on the HIP
+                                                   tests/test_gpu_docstring_pins.py); op_* chunk cases                  kernels (round 6); mask.h:164-196
+    GQA head mapping h -> h // (Hq / Hkv)          the docstring's "6 heads over 2: heads 0, 1, 2 -> kv head 0,         DOCSTRING :1187-1190, asserted on this file
+                                                   3, 4, 5 -> kv head 1" (same two test files); op_* groups 1-8         and on the HIP kernels (round 6)
+    rows that see no key -> 0                      the docstring's ":1203 If the row of the mask is all zero, the       DOCSTRING :1203 (output); LSE = +inf for
+                                                   output will be zero" on the 5 x 2 example; op_chunk_longer_than_keys  such a row stays OURS (ref_mha_bmhk: NaN)
     fp16 agreement at atol = 1e-3                  tests/test_gpu_attention.py::test_pod_sweep_shapes_...               the reference's own GPU-vs-GPU
                                                    (POD sweep shapes, pod_attn/tests/attn_sweep.py:82-97)              criterion, kernels vs this file
 
