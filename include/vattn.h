@@ -158,7 +158,8 @@ int vattn_cancel_premap(vattn_t* m, int slot);
 /* Lazy pool (the default: handles are created on first map or by the idle mapper thread): block until the mapper has created the
  * handles it creates ahead of demand — the WHOLE pool when it has at most 40 000 pages, a window of 4 096 below the pool's frontier
  * otherwise — or `timeout_ms` have passed (< 0: no limit).  Returns the number of handles still to be created ahead of demand (0 =
- * ready; always 0 with VATTN_FLAG_EAGER_CREATE / VATTN_FLAG_NO_MAPPER_THREAD).  The reference commits every page inside
+ * ready; always 0 with VATTN_FLAG_EAGER_CREATE / VATTN_FLAG_NO_MAPPER_THREAD), or a negative VATTN_ERR_* when a creation ahead of
+ * demand failed (VATTN_ERR_DRIVER: the pool does not fit the device — where the reference aborts inside reserve) or the mapper is dead.  The reference commits every page inside
  * reserve_physical_pages (/root/reference/vattention/cudaInternal.h:45-59); an engine calls this once after reserve, before it admits
  * requests, so that no launch of the first iterations shares the driver with a burst of hipMemCreate calls (round 5:
  * profiles/r05_cold_pool.md — the kernels are not slowed by concurrent creation, the LAUNCHES are late).  Thread-safe. */

@@ -164,7 +164,8 @@ int32_t vattn_prefill_plan(const vattn_attn_params* p, const int32_t* q_lens_hos
  * (a piece that follows another in a workgroup's queue pays its epilogue and a fragment of a tile, not a cold prologue), so finer cuts
  * pay off, and are assigned to at most `max_wg` workgroups (<= 0: one per CU, 256) longest first, each to the least loaded one among
  * the workgroups of its kv head's XCD class (workgroup w runs on XCD w % 8; class = kv head modulo the classes that divide 8, so that an
- * XCD's L2 keeps seeing one kv head).  items_out comes back GROUPED by workgroup; wg_first_out receives num_wg + 1 offsets;
+ * XCD's L2 keeps seeing one kv head).  items_out comes back GROUPED by workgroup; wg_first_out receives num_wg + 1 offsets — THE
+ * CALLER PROVIDES ROOM FOR (max_wg > 0 ? max_wg : 256) + 1 = at most 257 int32 VALUES (the function has no capacity argument for it);
  * counts_out[4] = {items, split blocks, partial rows, num_wg}.  wg_first_out == NULL: no assignment (drawn queues, see pf_num_wg):
  * items_out stays longest first, only num_wg is chosen.  Returns the number of items (0: default launch, as above). */
 int32_t vattn_prefill_plan_wg(const vattn_attn_params* p, const int32_t* q_lens_host, const int32_t* k_lens_host, vattn_prefill_item* items_out,

@@ -2,8 +2,8 @@
 key-tile range) pieces whose K / V tile stream does not stop between pieces — against the oracle, against the one-workgroup-per-piece
 launch of the same pieces (bit for bit), with few long queues (every seam kind: pieces of one, two, three and many tiles, pieces
 without tiles, partial and direct outputs following each other), stale host lengths, strided cache views and the varlen form; both
-queue forms: host-assigned (`drawn=False`) and drawn from the device counter (`drawn=True`, the default), whose counters must be
-back at zero after every launch."""
+queue forms: host-assigned (`drawn=False`: the product default, flash_attn.PERSISTENT_DRAWN = False) and drawn from the device counter
+(`drawn=True`), whose counters must be back at zero after every launch."""
 import ctypes as C
 
 import pytest

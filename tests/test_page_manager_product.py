@@ -167,6 +167,21 @@ def test_wait_pool_ready_returns_once_the_mapper_has_created_the_pool():
     q.pm.close()
 
 
+def test_wait_pool_ready_reports_a_failed_creation_ahead_of_demand():
+    """a hipMemCreate that fails while the idle mapper creates the pool must not read as "ready" — the reference aborts
+    inside reserve (cudaInternal.h:45-59, CHECK_CUDA); here wait_pool_ready returns VATTN_ERR_DRIVER and the reserve drop-in raises."""
+    from tests.impls import fake
+    from vattention_amd import _lib as L
+    cfg = dict(num_layers=2, num_kv_heads=8, head_size=128, max_batch_size=4, max_context_length=8192,
+               itemsize=2, page_size=2 << 20, megacache=False)
+    p = ProductImpl(cfg, flags=0)
+    fake().vattn_fake_fail_create_after(10)                    # the device "runs out" after 10 handles
+    assert p.reserve_physical_pages(256 << 20) == 128
+    assert p.pm.wait_pool_ready(5000) == L.VATTN_ERR_DRIVER
+    assert fake_counters()["n_create"] <= 11
+    p.pm.close()
+
+
 @pytest.mark.parametrize("flags", [0, 4], ids=["mapper_thread", "inline"])
 def test_lifecycle_cleanup_twice_use_after_cleanup_destroy_with_pending_work(flags):
     """Teardown paths of the C ABI: cleanup is idempotent, mutating calls after cleanup are explicit errors (the reference

@@ -196,9 +196,10 @@ int* merge_counters(hipStream_t st, size_t n_ints) {
 }
 
 
-// Counters of the DRAWN queues of the persistent prefill launch (csrc/prefill64p_kernels.hip): 8 ints per (device, stream), zeroed once —
-// every launch leaves them zero (the last draw of a queue resets its counter).  Created on first use; never while the stream is being
-// captured into a graph (NULL then: the caller launches one workgroup per piece; a warm-up call before capture creates them).
+// Counters of the DRAWN queues of the persistent prefill launch (csrc/prefill64p_kernels.hip): 8 ints per (device, stream), zeroed by the
+// caller in front of every drawn launch (launch_prefill_t; the last draw of a queue also resets its counter).  Created on first use; never
+// while the stream is being captured into a graph (NULL then: the caller launches one workgroup per piece; a warm-up call before capture
+// creates them).
 int* queue_counters(hipStream_t st) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, int*> bufs;

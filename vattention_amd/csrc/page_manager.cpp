@@ -345,6 +345,7 @@ int64_t PageManager::reserve_physical_pages(uint64_t free_memory) {   // cudaInt
             std::lock_guard<std::mutex> q(q_mu_);
             frontier_.store(num_pages_);
             precreate_window_.store(num_pages_ <= kPrecreateWholePoolBelow ? num_pages_ : kPrecreateAheadPages);
+            precreate_error_.store(0);
             precreate_left_.store(num_pages_);
         }
         q_cv_.notify_all();
@@ -532,7 +533,9 @@ int64_t PageManager::wait_pool_ready(int64_t timeout_ms) {
     const uint64_t t0 = now_ns();
     for (;;) {
         const uint64_t left = precreate_left_.load(), floor = precreate_floor();
-        if (left <= floor || fatal_.load()) return 0;      // (a failed creation zeroes precreate_left_)
+        if (precreate_error_.load() != 0) return (int64_t)precreate_error_.load();      // hipMemCreate failed ahead of demand (a failed creation also zeroes precreate_left_)
+        if (fatal_.load()) return (int64_t)VATTN_ERR_DRIVER;
+        if (left <= floor) return 0;
         if (timeout_ms >= 0 && now_ns() - t0 >= (uint64_t)timeout_ms * 1000000ull) return (int64_t)(left - floor);
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
@@ -1048,8 +1051,12 @@ void PageManager::mapper_main() {
             std::lock_guard<std::mutex> e(exec_mu_);
             const uint64_t left = precreate_left_.load();
             if (left != 0 && left > precreate_floor()) {
-                if (left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) precreate_left_.store(0);
-                else precreate_left_.store(left - 1);
+                if (left > handles_.size() || ensure_created((uint32_t)(left - 1)) != 0) {
+                    // creation ahead of demand failed (out of device memory: the reference aborts inside reserve, cudaInternal.h:45-59):
+                    // remembered for wait_pool_ready; the pages are created on demand from here on and a step that needs one reports it
+                    precreate_error_.store(VATTN_ERR_DRIVER);
+                    precreate_left_.store(0);
+                } else precreate_left_.store(left - 1);
             }
         } else {
             std::this_thread::yield();

@@ -133,6 +133,7 @@ private:
     std::vector<uint64_t> handles_;              // page id -> backend handle (0 = not created yet)
     std::vector<uint8_t> created_;
     std::vector<uint32_t> create_order_;         // page ids in creation order: handles are released oldest-first (see cleanup)
+    std::atomic<int> precreate_error_{0};       // VATTN_ERR_* of a creation ahead of demand that failed (wait_pool_ready reports it)
     std::atomic<uint64_t> precreate_left_{0};   // ids [0, precreate_left_) still to be looked at, top down
     std::atomic<uint64_t> join_wait_ns_{0};
     std::atomic<uint64_t> frontier_{0};          // lowest page id ever handed out by the pool (ids below it were never used)

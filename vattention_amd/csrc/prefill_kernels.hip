@@ -587,7 +587,10 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
             bool persistent = p->pf_num_wg > 0 && !p->rotary_cos_sin && ((p->o_row_stride | p->o_head_stride | p->o_batch_stride) & 7) == 0;
             if (persistent && !p->pf_wg_first) {      // drawn queues need the library's counters (none while a graph is being captured before they exist)
                 ctr = queue_counters(st);
-                persistent = ctr != nullptr;
+                // the counters are zeroed IN FRONT OF every drawn launch, stream-ordered (a memset node when captured): a graph replayed
+                // on another stream beside eager launches on the capture stream, or a launch that was aborted, must not leave tickets
+                // behind for the next one (the kernel's own reset by the last draw stays — it costs nothing)
+                persistent = ctr != nullptr && hipMemsetAsync(ctr, 0, 16 * sizeof(int), st) == hipSuccess;
             }
             if (persistent) launch_prefill64p(p, st, ctr);
             else launch_prefill64(p, st, 1, nullptr, 0);

@@ -316,7 +316,10 @@ counters = {"prefill_calls": 0, "lengths_from_page_manager": 0, "plan_built": 0,
 def _cached_prefill_plan(p, klens, dev):
     # keyed on the STREAM too: the tables travel by a copy queued on the stream current at build time, and nothing orders a launch on
     # another stream behind that copy
-    key = (p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal, tuple(klens), dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    # ... and on what decides the FORM of the list: the persistent-queue switches, fused RoPE and the output stride alignment
+    # (both force one workgroup per piece: prefill_plan) — a list built under one policy is not reused under another
+    key = (p.b, p.seqlen_q, p.h, p.h_k, p.d, p.is_causal, tuple(klens), dev.index, torch.cuda.current_stream(dev).cuda_stream,
+           PERSISTENT, PERSISTENT_DRAWN, bool(p.rotary_cos_sin), bool((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7))
     pl = _plan_cache.get(key)
     if pl is None:
         if len(_plan_cache) >= 64:

@@ -163,20 +163,34 @@ class Sampler:
                                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         except OSError as e:
             self.error = str(e)
+            return self
+        # the child's lines are drained as they come (a reader thread that only sleeps in read()): left in the pipe they fill its 64 KiB
+        # after about a thousand samples and the child blocks in print — the means would then cover the head of a long region only
+        import threading
+        self._lines = []
+        self._reader = threading.Thread(target=self._drain, args=(self.proc.stdout, self._lines), daemon=True)
+        self._reader.start()
         return self
+
+    @staticmethod
+    def _drain(pipe, lines):
+        try:
+            for line in pipe:
+                lines.append(line)
+        except Exception:      # noqa: BLE001
+            pass
 
     def stop(self):
         if self.proc is None:
             return
         try:
             self.proc.stdin.close()
-            out = self.proc.stdout.read()
+            self._reader.join(timeout=10)
             self.proc.wait(timeout=10)
         except Exception:      # noqa: BLE001
             self.proc.kill()
-            out = ""
         self.proc = None
-        for line in out.splitlines():
+        for line in list(self._lines):
             try:
                 d = json.loads(line)
             except ValueError:

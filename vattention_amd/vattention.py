@@ -69,6 +69,7 @@ def init_kvcache(num_layers: int, num_kv_heads: int, head_size: int, max_batch_s
 
 
 _wait_pool = True
+POOL_READY_TIMEOUT_MS = 600_000     # a 259 GB pool of 2 MiB pages is 98-125 s of hipMemCreate; never wait forever on a wedged mapper
 pool_ready_seconds = 0.0       # what the last reserve_physical_pages spent waiting for the pool's handles (introspection: bench.py)
 
 
@@ -88,8 +89,12 @@ def reserve_physical_pages(free_memory: int) -> int:
     if _wait_pool:
         import time
         t0 = time.perf_counter()
-        _require().wait_pool_ready(-1)
+        left = _require().wait_pool_ready(POOL_READY_TIMEOUT_MS)
         pool_ready_seconds = time.perf_counter() - t0
+        if left < 0:      # the reference aborts inside reserve when the pool cannot be committed (cudaInternal.h:45-59, CHECK_CUDA)
+            raise RuntimeError("reserve_physical_pages: creating the pool's physical handles failed (error %d): the pool does not fit the device" % left)
+        if left > 0:
+            raise RuntimeError("reserve_physical_pages: the mapper thread created no handle for %.0f s (%d left): wedged driver?" % (POOL_READY_TIMEOUT_MS / 1e3, left))
     return n
 
 
