@@ -106,6 +106,11 @@ def parse():
     return ap.parse_args()
 
 
+def valid_or_dry(a) -> bool:
+    """the N > 1 extras also run in the reduced dry runs (--layers / --requests over the gloo hook), not under the A/B switches"""
+    return not (a.rank_of or a.per_piece_prefill or a.persistent_prefill or a.timer_every or a.ctx)
+
+
 def spawn_ranks(a) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (one per GPU)."""
     import socket
@@ -202,6 +207,19 @@ def rooflines(detail: dict, traffic=None) -> dict:
         dom = max(est, key=est.get)
         out["roofline"] = dict(out["roofline_" + dom], dominant_of=sorted(est))
     return out
+
+
+def mfma_views(roofs: dict, clock_mhz, traffic) -> None:
+    """adds `frac_at_clock` (achieved / (2.5 PF x clock / 2400 MHz)) and `mfma_busy_frac` (from the committed PMC pass) to the MFMA-bound rooflines"""
+    for key in ("roofline", "roofline_prefill"):
+        r = roofs.get(key)
+        if r and r.get("bound") == "mfma":
+            if clock_mhz:
+                r["frac_at_clock"] = round(r["achieved"] / (MFMA_PEAK_TFLOPS * clock_mhz / 2400.0), 4)
+                r["clock_mhz_mean"] = clock_mhz
+            if traffic and traffic.get("mfma_busy_frac") is not None:
+                r["mfma_busy_frac"] = traffic["mfma_busy_frac"]
+                r["mfma_busy_source"] = traffic["source"] + " (separate --pmc pass over the same launch, not this run)"
 
 
 _REAL_STDOUT = None
@@ -408,12 +426,12 @@ def main():
     try:       # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 note); configs[1] only
         # (PMC counters cannot be collected inside the timed run: they come from the newest committed separate pass over the SAME two
         # launches, tools/prof_round.sh -> tools/traffic_json.py; `traffic_source` names the file)
-        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             pth = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pth) and world == 1 and valid:
                 tj = json.load(open(pth))
                 traffic = {"prefill": tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"], "decode": tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"],
-                           "source": "profiles/" + name}
+                           "mfma_busy_frac": tj["prefill_yi6b_n32702"].get("mfma_busy_frac"), "source": "profiles/" + name}
                 break
     except Exception:
         traffic = None
@@ -421,6 +439,11 @@ def main():
     for key in ("roofline", "roofline_prefill", "roofline_decode"):
         if key in roofs and traffic:
             roofs[key]["traffic_source"] = traffic["source"] + " (separate --pmc pass over the same launch, not this run)"
+    # MFMA utilisation the three ways a reader may mean it: `frac` of the 2.5 PF spec peak (2.4 GHz), `frac_at_clock`
+    # of the peak at the shader clock this run sustained (a power-capped part runs this kernel at 1.7-1.9 GHz), and `mfma_busy_frac` =
+    # matrix-pipe duty from the committed PMC pass over the same launch (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) over
+    # GRBM_GUI_ACTIVE / 8 XCDs; like `traffic`, counters cannot be collected inside the timed run)
+    mfma_views(roofs, (telemetry or {}).get("clock_mhz_mean"), traffic)
     if "roofline" in roofs:
         # how the launches were timed: per-launch HIP event pairs, except decode-only iterations: ONE pair around the
         # iteration's L back-to-back decode launches (an event pair costs microseconds of its own on 60-150 us launches)
@@ -435,6 +458,42 @@ def main():
             if key in roofs:
                 roofs[key]["ms_per_launch_by_rank"] = [round(float(x.item()), 4) for x in gl]
     op_ms = {k: round(v["ms"] * (v["n"] / v["timed"] if v["timed"] else 0.0), 2) for k, v in detail.items()}
+
+    # ---- N > 1, outside the timed region: (a) `scaling_reference` — the SAME step once more on every rank with the control-plane
+    # exchange switched off: one rank's share of the work on its own, what `bench.py --rank-of N` measures on a single GPU; value /
+    # that = what the exchange and the ranks' skew cost.  (b) `scale_series` — the fixed Yi-34B 128 k request at this N (the main
+    # workload itself at N = 2 / 4; run here at N = 8) ----
+    scaling_reference = series = None
+    if dist is not None and valid_or_dry(a):
+        hook_saved, runner.iter_hook = runner.iter_hook, None
+        pairs_saved = dict(pairs)                        # (the cpu_baseline scales by the pairs of the TIMED steps)
+        barrier()
+        t1 = time.perf_counter()
+        tk_ref = one_step()
+        torch.cuda.synchronize()
+        dt_ref = time.perf_counter() - t1
+        runner.iter_hook = hook_saved
+        pairs.update(pairs_saved)
+        tr = torch.tensor([dt_ref], dtype=torch.float64, device=red_dev)
+        gl = [torch.zeros_like(tr) for _ in range(world)]
+        dist.all_gather(gl, tr)
+        per_rank = [float(x.item()) for x in gl]
+        scaling_reference = {"what": "one more step on every rank WITHOUT the control-plane exchange (a rank's share on its own, = bench.py --rank-of %d on one GPU)" % world,
+                             "tokens_per_s_slowest_rank": round(tk_ref / max(per_rank), 2), "seconds_by_rank": [round(x, 4) for x in per_rank],
+                             "value_over_reference": round((tokens / dt) / (tk_ref / max(per_rank)), 4)}
+        if w["model"] == "yi-34b" and w["ctx"] == 131072 and not a.requests:
+            series = {"n_gpus": world, "tokens_per_s": round(tokens / dt, 2), "seconds": round(dt / a.steps, 3), "same_as": "value (the main workload of this N is the series' workload)"}
+        else:
+            def mx(x):
+                t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            runner.close()
+            runner = None
+            try:
+                series = scale_series_leg(lambda *args: make_runner(*args, layers=a.layers), mem_for_kv, world, hook_saved, mx)
+            except Exception as e:      # noqa: BLE001  (every rank fails alike: shapes and memory are the same)
+                series = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- N = 1 extras, outside the timed region ----
     extras = {}
@@ -475,6 +534,7 @@ def main():
             "one TP=8 rank of configs[4]: llama-3-70b, 8/1 heads, 80 layers (40 KB of KV per token: 256 sequences fit at full depth); decode "
             "lengths capped at 768", True, dtype, False)
         leg("c4_rank_share_128k", c4_rank_share_leg, make_runner, mem_for_kv)
+        leg("scale_series", scale_series_leg, make_runner, mem_for_kv, 1)
         leg("hybrid_sarathi", hybrid_sarathi_leg, make_runner, mem_for_kv)
         leg("open_loop", open_loop_leg, make_runner, mem_for_kv, lengths256, 6.0, 256)
         leg("capacity", capacity_leg, dev, mem_for_kv)
@@ -520,7 +580,7 @@ def main():
             # roofline, prefill vs the MFMA roofline — are read from the same place whichever kernel dominates the step; plus the two
             # fractions of each dynamic leg (ragged launches, accounted per launch)
             pick = lambda r: None if not r else {k: r.get(k) for k in ("bound", "frac", "achieved", "peak", "unit", "ms_per_launch", "bytes_per_launch", "flops_per_launch",
-                                                                       "traffic", "launches_timed") if r.get(k) is not None}
+                                                                       "traffic", "launches_timed", "frac_at_clock", "mfma_busy_frac", "kernel_us_per_launch") if r.get(k) is not None}
             other = {"decode": pick(roofs.get("roofline_decode")), "prefill": pick(roofs.get("roofline_prefill"))}
             # the dynamic legs: the replay's second pass (warm pool: every handle exists — the serving steady state) and its first
             # (cold pool: the mapper thread is still creating the pool's handles under the first iterations)
@@ -542,6 +602,10 @@ def main():
             out["cold_wave"] = cold
         if tp_check:
             out["tensor_parallel"] = tp_check
+        if scaling_reference:
+            out["scaling_reference"] = scaling_reference
+        if series:
+            out["_series"] = series
         out["_extras"] = extras
     if runner is not None:
         runner.close()
@@ -562,6 +626,7 @@ def main():
         # line: the contract's fields, `roofline` (with both kernels and the dynamic legs' fractions under `other`), `cpu_baseline`, and
         # a digest of the legs.  The details (every leg in full: tens of kilobytes) go to stderr as one {"details": ...} line.
         extras = out.pop("_extras", {})
+        series = out.pop("_series", None) or extras.get("scale_series")
         details = dict(extras)
         for k in ("roofline_prefill", "roofline_decode", "op_ms", "cold_wave"):
             if k in out:
@@ -595,6 +660,10 @@ def main():
             dig["open_loop_qps6"] = {k: extras["open_loop"].get(k) for k in ("request_e2e_time_normalized_p50", "request_e2e_time_normalized_p99", "sync_map_ms_per_step_p99")}
         if extras.get("capacity"):
             dig["capacity"] = {k: extras["capacity"].get(k) for k in ("mapped_over_budget", "mapped_over_hbm", "tokens_resident", "fill_seconds")}
+        if series:
+            # legs.scale_series: the SAME request at every N — read tokens_per_s across the N = 1 / 2 / 4 / 8 lines for a strong-scaling curve
+            dig["scale_series"] = {k: series.get(k) for k in ("n_gpus", "tokens_per_s", "seconds", "prefill_frac", "decode_frac", "same_as", "error") if series.get(k) is not None}
+            dig["scale_series"]["workload"] = "yi-34b (56/8 heads / N, 60 layers), ONE 131072-token request, P:D=500, 16 k chunks, 2 MiB pages: identical at every N (strong scaling)"
         if dig:
             out["legs"] = dig
         _emit(json.dumps(out))
@@ -689,6 +758,40 @@ def dynamic_leg(make_runner, mem_for_kv, lengths, model, tp, what, ab_deferred, 
                                                                   "kv_live_over_mapped_mean_per_iteration", "map_calls", "unmap_calls",
                                                                   "sync_map_ms", "sync_fence_wait_ms", "mapper_thread_map_ms")}
     return res
+
+
+def scale_series_leg(make_runner, mem_for_kv, tp, hook=None, max_over_ranks=None) -> dict:
+    """ONE fixed workload for every N: Yi-34B (56 query / 8 kv heads, 60 layers) tensor-parallel over N GPUs (56/N
+    and 8/N heads per rank), 2 MiB pages, static trace @ 131 072 ctx, P:D = 500, Sarathi 16 k chunks, ONE request end to end — the
+    workload of configs[3] / run_figure_6.sh:32-33 at every degree, so that tokens/s over the N = 1 / 2 / 4 / 8 lines IS a strong-scaling
+    series (the lines' `value`s are BASELINE.json's per-N configs: three different models).  N = 2 / 4 run exactly this as their main
+    workload; N = 1 and N = 8 run it here, outside the timed region.  hook: the per-iteration control-plane exchange of an N > 1 job;
+    max_over_ranks(dt): the job's time."""
+    import torch
+    from vattention_amd.attention.timers import drain_op_timers_detail, enable_op_timers
+    r = make_runner("yi-34b", tp, 131072, 2 << 20, 4, "fa_vattn", mem_for_kv)
+    try:
+        r.iter_hook = hook
+        r.run_static_trace(1, 16384, 500.0, 16384)                   # warm-up: one 16 k request
+        torch.cuda.synchronize()
+        r.stats.__init__()
+        enable_op_timers(True, every=1)
+        t0 = time.perf_counter()
+        r.run_static_trace(1, 131072, 500.0, 16384)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        det = drain_op_timers_detail()
+        enable_op_timers(False)
+        if max_over_ranks is not None:
+            dt = max_over_ranks(dt)
+        roofs = rooflines(det)
+        tk = r.stats.prefill_tokens + r.stats.decode_tokens
+        return {"workload": "yi-34b TP=%d (%d/%d heads per rank, 60 layers), 2 MiB pages, static trace @ 131072 ctx, P:D=500, Sarathi 16 k chunks, ONE request "
+                            "(130810 prefill + 262 decode tokens): the same request at every N" % (tp, r.Hq, r.Hkv),
+                "n_gpus": tp, "tokens": tk, "seconds": round(dt, 3), "tokens_per_s": round(tk / dt, 1),
+                "prefill_frac": (roofs.get("roofline_prefill") or {}).get("frac"), "decode_frac": (roofs.get("roofline_decode") or {}).get("frac")}
+    finally:
+        r.close()
 
 
 def c4_rank_share_leg(make_runner, mem_for_kv) -> dict:

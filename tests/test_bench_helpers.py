@@ -22,6 +22,19 @@ def test_rooflines_pick_the_dominant_kernel_and_scale_sampled_time():
     assert bench.rooflines({}) == {}
 
 
+def test_mfma_utilisation_three_ways():
+    """fraction of the spec peak, of the peak at the sustained clock, and the matrix-pipe duty of the PMC pass"""
+    detail = {"attn_prefill": {"ms": 7.64, "timed": 1, "n": 1, "work": 8.761e12}}
+    r = bench.rooflines(detail, {"prefill": 1})
+    bench.mfma_views(r, 1811.0, {"mfma_busy_frac": 0.655, "source": "profiles/x.json"})
+    assert r["roofline"]["frac"] == round(8.761e12 / 7.64e-3 / 1e12 / 2500.0, 4)
+    assert abs(r["roofline"]["frac_at_clock"] - r["roofline"]["achieved"] / (2500.0 * 1811.0 / 2400.0)) < 1e-4
+    assert r["roofline"]["mfma_busy_frac"] == 0.655 and r["roofline_prefill"]["frac_at_clock"] == r["roofline"]["frac_at_clock"]
+    d = bench.rooflines({"attn_decode": {"ms": 3.0, "timed": 10, "n": 10, "work": 10 * 1.2e9}})
+    bench.mfma_views(d, 1811.0, None)
+    assert "frac_at_clock" not in d["roofline"]            # an HBM-bound kernel's peak does not move with the shader clock
+
+
 def test_cpu_baseline_scales_measured_rates_by_counted_pairs():
     torch.manual_seed(0)
     b = bench.cpu_baseline(torch.float16, 2, 4, 2, 64, 512, 2, 1000, 512 * 513 / 2.0, 3 * 512.0, "test")

@@ -35,6 +35,7 @@ def params(q, kc, vc, cl, idx=None, kn=None, vn=None, causal=True, splits=0, var
     p.is_causal, p.dtype, p.num_splits, p.softmax_scale, p.variant = int(causal), (1 if q.dtype == torch.bfloat16 else 0), splits, q.shape[3] ** -0.5, variant
     p.max_seqlen_k_hint = kc.shape[1]        # the benchmark caches are exactly as long as the sequences
     p.split_reserved = int(os.environ.get("KBENCH_SWITCH_TILES", "-1")) + 1      # stream decode: switch allowance override (tuning)
+    p.split_reserved |= int(os.environ.get("KBENCH_LAB_SUB", "0")) << 16         # lab builds: sub-selector (prefill64 round-6 price list)
     keep = [out, q, kc, vc, cl, idx, kn, vn]
     need = K.klib_for(p.variant).vattn_attn_workspace_bytes(C.byref(p))
     if need:

@@ -33,6 +33,12 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+# The tile steps of the prefill kernels are 64 hand-placed groups written as `#pragma unroll` loops over compile-time group numbers.  LLVM stops
+# honouring the pragma once the unrolled body passes -pragma-unroll-threshold (16 K cost units): the loop then stays a loop, the register arrays
+# are indexed at run time (s_set_gpr_idx) and half the kernel goes to scratch (found in round 6 when 16 MFMAs were added to the step).
+UNROLL_FLAGS = ["-mllvm", "-pragma-unroll-threshold=1000000"]
+
+
 # prefill64_kernel counts its own `vmcnt` around LDS-DMA issued by inline asm: a register spill (scratch access, compiler-inserted
 # waits the hand-placed ones do not know about) silently breaks it, and the kernel sits at the SGPR / VGPR limits.  Its translation unit
 # is therefore compiled with the resource-usage remarks on, and the build FAILS when any instantiation of a guarded kernel spills.
@@ -101,7 +107,7 @@ def build_lib(force=False):
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-inline-asm"] + os.environ.get("VATTN_CXXFLAGS", "").split()
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-inline-asm", *UNROLL_FLAGS] + os.environ.get("VATTN_CXXFLAGS", "").split()
         objdir = os.path.join(ROOT, "build", "obj")
         os.makedirs(objdir, exist_ok=True)
         objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]
@@ -129,7 +135,7 @@ def build_lab(force=False):
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-inline-asm"]
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-inline-asm", *UNROLL_FLAGS]
         objdir = os.path.join(ROOT, "build", "obj_lab")
         os.makedirs(objdir, exist_ok=True)
         objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]

@@ -25,6 +25,16 @@ __device__ __forceinline__ void dma_piece_first(unsigned lds_addr, u32x4 rsrc, u
 template <int OFF> __device__ __forceinline__ void dma_piece_at(unsigned lds_base, u32x4 rsrc, unsigned voff) {
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds" : : "s"(lds_base), "s"(rsrc), "v"(voff), "i"(OFF) : "memory", "m0", "scc");
 }
+// the same with the piece's distance from piece 0 in the SCALAR offset operand (ROWS x row_bytes, formed by one s_mul in the wait state
+// behind the M0 write): every piece of a tile then takes piece 0's per-lane offset — no v_mad per piece (a VALU instruction beside the
+// MFMAs costs 7.3 cycles of this wave, a scalar one 0.3: profiles/r06_p64_price_list.txt).  The scalar offset is part of the descriptor's
+// range check on gfx950 (tools/lab/soffset_probe.cpp: a lane with voffset + soffset >= num_records reads zeros), so rows beyond the
+// sequence's visible length stay unfetched exactly as before.
+template <int OFF, int ROWS> __device__ __forceinline__ void dma_piece_so(unsigned lds_base, u32x4 rsrc, unsigned voff, unsigned row_bytes) {
+    unsigned so;
+    asm volatile("s_add_u32 m0, %1, %6\n\ts_mul_i32 %0, %4, %5\n\tbuffer_load_dwordx4 %3, %2, %0 offen lds"
+                 : "=&s"(so) : "s"(lds_base), "s"(rsrc), "v"(voff), "s"(row_bytes), "n"(ROWS), "i"(OFF) : "memory", "m0", "scc");
+}
 // base + ROWS x row_bytes per lane (row strides are far below 2^24 bytes)
 template <int ROWS> __device__ __forceinline__ unsigned piece_off(unsigned base, unsigned row_bytes) {
     unsigned r;
@@ -63,7 +73,7 @@ __device__ __forceinline__ u32x4 tile_rsrc(const void* base, unsigned bytes) {
 // hipcc does not pad hazards around inline asm: callers keep MFMA results away from VALU readers by program order (an 8-pass
 // MFMA result is readable >= 12 states later) and use the _NOP forms when an A/B/C operand was just written by the VALU.
 template <typename T> struct Mfma;
-#define VATTN_MFMA_STRUCT(TYPE, MNEM)                                                                                              \
+#define VATTN_MFMA_STRUCT(TYPE, MNEM, MNEM4)                                                                                             \
     template <> struct Mfma<TYPE> {                                                                                                \
         using V8 = typename Tr<TYPE>::v8;                                                                                          \
         /* S(vgpr) = A(vgpr) x B(agpr) + 0: the first MFMA of a chain */                                                           \
@@ -81,13 +91,18 @@ template <typename T> struct Mfma;
         static __device__ __forceinline__ void qk_acc_a(f32x16& d, V8 a, V8 b) {                                                   \
             asm volatile(MNEM " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));                                                       \
         }                                                                                                                          \
+        /* l(agpr, 4 equal registers) += the lane's OWN four P values: v_mfma_f32_4x4x4 (16 blocks of 4 lanes, K = 4) with A = ones gives    \
+           D[i][j] = sum_k B[k][j], and lane (block, j) holds exactly B[0..3][j] (round 6: row sums on the matrix pipe) */                  \
+        static __device__ __forceinline__ void rowsum4(f32x4& l, typename Tr<TYPE>::v4 ones, typename Tr<TYPE>::v4 b) {            \
+            asm volatile(MNEM4 " %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(b));                                                   \
+        }                                                                                                                          \
         /* O(agpr) += A(vgpr) x B(vgpr) */                                                                                         \
         static __device__ __forceinline__ void pv(f32x16& o, V8 a, V8 b) {                                                         \
             asm volatile(MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                                       \
         }                                                                                                                          \
     };
-VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16")
-VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16")
+VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16", "v_mfma_f32_4x4x4_16b_f16")
+VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_4x4x4_16b_bf16")
 #undef VATTN_MFMA_STRUCT
 // one scalar f32 add that the SLP vectoriser cannot pack into v_pk_add_f32 (packed f32 VALU beside MFMAs costs more than two
 // plain adds, MI355X_MICROARCH "price of one filler")
