@@ -28,21 +28,22 @@
 namespace vattn_k {
 
 
-// The schedule of the tile step (compile-time constants below): 24 of the tile's 32 exp2 pairs start in phase A, a fragment ring of 4
-// (three fragments ahead of their MFMA), the row-max chain in phase-B groups 8-23, the per-tile wait + barrier in front of group 8, one
-// LDS-DMA piece in groups 9, 12, ... 30.  Every alternative that was measured — other placements, the XOR-swizzled K image, timing
-// ablations, per-group clock stamps, the issue-price list of round 6 — lives in the LAB copy of this kernel, tools/lab/csrc/prefill64_lab.hip
-// (built into tools/lab/libvattn_lab.so only).
-// Round 6 (profiles/r06_p64_price_list.txt, r06_p64_issue_ablation_pmc.txt): the step is bound by what ONE wave can issue to the vector
-// ALU — a VALU instruction beside the MFMAs costs 7.3 cycles (v_exp 10.7, packed-f32 43), a scalar instruction, an s_nop or an
-// s_waitcnt that does not wait 0.3, and the matrix pipe idles a third of the time.  Hence: (1) nothing per-lane that a scalar
-// register can carry stays in the VALU (the scale of the exp2 argument; the distance of an LDS-DMA piece from piece 0 travels in the
-// load's scalar offset instead of a v_mad per piece); (2) the first V^T fragments of phase B are read during the LAST groups of phase A
-// (the first P.V MFMA used to wait a whole LDS round trip with the matrix pipe idle); (3) the row-max chain starts from its first link.
-// What is left per tile is the algorithm's own 64 v_fma + 64 v_exp + 64 v_add + 32 v_cvt_pk + 32 v_max3 and ~20 others against 64 MFMAs.
-template <typename T>
-__global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
-    constexpr int NA = 24, RING = 4, MS = 8, BJ = 8, D0 = 9, DS = 3;
+// ABL bits 0-5: timing ablations for tools/kbench.py (results are WRONG when any is set): bit 0 no LDS-DMA in the steady state,
+// bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the first MFMAs of
+// a phase, bit 5 no f16 packing.  Bit 7 selects the padded K image (the product instantiates ABL = 128; 0 = round 2's XOR-swizzled
+// image, lab).  [Round 2's bit 6 — row sums by v_dot2c over the packed P — measured +-0 (the dot instructions serialise with the
+// MFMA pipe, profiles/r02_issue_probe.txt, r02_prefill64_ablations.md) and was removed in round 3.]
+// NA: exp2 pairs (of the tile's 32) whose stages start in phase A, the rest in phase B.  RING: K / V^T fragment registers in flight
+// (RING - 1 fragments ahead of their MFMA).
+// R6 (round 6): bit 0 = the first three V^T fragments of phase B are read inside the LAST groups of phase A (into the K fragment ring's freed
+// registers) instead of in front of the first P.V MFMA, which then waited a whole LDS round trip with the matrix pipe idle; bit 1 (LAB) =
+// s_memtime stamps at every 8th group of the first 64 tile steps of every wave (tools/lab/p64_stamps.py; behind softmax_lse).
+constexpr int kStampBase = 86528;      // LAB: LDS offset of the stamps (behind the K ring, the V ring and the merge ticket), 8 KiB
+// XTRA (LAB price list, results unchanged): ONE extra instruction of a class behind every MFMA of the tile step (64 per tile): 1 s_nop 0,
+// 2 s_mov (SALU), 3 s_waitcnt that waits for nothing, 4 v_mov (VALU, 4 bytes), 5 v_exp, 6 v_max3 (VALU, 8 bytes, 3 operands), 7 v_pk_fma_f32,
+// 8 v_pk_add_f32, 9 v_add_f32, 10 v_cvt_pk_f16_f32, 11 v_pk_mul_f32
+template <typename T, int ABL, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3, int R6 = 0, int XTRA = 0>
+__global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done, int merge_mode) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int HD = 128;
@@ -53,14 +54,15 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring [2][16 KiB], then V ring [3][16 KiB]; LDS address 0
     // (no static __shared__ in this kernel: the LDS-DMA destinations are ABSOLUTE LDS addresses that assume smem starts at 0; the
     // merge ticket lives in the 16 bytes behind the V ring)
-    // The K image in LDS is stored as 16 pieces of 4 rows, each piece 1088 bytes apart (64
+    // ABL bit 7 (a layout, not an ablation): the K image in LDS is stored as 16 pieces of 4 rows, each piece 1088 bytes apart (64
     // bytes of padding), inside a piece chunk c of row r3 at byte 64*c + 16*r3.  ds_read_b128's lane groups ({0-3,12-15,20-27}, ...)
     // then hit 16 distinct 16-byte slots of the 256-byte bank row WITHOUT an XOR swizzle, so the address of fragment (kk, kb) is
     // one lane-dependent register + the immediate 8704*kb + 128*kk (+ the slot, static because slots go by (t - tb) & 1 and the
     // loop is unrolled twice): no per-fragment address arithmetic in the hot loop.
-    constexpr int KPIECE = 1088;
-    constexpr int KSLOT = 16 * 1088;
-    constexpr int VBASE = 36864;
+    constexpr bool KP = (ABL & 128) != 0;
+    constexpr int KPIECE = KP ? 1088 : 1024;
+    constexpr int KSLOT = KP ? 16 * 1088 : S::kTileBytes;
+    constexpr int VBASE = KP ? 36864 : 2 * S::kTileBytes;
     // MS: first phase-B group of the row-max chain of S'(t+1).  BJ: the phase-B group that opens with the per-tile wait + barrier; the
     // eight DMA pieces go out in groups D0, D0 + DS, ... (all >= BJ).
     static_assert(D0 >= BJ && D0 + 7 * DS < 32, "DMA pieces behind the barrier, inside phase B");
@@ -119,20 +121,20 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
 
     // ---- DMA addressing (tile-invariant per-lane offsets) ----
-    // K piece pc = 4*wave + j holds rows 4*pc .. 4*pc+3: lane i -> row 4*pc + (i & 3), 16-byte chunk i >> 2 of that row
+    // K piece pc = 4*wave + j holds rows 4*pc .. 4*pc+3: lane i -> row 4*pc + (i >> 4), LDS chunk i & 15 <- global chunk (i & 15) ^ (row & 15)
     // V piece pc = 4*wave + j = (d block wave, keys 16*j .. 16*j+15): lane i -> key 16*j + (i >> 2), global chunk 4*wave + (i & 3)
     unsigned koff[4], voff[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int row = 4 * (4 * wave + j) + (lane & 3);
-        koff[j] = (unsigned)row * k_rs_bytes + (unsigned)((lane >> 2) << 4);
+        const int row = 4 * (4 * wave + j) + (KP ? (lane & 3) : (lane >> 4));
+        koff[j] = (unsigned)row * k_rs_bytes + (unsigned)((KP ? (lane >> 2) : ((lane & 15) ^ (row & 15))) << 4);
         const int key = 16 * j + (lane >> 2);
         voff[j] = (unsigned)key * v_rs_bytes + (unsigned)((4 * wave + (lane & 3)) << 4);
     }
     using M = Mfma<T>;
     const unsigned k_lds_wave = (unsigned)(wave * 4 * KPIECE);                 // this wave's four K pieces inside a K slot
     const unsigned v_lds_wave = (unsigned)(VBASE + wave * 4096);               // ... and V pieces inside a V slot
-    auto kslot = [&](int t) { return (t - tb) & 1; };                          // K(t)'s slot of the ring
+    auto kslot = [&](int t) { return KP ? ((t - tb) & 1) : (t & 1); };         // K(t)'s slot of the ring
     auto k_rsrc = [&](int t) -> u32x4 {
         int rem = Lk - t * PF_BN;
         rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
@@ -160,13 +162,17 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         dma_piece(l0 + 3072, r, voff[3]);
     };
 
+    if constexpr ((R6 & 2) != 0) {
+        for (int i = tid; i < 2048; i += 256) ((unsigned*)(smem + kStampBase))[i] = 0u;
+        __syncthreads();
+    }
     // ---- prologue ----
     // A key row past the sequence's end must hold FINITE data in the V image (its probability is exactly 0, and 0 x NaN would poison
     // O).  On gfx950 the DMA writes zeros for a lane beyond the descriptor's bound (vattn_selftest_layouts [6]); the kernel does not
     // lean on that: a workgroup whose key range reaches the sequence's ragged last tile zero-fills the V ring first.  Every other
     // workgroup only ever multiplies rows that the DMA fetched (tiles past `nt` are computed into S' and never used) and skips the
     // 48 KiB of LDS writes and the barrier in front of its first fetch (below the noise in time: profiles/r03_p64_prologue_epilogue.txt).
-    if (nt * PF_BN > Lk) {
+    if (!(ABL & 512) && nt * PF_BN > Lk) {
         const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < (3 * S::kTileBytes) / (256 * 16); i++) *(uint4*)(smem + VBASE + (i * 256 + tid) * 16) = z;
@@ -190,7 +196,13 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         for (int kk = 0; kk < KK; kk++) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (my_q < Sq) {
-                v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+                if constexpr ((ABL & 1024) != 0) {      // LAB A/B: Q read once per workgroup — streaming (nt), so that it does not evict the K/V the XCD shares
+                    typedef unsigned nt4 __attribute__((ext_vector_type(4)));
+                    const nt4 t = __builtin_nontemporal_load((const nt4*)(qptr + 16 * kk + 8 * g));
+                    v = make_uint4(t[0], t[1], t[2], t[3]);
+                } else {
+                    v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+                }
             }
             raw[kk] = as_v8<V8>(v);
         }
@@ -231,11 +243,34 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         for (int a4 = 0; a4 < 2; a4++) l_acc[qc][a4] = 0.f;
     }
 
+    // R6 bit 8: the row sums on the MATRIX pipe.  The tile step is bound by what the wave can ISSUE to the vector ALU (profiles/
+    // r06_p64_price_list.txt: every VALU instruction beside the MFMAs costs 7.3 cycles, a scalar instruction 0.3, and the matrix pipe idles
+    // a third of the time).  v_mfma_f32_4x4x4 (16 independent 4 x 4 blocks of four lanes, K = 4) with A = ones adds the four values a lane
+    // holds in its B operand into that lane's accumulator: 16 of them per tile (one per four packed probabilities) replace the tile's 64
+    // v_add_f32, lane-local like the adds were (the other half-wave holds the other 32 keys; joined in the epilogue).  The sum is over the
+    // probabilities ROUNDED to the I/O dtype — the values the P.V product uses; softmax.h:135-157 sums them before rounding: the difference
+    // is the mean of the roundings, ~2^-12 / sqrt(keys) relative for f16.
+    constexpr bool MSUM = (R6 & 256) != 0;
+    using V4 = typename X::v4;
+    f32x4 lsum[2];
+    V4 ones4;
+    if constexpr (MSUM) {
+#pragma unroll
+        for (int qc = 0; qc < 2; qc++) {
+            lsum[qc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(lsum[qc]));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) ones4[j] = X::cvt(1.0f);
+        asm volatile("" : "+v"(ones4));
+    }
     // LDS fragment addressing: one lane-dependent base per tensor + immediate offsets
-    const unsigned kfrag_lane = (unsigned)((l31 >> 2) * KPIECE + (l31 & 3) * 16 + g * 64);
+    const unsigned kfrag_lane = KP ? (unsigned)((l31 >> 2) * KPIECE + (l31 & 3) * 16 + g * 64) : (unsigned)(l31 * S::kRowBytes);
+    const unsigned kswz = (unsigned)(l31 & 15);
     auto kfrag = [&](const char* ksm, int f) -> V8 {                  // f = 2*kk + kb: K rows 32*kb + l31, d = 16*kk + 8*g ..
         const int kk = f >> 1, kb = f & 1;
-        return *(const V8*)(ksm + kb * 8 * KPIECE + kk * 128 + kfrag_lane);
+        if (KP) return *(const V8*)(ksm + kb * 8 * KPIECE + kk * 128 + kfrag_lane);
+        return *(const V8*)(ksm + kb * 32 * S::kRowBytes + kfrag_lane + (((unsigned)(2 * kk + g) ^ kswz) << 4));
     };
     const int i16 = lane & 15, dh = (lane >> 4) & 1;
     const unsigned vfrag_lane = (unsigned)((4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2);
@@ -283,6 +318,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             for (int r = 0; r < 16; r++) o[i][qc][r] *= alpha;
 #pragma unroll
         for (int a4 = 0; a4 < 2; a4++) l_acc[qc][a4] *= alpha;
+        if constexpr (MSUM) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) lsum[qc][r] *= alpha;
+        }
     };
     // P(t) -> the PV B-operand fragment of key slice ks for query block qc: slot (g, j) <-> P registers 8*(ks&1) + j of key block ks>>1
     auto pack_p = [&](const f32x16 (&pt)[2][2], int ks, int qc) -> V8 {
@@ -326,17 +365,45 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     auto GE = [](int e) { return e < NA ? 1 + (e * 30) / NA : 33 + ((e - NA) * 17) / (32 - NA); };
 #define P64_X0(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3)]
 #define P64_X1(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3) + 1]
-    // the scale as a REAL scalar register: the compiler satisfies "s"(a float the VALU computed) with a vector register, and the fma then
-    // read three vector registers beside a running MFMA (and cost copies)
+    // R6 bit 2: the scale is a REAL scalar register (the compiler satisfies "s"(float computed by the VALU) with a vector register: the
+    // fma then reads three vector registers beside a running MFMA); bit 3: stage order M, E, A inside a group instead of A, E, M
     const unsigned escale_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, escale));
+    // R6 bits 4-5 (LAB, WRONG results: the maximum is not subtracted): the v_fma replaced by a v_mul in the 4-byte VOP2 encoding / in the
+    // 8-byte VOP3 encoding — does the ENCODING SIZE price an instruction beside the MFMAs?  Bit 6 (exact): the same fused multiply-add
+    // from 4-byte instructions only: v_mov tmp, -m ; v_fmac tmp, scale, s (VOP2) ; then v_exp s, tmp.
+    float tmpE[32][2];
+    auto stage_m = [&](f32x16 (&cur)[2][2], int e, int qc) {
+        if (ABL & 2048) return;
+        if constexpr ((R6 & 16) != 0)
+            asm("v_mul_f32_e32 %0, %2, %0\n\tv_mul_f32_e32 %1, %2, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale_s));
+        else if constexpr ((R6 & 32) != 0)
+            asm("v_mul_f32_e64 %0, %2, %0\n\tv_mul_f32_e64 %1, %2, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale_s));
+        else if constexpr ((R6 & 64) != 0)
+            asm("v_mov_b32_e32 %0, %4\n\tv_mov_b32_e32 %1, %4\n\tv_fmac_f32_e32 %0, %5, %2\n\tv_fmac_f32_e32 %1, %5, %3"
+                : "=&v"(tmpE[e][0]), "=&v"(tmpE[e][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)), "v"(nmsub[qc]), "s"(escale_s));
+        else if constexpr ((R6 & 4) != 0)
+            asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale_s), "v"(nmsub[qc]));
+        else
+            asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale), "v"(nmsub[qc]));
+    };
     auto softmax_stages = [&](int G, f32x16 (&cur)[2][2]) {
+        if (ABL & 2) return;
+        if constexpr ((R6 & 8) != 0) {
+#pragma unroll
+            for (int e = 0; e < 32; e++)
+                if (GE(e) - 1 == G) stage_m(cur, e, (e >> 2) & 1);
+        }
 #pragma unroll
         for (int e = 0; e < 32; e++) {
             const int qc = (e >> 2) & 1;
-            if (GE(e) - 1 == G)
-                asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale_s), "v"(nmsub[qc]));
-            if (GE(e) == G) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
-            if (GE(e) + 1 == G)      // (v_pk_add_f32: a packed-f32 instruction beside the MFMAs costs 43 cycles, six plain ones)
+            if constexpr ((R6 & 8) == 0) {
+                if (GE(e) - 1 == G) stage_m(cur, e, qc);
+            }
+            if (GE(e) == G) {
+                if constexpr ((R6 & 64) != 0) asm("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=v"(P64_X0(cur, e)), "=v"(P64_X1(cur, e)) : "v"(tmpE[e][0]), "v"(tmpE[e][1]));
+                else asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
+            }
+            if (GE(e) + 1 == G && !(ABL & 4096) && !MSUM)      // (v_pk_add_f32 was tried: forming the register pairs costs more moves than the adds it saves)
                 asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][0]), "+v"(l_acc[qc][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
         }
     };
@@ -365,9 +432,36 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     // (step t-1), so K(t+3) -> slot of K(t+1) and V(t+2) -> slot of V(t-1) may be issued behind it — one piece every DS-th group from
     // group D0 on (back-to-back pieces in the barrier's own group and the seven after it, round 2's placement, measured 1-2 % slower on
     // boxes that are not pinned at their power limit: profiles/r03_p64_schedules.txt).
+    // LAB (R6 bit 1): per wave 64 steps x 8 stamps of s_memtime (low 32 bits), kept in LDS behind the rings (a global store per stamp
+    // would sit in front of the step's vmcnt(0)) and copied out behind softmax_lse's rows when the workgroup ends
+    int ts_step = 0;
+    unsigned* const ts_lds = (unsigned*)(smem + kStampBase) + wave * 512;
+    auto stamp = [&](int k) {
+        if constexpr ((R6 & 2) != 0) {
+            if (ts_step < 64) {
+                const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+                if (lane == 0) ts_lds[ts_step * 8 + k] = tnow;
+            }
+        }
+    };
+    float xdummy = 1.0f;
+    f32x2 xdummy2 = {1.0f, 1.0f};
+    auto extra = [&]() {
+        if constexpr (XTRA == 1) asm volatile("s_nop 0");
+        else if constexpr (XTRA == 2) { unsigned d; asm volatile("s_mov_b32 %0, 0" : "=s"(d)); }
+        else if constexpr (XTRA == 3) asm volatile("s_waitcnt lgkmcnt(15)");
+        else if constexpr (XTRA == 4) asm volatile("v_mov_b32_e32 %0, 1.0" : "=v"(xdummy));
+        else if constexpr (XTRA == 5) asm volatile("v_exp_f32_e32 %0, %0" : "+v"(xdummy));
+        else if constexpr (XTRA == 6) asm volatile("v_max3_f32 %0, %0, %0, %0" : "+v"(xdummy));
+        else if constexpr (XTRA == 7) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(xdummy2));
+        else if constexpr (XTRA == 8) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(xdummy2));
+        else if constexpr (XTRA == 9) asm volatile("v_add_f32_e32 %0, %0, %0" : "+v"(xdummy));
+        else if constexpr (XTRA == 10) asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(xdummy));
+        else if constexpr (XTRA == 11) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(xdummy2));
+    };
     auto step = [&](int t, const int par, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], V8& kf0, V8& kf1, V8& kf2) {
         // par = (t - tb) & 1, a literal at both call sites: with the padded K layout every K fragment address folds to lane + immediate
-        const int s_cur = par;                                                  // slot of K(t), K(t+2)
+        const int s_cur = KP ? par : (t & 1);                                   // slot of K(t), K(t+2)
         const char* ksm = smem + (s_cur ^ 1) * KSLOT;                           // K(t+1)
         const char* ksm_next = smem + s_cur * KSLOT;                            // K(t+2)
         const char* vsm = smem + VBASE + vs_cur;                                // V(t)
@@ -382,10 +476,12 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         V8 pf[2][2];         // P(t) fragments of the key slice being multiplied and of the next one
         V8 kf[RING];         // RING - 1 fragments (twice as many MFMAs) ahead of their use
         V8 vf[RING];         // V(t)^T fragments of phase B
+        constexpr bool VPRE = (R6 & 1) != 0;
         SCHED_FENCE();
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const int f = i >> 1, qc = i & 1;
+            if ((i & 7) == 0) stamp(i >> 3);
             if (f < RING - 1) {
                 // the fragments read before the previous step ended sit in accumulator registers
                 const V8 a = f == 0 ? kf0 : (f == 1 ? kf1 : kf2);
@@ -393,7 +489,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                 else M::qk_acc_a(nxt[f & 1][qc], a, qf[qc][f >> 1]);
             } else if (i < 4) M::qk_first(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
             else M::qk_acc(nxt[f & 1][qc], kf[f % RING], qf[qc][f >> 1]);
-            if ((i & 1) == 0 && f + RING - 1 < 2 * KK) kf[(f + RING - 1) % RING] = kfrag(ksm, f + RING - 1);
+            extra();
+            if ((i & 1) == 0 && f + RING - 1 < 2 * KK && !((ABL & 16) && f >= 1)) kf[(f + RING - 1) % RING] = kfrag(ksm, f + RING - 1);
             softmax_stages(i, cur);
             // key slice 0 of P(t) (pairs 0-7: exponentiated by group GE(7) <= 12 for NA >= 16) is packed HERE, so the first P.V MFMA
             // of phase B does not wait for eight conversions issued right in front of it
@@ -406,18 +503,24 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             if (i == 21) k_rsrc_advance(rk, k_rows_left, k_tile_b, k_rs_bytes);
             if (i == 23) v_rsrc_advance(rv, v_rows_left, v_tile_b, v_rs_bytes);
             // V(t) landed a step ago: its first fragments are asked for while the last S' MFMAs run (the K ring has stopped reading at i = 24)
-            if (i == 26) vf[0] = vfrag(vsm, 0);
-            if (i == 28) vf[1] = vfrag(vsm, 1);
-            if (i == 30 && RING > 3) vf[2] = vfrag(vsm, 2);
+            if (VPRE && i == 26) vf[0] = vfrag(vsm, 0);
+            if (VPRE && i == 28) vf[1] = vfrag(vsm, 1);
+            if (VPRE && i == 30 && RING > 3) vf[2] = vfrag(vsm, 2);
             SCHED_FENCE();
         }
         // phase B: O^T += V(t)^T.P(t)^T   (32 MFMAs: key slice ks = j>>3, d block (j>>1)&3, query block j&1)
+        if (!VPRE) {
+            vf[0] = vfrag(vsm, 0);
+            vf[1] = vfrag(vsm, 1);
+            if (RING > 3) vf[2] = vfrag(vsm, 2);
+        }
         float mx0 = -INFINITY, mx1 = -INFINITY, g0 = -INFINITY, g1 = -INFINITY, grow = -INFINITY;
         SCHED_FENCE();
 #pragma unroll
         for (int j = 0; j < 32; j++) {
             const int f = j >> 1, ks = j >> 3, qc = j & 1;
-            if (j == BJ) {
+            if ((j & 7) == 0) stamp(4 + (j >> 3));
+            if (j == BJ && !(ABL & 8)) {
                 // this wave's pieces of K(t+2) and V(t+1) (issued one step ago) have landed; behind the barrier everyone's have, and
                 // every wave is past its reads of K(t+1) and V(t-1)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -425,19 +528,33 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             }
             // (a P fragment is packed at least one MFMA group before its first use: no VALU -> MFMA operand hazard to pad)
             M::pv(o[f & 3][qc], vf[f % RING], pf[ks & 1][qc]);
-            if ((j & 1) == 0 && f + RING - 1 < 16) vf[(f + RING - 1) % RING] = vfrag(vsm, f + RING - 1);
+            extra();
+            if ((j & 1) == 0 && f + RING - 1 < 16 && !((ABL & 16) && f >= 1)) vf[(f + RING - 1) % RING] = vfrag(vsm, f + RING - 1);
             softmax_stages(32 + j, cur);
+            // row sums of key slice ks (its P fragments were packed at least two groups ago): four 4x4x4 MFMAs per slice, behind the
+            // first fillers of a group so that they do not queue straight behind the group's own MFMA
+            if constexpr (MSUM) {      // groups 0, 2 of a slice: query block 0 (low, high half of its fragment); 4, 6: block 1
+                if ((j & 7) == 0) M::rowsum4(lsum[0], ones4, __builtin_shufflevector(pf[ks & 1][0], pf[ks & 1][0], 0, 1, 2, 3));
+                if ((j & 7) == 2) M::rowsum4(lsum[0], ones4, __builtin_shufflevector(pf[ks & 1][0], pf[ks & 1][0], 4, 5, 6, 7));
+                if ((j & 7) == 4) M::rowsum4(lsum[1], ones4, __builtin_shufflevector(pf[ks & 1][1], pf[ks & 1][1], 0, 1, 2, 3));
+                if ((j & 7) == 6) M::rowsum4(lsum[1], ones4, __builtin_shufflevector(pf[ks & 1][1], pf[ks & 1][1], 4, 5, 6, 7));
+            }
             // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
-            if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
-            if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
+            if (!(ABL & 32)) {
+                if (ks < 3 && (j & 7) == 4) pf[(ks + 1) & 1][0] = pack_p(cur, ks + 1, 0);
+                if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
+            }
             // row max of S'(t+1): 2 chains x 16 v_max3, groups MS .. MS+15 (>= 4 MFMAs after the last S^T MFMA was issued); the
             // half-wave exchange and the growth test follow in the next gaps, so that only the branch itself is left behind the
             // step's last MFMA
-            if (j >= MS && j < MS + 16) {
+            if (!(ABL & 4) && j >= MS && j < MS + 16) {
                 const int r = j - MS;
-                if (r == 0) {      // the chain's first link needs no -inf to start from
+                if (r == 0 && (R6 & 512) != 0) {      // the chain's first link needs no -inf to start from (two v_mov fewer per tile)
                     asm("v_max_f32_e32 %0, %1, %2" : "=v"(mx0) : "v"(nxt[0][0][0]), "v"(nxt[1][0][0]));
                     asm("v_max_f32_e32 %0, %1, %2" : "=v"(mx1) : "v"(nxt[0][1][0]), "v"(nxt[1][1][0]));
+                } else if constexpr ((R6 & 128) != 0) {      // two 4-byte v_max instead of one 8-byte v_max3 (exact either way)
+                    asm("v_max_f32_e32 %0, %0, %1\n\tv_max_f32_e32 %0, %0, %2" : "+v"(mx0) : "v"(nxt[0][0][r]), "v"(nxt[1][0][r]));
+                    asm("v_max_f32_e32 %0, %0, %1\n\tv_max_f32_e32 %0, %0, %2" : "+v"(mx1) : "v"(nxt[0][1][r]), "v"(nxt[1][1][r]));
                 } else {
                     asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx0) : "v"(nxt[0][0][r]), "v"(nxt[1][0][r]));
                     asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx1) : "v"(nxt[0][1][r]), "v"(nxt[1][1][r]));
@@ -447,24 +564,37 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             if (j == MS + 17) mx1 = max_halves(mx1);
             if (j == MS + 18) {
                 // growth of the row maxima over the running maxima, log2 units (nmsub = -m*scale*log2e; -inf for rows that see nothing here)
-                asm("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(g0), "=&v"(g1) : "v"(mx0), "v"(mx1), "s"(escale_s), "v"(nmsub[0]), "v"(nmsub[1]));
+                asm("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(g0), "=&v"(g1) : "v"(mx0), "v"(mx1), "s"(escale), "v"(nmsub[0]), "v"(nmsub[1]));
             }
             if (j == MS + 19) asm("v_max_f32 %0, %1, %2" : "=v"(grow) : "v"(g0), "v"(g1));
-            // this wave's four pieces of K(t+3) and of V(t+2): every piece takes piece 0's per-lane offset, its distance from piece 0 (4 K rows |
-            // 16 V keys per piece) travels in the load's scalar offset (prefill64_common.h)
-            if (j == dma_gap(0)) dma_piece_at<0>(lk0, rk, koff[0]);
-            if (j == dma_gap(1)) dma_piece_so<KPIECE, 4>(lk0, rk, koff[0], k_rs_bytes);
-            if (j == dma_gap(2)) dma_piece_so<2 * KPIECE, 8>(lk0, rk, koff[0], k_rs_bytes);
-            if (j == dma_gap(3)) dma_piece_so<3 * KPIECE, 12>(lk0, rk, koff[0], k_rs_bytes);
-            if (j == dma_gap(4)) dma_piece_at<0>(lv0, rv, voff[0]);
-            if (j == dma_gap(5)) dma_piece_so<1024, 16>(lv0, rv, voff[0], v_rs_bytes);
-            if (j == dma_gap(6)) dma_piece_so<2048, 32>(lv0, rv, voff[0], v_rs_bytes);
-            if (j == dma_gap(7)) dma_piece_so<3072, 48>(lv0, rv, voff[0], v_rs_bytes);
+            if (!(ABL & 1)) {
+                if (j == dma_gap(0)) dma_piece_at<0>(lk0, rk, koff[0]);
+                // piece j's per-lane offset = piece 0's + j x (4 K rows | 16 V keys): one v_mad beside the DMA instead of six more
+                // loop-invariant registers that the allocator parks in the accumulator file and reads back every tile
+                if constexpr ((R6 & 512) != 0 && KP) {      // the pieces' distances in the scalar offset (prefill64_common.h)
+                    if (j == dma_gap(1)) dma_piece_so<KPIECE, 4>(lk0, rk, koff[0], k_rs_bytes);
+                    if (j == dma_gap(2)) dma_piece_so<2 * KPIECE, 8>(lk0, rk, koff[0], k_rs_bytes);
+                    if (j == dma_gap(3)) dma_piece_so<3 * KPIECE, 12>(lk0, rk, koff[0], k_rs_bytes);
+                    if (j == dma_gap(4)) dma_piece_at<0>(lv0, rv, voff[0]);
+                    if (j == dma_gap(5)) dma_piece_so<1024, 16>(lv0, rv, voff[0], v_rs_bytes);
+                    if (j == dma_gap(6)) dma_piece_so<2048, 32>(lv0, rv, voff[0], v_rs_bytes);
+                    if (j == dma_gap(7)) dma_piece_so<3072, 48>(lv0, rv, voff[0], v_rs_bytes);
+                } else {
+                if (j == dma_gap(1)) dma_piece_at<KPIECE>(lk0, rk, KP ? piece_off<4>(koff[0], k_rs_bytes) : koff[1]);
+                if (j == dma_gap(2)) dma_piece_at<2 * KPIECE>(lk0, rk, KP ? piece_off<8>(koff[0], k_rs_bytes) : koff[2]);
+                if (j == dma_gap(3)) dma_piece_at<3 * KPIECE>(lk0, rk, KP ? piece_off<12>(koff[0], k_rs_bytes) : koff[3]);
+                if (j == dma_gap(4)) dma_piece_at<0>(lv0, rv, voff[0]);
+                if (j == dma_gap(5)) dma_piece_at<1024>(lv0, rv, piece_off<16>(voff[0], v_rs_bytes));
+                if (j == dma_gap(6)) dma_piece_at<2048>(lv0, rv, piece_off<32>(voff[0], v_rs_bytes));
+                if (j == dma_gap(7)) dma_piece_at<3072>(lv0, rv, piece_off<48>(voff[0], v_rs_bytes));
+                }
+            }
             if (j == 27) kf0 = kfrag(ksm_next, 0);          // the next step's first K fragments: K(t+2) is behind the barrier
             if (j == 28) kf1 = kfrag(ksm_next, 1);
             if (j == 29 && RING > 3) kf2 = kfrag(ksm_next, 2);
             SCHED_FENCE();
         }
+        if constexpr ((R6 & 2) != 0) ts_step++;
         if (mask_next) {
             mask_tile(t + 1, nxt);
             mx0 = row_max(nxt, 0);
@@ -492,6 +622,11 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         step(t, 0, sc, sd, kfa, kfb, kfc);
         if (t + 1 < nt) step(t + 1, 1, sd, sc, kfa, kfb, kfc);
     }
+    if constexpr ((R6 & 2) != 0) {
+        __syncthreads();
+        unsigned* const ts_out = (unsigned*)(p.softmax_lse + (((size_t)p.b * p.h * p.seqlen_q + 1) & ~(size_t)1)) + (size_t)blockIdx.x * 2048;
+        for (int i = tid; i < 2048; i += 256) ts_out[i] = ((unsigned*)(smem + kStampBase))[i];
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // trailing DMA retired (nothing may land in LDS of
     SCHED_FENCE();                                                                // a later workgroup); last PV results readable
 #undef P64_X0
@@ -506,7 +641,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
     for (int qc = 0; qc < 2; qc++) {
         const int my_q = qw0 + 32 * qc + l31;
         const float l_loc = l_acc[qc][0] + l_acc[qc][1];
-        const float l_tot = l_loc + swap_halves(l_loc);
+        const float l_own = MSUM ? lsum[qc][0] : l_loc;
+        const float l_tot = l_own + swap_halves(l_own);
         const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
         const float m_log2 = -nmsub[qc];                      // running max of softmax_scale*log2e*q.k
         // row of the partial buffer that query row q of this block goes to
@@ -514,7 +650,9 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             return listed ? (int64_t)it_row + (q - q_wg0) : (((int64_t)split * p.b + b) * p.seqlen_q + q) * p.h + h;
         };
         float* lpart = (float*)p.workspace + (listed ? (int64_t)p.pf_part_rows : (int64_t)nsplit * p.b * p.seqlen_q * p.h) * HD;
-        if (my_q < Sq && partial) {
+        if (ABL & 256) {
+            if (l_tot == 12345.f) ((float*)p.workspace)[lane] = o[0][qc][0] * inv;      // ablation: no epilogue stores
+        } else if (my_q < Sq && partial) {
             const int64_t row = part_row(my_q);
             float* opart = (float*)p.workspace + row * HD;
 #pragma unroll
@@ -524,11 +662,17 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                     f32x4 w;
 #pragma unroll
                     for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
-                    *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    if (kLab && merge_mode == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) store_dev(opart + 32 * db + 8 * tq + 4 * g + e, w[e]);
+                    } else {
+                        *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    }
                 }
             if (g == 0) {
                 const float lv = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_log2 + __log2f(l_tot));
-                lpart[row] = lv;
+                if (kLab && merge_mode == 2) store_dev(lpart + row, lv);
+                else lpart[row] = lv;
             }
         } else if (my_q < Sq) {
             T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + my_q) * p.o_row_stride + (int64_t)h * p.o_head_stride;
@@ -549,7 +693,13 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
                         __builtin_memcpy(&uo, &wo, 8);
                         const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
-                        *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        if constexpr ((ABL & 1024) != 0) {      // LAB A/B: O written once — nt
+                            typedef unsigned nt4 __attribute__((ext_vector_type(4)));
+                            const nt4 t = {r0[0], r1[0], r0[1], r1[1]};
+                            __builtin_nontemporal_store(t, (nt4*)(optr + 32 * db + 8 * (2 * pr + g)));
+                        } else {
+                            *(uint4*)(optr + 32 * db + 8 * (2 * pr + g)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        }
                     }
             } else {
 #pragma unroll
@@ -570,13 +720,16 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
         }
     }
     (void)sc_ln;
+    // single-launch merge of the key-range shares (attn_common.h)
+    if (kLab && nsplit > 1 && done != nullptr)
+        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, done + ((int64_t)b * p.h + h) * nqb + qb, (int*)(smem + VBASE + 3 * S::kTileBytes), merge_mode);
 }
 
 // host side: grid as prefill_kernels.hip's 1-D / 3-D orders with 256-row query blocks
 dim3 prefill_grid(const vattn_attn_params* p, int nqb, int* order_out);       // prefill_kernels.hip
 
-constexpr int kSmem64 = 36864 + 3 * PfSmem<128>::kTileBytes;      // K ring (2 x 17 408, rounded up) + V ring
-template <typename T> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit) {
+constexpr int kSmem64 = 36864 + 3 * PfSmem<128>::kTileBytes;      // K ring (padded layout: 2 x 17 408, rounded up) + V ring
+template <typename T, int ABL, int NA, int RING, int MS = 8, int BJ = 8, int D0 = 9, int DS = 3, int R6 = 0, int XTRA = 0> static void launch64_t(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
     const int nqb = (p->seqlen_q + 255) / 256;
     int order;
     dim3 grid = prefill_grid(p, nqb, &order);
@@ -590,20 +743,80 @@ template <typename T> static void launch64_t(const vattn_attn_params* p, hipStre
         grid = dim3(((grid.x + 7) / 8) * 8 * nsplit);
     }
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem64 + 16);
+        (void)hipFuncSetAttribute((const void*)prefill64_kernel<T, ABL, NA, RING, MS, BJ, D0, DS, R6, XTRA>, hipFuncAttributeMaxDynamicSharedMemorySize, (R6 & 2) ? kStampBase + 8192 : kSmem64 + 16);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((prefill64_kernel<T>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit);
+    hipLaunchKernelGGL((prefill64_kernel<T, ABL, NA, RING, MS, BJ, D0, DS, R6, XTRA>), grid, dim3(256), (R6 & 2) ? kStampBase + 8192 : kSmem64 + 16, st, *p, order, nqb, nsplit, done, merge_mode);
 }
 
-// ONE build per dtype.  `done` / `merge_mode` belong to the lab copy's in-launch merge (tools/lab/csrc/prefill64_lab.hip); the product's callers
-// pass none and the key-range shares are merged by combine_rows_kernel / combine_blocks_kernel in a second launch.
+// Product: ONE build per dtype (padded K image, 24 exp2 pairs in phase A, fragment ring of 4, row-max chain in groups 8-23, barrier at group 8, DMA in groups 9, 12, .. 30).  The lab library (-DVATTN_LAB) adds the
+// K-image alternative and the timing ablations of tools/kbench.py behind variant bits 8-11 (0 = product; 1-3, 11, 12, 14 = correct alternatives;
+// 4-9 = ablations whose RESULTS ARE WRONG).
 void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
-    (void)done;
-    (void)merge_mode;
-    if (p->dtype == VATTN_DTYPE_BF16) launch64_t<__bf16>(p, st, nsplit);
-    else launch64_t<_Float16>(p, st, nsplit);
+#ifdef VATTN_LAB
+    // round 6 experiments, variant bits 28-30 (fp16): 1 = V^T fragments pre-read in phase A's tail; 3 = the same with stamps
+    switch ((p->variant >> 28) & 7) {
+        case 1: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1>(p, st, nsplit, done, merge_mode);
+        case 3: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 3>(p, st, nsplit, done, merge_mode);
+        // encoding-size probes (RESULTS ARE WRONG: the maximum is not subtracted): the v_fma as a 4-byte / an 8-byte v_mul
+        case 2: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 16>(p, st, nsplit, done, merge_mode);
+        case 4: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 32>(p, st, nsplit, done, merge_mode);
+        // (call 2 counted the issue-budget ablations — no v_fma: ABL 2048, no v_add: 4096, ...: profiles/r06_p64_issue_ablation_pmc.txt)
+        // (round-6 call 2 also counted: no v_fma + no v_add, no fma / exp / add, MFMAs + reads + DMA only: profiles/r06_p64_issue_ablation_pmc.txt)
+        case 5: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4>(p, st, nsplit, done, merge_mode);             // scale in a scalar register
+        // (call 3 also counted the stage order M, E, A inside a group: slower, profiles/r06_p64_scalar_scale_pmc.txt)
+        case 6: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 64>(p, st, nsplit, done, merge_mode);            // v_mov + v_fmac (4-byte encodings), exact
+        case 7:      // sub-selected by split_reserved bits 16-23 (tools/kbench.py: KBENCH_LAB_SUB)
+            switch ((p->split_reserved >> 16) & 255) {
+                case 0: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 64 | 128>(p, st, nsplit, done, merge_mode);      // + two v_max for each v_max3, exact
+                // price list: the scalar-scale schedule + 64 extra instructions of ONE class per tile (results unchanged)
+                case 1: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 1>(p, st, nsplit, done, merge_mode);
+                case 2: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 2>(p, st, nsplit, done, merge_mode);
+                case 3: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 3>(p, st, nsplit, done, merge_mode);
+                case 4: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 4>(p, st, nsplit, done, merge_mode);
+                case 5: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 5>(p, st, nsplit, done, merge_mode);
+                case 6: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 6>(p, st, nsplit, done, merge_mode);
+                case 7: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 7>(p, st, nsplit, done, merge_mode);
+                case 8: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 8>(p, st, nsplit, done, merge_mode);
+                case 9: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 9>(p, st, nsplit, done, merge_mode);
+                case 10: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 10>(p, st, nsplit, done, merge_mode);
+                case 11: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4, 11>(p, st, nsplit, done, merge_mode);
+                case 12: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4 | 256>(p, st, nsplit, done, merge_mode);      // row sums on the matrix pipe (closed: slower, profiles/r06_p64_rowsum_mfma_pmc.txt)
+                case 13: return launch64_t<_Float16, 128, 24, 4, 8, 8, 9, 3, 1 | 4 | 512>(p, st, nsplit, done, merge_mode);      // DMA piece distances in the scalar offset
+                default: break;
+            }
+            break;
+        default: break;
+    }
+    const int sel = (p->variant >> 8) & 15;
+    if (p->dtype == VATTN_DTYPE_BF16) {
+        if (sel == 3) return launch64_t<__bf16, 0, 24, 4>(p, st, nsplit, done, merge_mode);
+    } else {
+        switch (sel) {
+            case 3: return launch64_t<_Float16, 0, 24, 4>(p, st, nsplit, done, merge_mode);                    // XOR-swizzled K image (round 2's first layout)
+            // schedule alternatives (correct, bit-identical results; tools/p64_variants.py, profiles/r03_p64_schedules.txt)
+            case 14: return launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode);               // the product build inside the lab library (lab vs
+                                                                                                              // product binaries of one source differ by up to 1 %)
+            case 1: return launch64_t<_Float16, 128, 20, 4, 8, 8, 9, 3>(p, st, nsplit, done, merge_mode);    // 20 exp2 pairs in phase A
+            case 2: return launch64_t<_Float16, 128, 24, 4, 4, 8, 9, 3>(p, st, nsplit, done, merge_mode);    // row-max chain from group 4
+            case 11: return launch64_t<_Float16, 128, 24, 4, 8, 12, 13, 2>(p, st, nsplit, done, merge_mode); // barrier after group 11, DMA every second group
+            case 12: return launch64_t<_Float16, 128, 24, 4, 8, 24, 24, 1>(p, st, nsplit, done, merge_mode); // round 2's placement: barrier after 23, DMA 24-31
+            case 15: return launch64_t<_Float16, 1024 | 128, 24, 4>(p, st, nsplit, done, merge_mode);         // A/B (round 4): non-temporal Q loads and O stores
+            case 10: return launch64_t<_Float16, 256 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no epilogue stores
+            case 13: return launch64_t<_Float16, 512 | 128, 24, 4>(p, st, nsplit, done, merge_mode);          // ablation: no zero-fill of the V ring
+            case 4: return launch64_t<_Float16, 1 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no LDS-DMA in the steady state
+            case 5: return launch64_t<_Float16, 2 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no fma / exp2 / row sums
+            case 6: return launch64_t<_Float16, 8 | 128, 24, 4>(p, st, nsplit, done, merge_mode);              // no per-tile wait + barrier
+            case 7: return launch64_t<_Float16, 16 | 128, 24, 4>(p, st, nsplit, done, merge_mode);             // no LDS fragment reads
+            case 8: return launch64_t<_Float16, 1 | 2 | 4 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode);           // MFMAs + fragment reads + barrier
+            case 9: return launch64_t<_Float16, 1 | 2 | 4 | 8 | 16 | 32 | 128, 24, 4>(p, st, nsplit, done, merge_mode);  // MFMAs only
+            default: break;
+        }
+    }
+#endif
+    if (p->dtype == VATTN_DTYPE_BF16) launch64_t<__bf16, 128, 24, 4>(p, st, nsplit, done, merge_mode);
+    else launch64_t<_Float16, 128, 24, 4>(p, st, nsplit, done, merge_mode);
 }
 
 }  // namespace vattn_k

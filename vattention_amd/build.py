@@ -119,7 +119,12 @@ def build_lib(force=False):
     return out
 
 
-LAB_SOURCES = ("attn_api.hip", "prefill_kernels.hip", "prefill64_kernels.hip", "prefill64p_kernels.hip", "decode_kernels.hip", "cache_kernels.hip", "hybrid_kernels.hip")
+# The lab library compiles the product sources with -DVATTN_LAB — except where the laboratory has its OWN copy of a kernel
+# (tools/lab/csrc/): prefill64 since round 6 (the product's prefill64_kernels.hip carries one schedule and no measurement code; the lab
+# copy keeps every alternative schedule, ablation, stamp and price-list build behind `variant` bits).
+LAB_DIR_SRC = os.path.join(ROOT, "tools", "lab", "csrc")
+LAB_SOURCES = ("attn_api.hip", "prefill_kernels.hip", os.path.join(LAB_DIR_SRC, "prefill64_lab.hip"), "prefill64p_kernels.hip", "decode_kernels.hip", "cache_kernels.hip",
+               "hybrid_kernels.hip")
 
 
 def build_lab(force=False):
@@ -130,12 +135,12 @@ def build_lab(force=False):
     outdir = os.path.join(ROOT, "tools", "lab")
     os.makedirs(outdir, exist_ok=True)
     out = os.path.join(outdir, "libvattn_lab.so")
-    srcs = [os.path.join(CSRC, f) for f in LAB_SOURCES]
+    srcs = [f if os.path.isabs(f) else os.path.join(CSRC, f) for f in LAB_SOURCES]
     deps = srcs + [os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill64_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
                    os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-inline-asm", *UNROLL_FLAGS]
+        flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-inline-asm", "-I" + CSRC, *UNROLL_FLAGS]
         objdir = os.path.join(ROOT, "build", "obj_lab")
         os.makedirs(objdir, exist_ok=True)
         objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in srcs]

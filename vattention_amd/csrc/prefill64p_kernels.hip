@@ -347,12 +347,16 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p,
     auto GE = [](int e) { return e < NA ? 1 + (e * 30) / NA : 33 + ((e - NA) * 17) / (32 - NA); };
 #define P64_X0(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3)]
 #define P64_X1(cur, e) cur[(e) >> 4][((e) >> 2) & 1][8 * (((e) >> 3) & 1) + 2 * ((e) & 3) + 1]
+    // (round 6, as in prefill64_kernel: the scale in a REAL scalar register, the V^T fragments of phase B read in phase A's tail, the LDS-DMA
+    // pieces' distances in the loads' scalar offset, the row-max chain started from its first link: a VALU instruction beside the MFMAs costs
+    // 7.3 cycles of this wave, a scalar one 0.3 — profiles/r06_p64_price_list.txt)
+    const unsigned escale_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, escale));
     auto softmax_stages = [&](int Gp, f32x16 (&cur)[2][2]) {
 #pragma unroll
         for (int e = 0; e < 32; e++) {
             const int qc = (e >> 2) & 1;
             if (GE(e) - 1 == Gp)
-                asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale), "v"(nmsub[qc]));
+                asm("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)) : "s"(escale_s), "v"(nmsub[qc]));
             if (GE(e) == Gp) asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(P64_X0(cur, e)), "+v"(P64_X1(cur, e)));
             if (GE(e) + 1 == Gp)
                 asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(l_acc[qc][0]), "+v"(l_acc[qc][1]) : "v"(P64_X0(cur, e)), "v"(P64_X1(cur, e)));
@@ -425,6 +429,7 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p,
         unsigned lv0 = 0;
         V8 pf[2][2];
         V8 kf[RING];
+        V8 vf[RING];
         SCHED_FENCE();
 #pragma unroll
         for (int i = 0; i < 32; i++) {
@@ -448,12 +453,12 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p,
             // the piece's counters move on inside a gap (pinned: scalar C++ would be sunk behind the step's last MFMA, where nothing
             // hides it): t = the tile being scored, rem = tiles left after this step
             if (i == 25) asm volatile("s_add_u32 %0, %0, 1\n\ts_sub_u32 %1, %1, 1" : "+s"(t), "+s"(rem) : : "scc");
+            // V(t) landed a step ago: its first fragments are asked for while the last S' MFMAs run (the K ring has stopped reading at i = 24)
+            if (i == 26) vf[0] = vfrag(vsm, 0);
+            if (i == 28) vf[1] = vfrag(vsm, 1);
+            if (i == 30 && RING > 3) vf[2] = vfrag(vsm, 2);
             SCHED_FENCE();
         }
-        V8 vf[RING];
-        vf[0] = vfrag(vsm, 0);
-        vf[1] = vfrag(vsm, 1);
-        if (RING > 3) vf[2] = vfrag(vsm, 2);
         float mx0 = -INFINITY, mx1 = -INFINITY, g0 = -INFINITY, g1 = -INFINITY, grow = -INFINITY;
         SCHED_FENCE();
 #pragma unroll
@@ -470,23 +475,28 @@ __global__ __launch_bounds__(256, 1) void prefill64p_kernel(vattn_attn_params p,
             if (ks < 3 && (j & 7) == 6) pf[(ks + 1) & 1][1] = pack_p(cur, ks + 1, 1);
             if (j >= MS && j < MS + 16) {
                 const int r = j - MS;
-                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx0) : "v"(nxt[0][0][r]), "v"(nxt[1][0][r]));
-                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx1) : "v"(nxt[0][1][r]), "v"(nxt[1][1][r]));
+                if (r == 0) {
+                    asm("v_max_f32_e32 %0, %1, %2" : "=v"(mx0) : "v"(nxt[0][0][0]), "v"(nxt[1][0][0]));
+                    asm("v_max_f32_e32 %0, %1, %2" : "=v"(mx1) : "v"(nxt[0][1][0]), "v"(nxt[1][1][0]));
+                } else {
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx0) : "v"(nxt[0][0][r]), "v"(nxt[1][0][r]));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx1) : "v"(nxt[0][1][r]), "v"(nxt[1][1][r]));
+                }
             }
             if (j == MS + 16) mx0 = max_halves(mx0);
             if (j == MS + 17) mx1 = max_halves(mx1);
             if (j == MS + 18) {
-                asm("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(g0), "=&v"(g1) : "v"(mx0), "v"(mx1), "s"(escale), "v"(nmsub[0]), "v"(nmsub[1]));
+                asm("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(g0), "=&v"(g1) : "v"(mx0), "v"(mx1), "s"(escale_s), "v"(nmsub[0]), "v"(nmsub[1]));
             }
             if (j == MS + 19) asm("v_max_f32 %0, %1, %2" : "=v"(grow) : "v"(g0), "v"(g1));
             if (j == dma_gap(0)) dma_piece_at<0>(lk0, rk, koff[0]);
-            if (j == dma_gap(1)) dma_piece_at<KPIECE>(lk0, rk, piece_off<4>(koff[0], k_rs_bytes));
-            if (j == dma_gap(2)) dma_piece_at<2 * KPIECE>(lk0, rk, piece_off<8>(koff[0], k_rs_bytes));
-            if (j == dma_gap(3)) dma_piece_at<3 * KPIECE>(lk0, rk, piece_off<12>(koff[0], k_rs_bytes));
+            if (j == dma_gap(1)) dma_piece_so<KPIECE, 4>(lk0, rk, koff[0], k_rs_bytes);
+            if (j == dma_gap(2)) dma_piece_so<2 * KPIECE, 8>(lk0, rk, koff[0], k_rs_bytes);
+            if (j == dma_gap(3)) dma_piece_so<3 * KPIECE, 12>(lk0, rk, koff[0], k_rs_bytes);
             if (j == dma_gap(4)) dma_piece_at<0>(lv0, rv, voff[0]);
-            if (j == dma_gap(5)) dma_piece_at<1024>(lv0, rv, piece_off<16>(voff[0], v_rs_bytes));
-            if (j == dma_gap(6)) dma_piece_at<2048>(lv0, rv, piece_off<32>(voff[0], v_rs_bytes));
-            if (j == dma_gap(7)) dma_piece_at<3072>(lv0, rv, piece_off<48>(voff[0], v_rs_bytes));
+            if (j == dma_gap(5)) dma_piece_so<1024, 16>(lv0, rv, voff[0], v_rs_bytes);
+            if (j == dma_gap(6)) dma_piece_so<2048, 32>(lv0, rv, voff[0], v_rs_bytes);
+            if (j == dma_gap(7)) dma_piece_so<3072, 48>(lv0, rv, voff[0], v_rs_bytes);
             if (j == 27) kf0 = kfrag(ksm_next, 0);
             if (j == 28) kf1 = kfrag(ksm_next, 1);
             if (j == 29 && RING > 3) kf2 = kfrag(ksm_next, 2);
