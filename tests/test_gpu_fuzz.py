@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle.attn import flash_attn_with_kvcache_ref
+from tests.variants import product_or_self
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -56,7 +57,7 @@ def test_fuzz_prefill(seed):
         idx = torch.tensor(slots, dtype=torch.int32)
         ref = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=causal)
         out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
-                                      causal=causal, num_splits=splits, _variant=variant, _max_seqlen_k=rng.choice([0, max(cls)]))
+                                      causal=causal, num_splits=splits, _variant=product_or_self(variant), _max_seqlen_k=rng.choice([0, max(cls)]))
         torch.cuda.synchronize()
         _check(out, ref, dtype, "prefill seed %d case %d (D=%d Hq=%d Hkv=%d B=%d n=%d cl=%s causal=%s variant=%d splits=%d)" % (
             seed, case, D, Hq, Hkv, B, n, cls, causal, variant, splits))
@@ -86,7 +87,7 @@ def test_fuzz_batched_chunks(seed):
         slots = rng.sample(range(B + 1), B)
         i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
         out = flash_attn_varlen_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), i32(starts), i32(lens), max(lens), i32(cls), i32(slots),
-                                             causal=True, num_splits=rng.choice([0, 0, 2, 5]), _variant=rng.choice([0, 2, 8, 64, 14, 782]),
+                                             causal=True, num_splits=rng.choice([0, 0, 2, 5]), _variant=product_or_self(rng.choice([0, 2, 8, 64, 14, 782])),
                                              _max_seqlen_k=max(cls))
         torch.cuda.synchronize()
         for i in range(B):
@@ -124,7 +125,7 @@ def test_fuzz_decode(seed):
         kg, vg = kc.to(DEV), vc.to(DEV)
         out = flash_attn_with_kvcache(q.to(DEV), kg, vg, kn.to(DEV) if append else None, vn.to(DEV) if append else None,
                                       cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV), causal=True,
-                                      num_splits=rng.choice([0, 0, 1, 2, 9, 48]), _variant=rng.choice([0, 1, 64, 128, 512, 1024, 128 | 1024]))
+                                      num_splits=rng.choice([0, 0, 1, 2, 9, 48]), _variant=product_or_self(rng.choice([0, 1, 64, 128, 512, 1024, 128 | 1024])))
         torch.cuda.synchronize()
         _check(out, ref, dtype, "decode seed %d case %d (D=%d Hq=%d Hkv=%d B=%d ctx=%d append=%s)" % (seed, case, D, Hq, Hkv, B, ctx, append))
         assert torch.equal(kg.cpu(), kr) and torch.equal(vg.cpu(), vr)
@@ -161,7 +162,7 @@ def test_fuzz_prefill64_midsize(seed):
         idx = torch.tensor(slots, dtype=torch.int32)
         ref = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=causal)
         out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
-                                      causal=causal, num_splits=splits, _variant=variant, _max_seqlen_k=max(cls))
+                                      causal=causal, num_splits=splits, _variant=product_or_self(variant), _max_seqlen_k=max(cls))
         torch.cuda.synchronize()
         _check(out, ref, dtype, "prefill64 seed %d case %d (Hq=%d Hkv=%d B=%d n=%d cl=%s causal=%s variant=%d splits=%d %s)" % (
             seed, case, Hq, Hkv, B, n, cls, causal, variant, splits, dtype))

@@ -46,6 +46,7 @@ def _oracle(c, chunks, dec_lens, dtype, math):
     return torch.cat(outs + [od[:, 0]], 0), kcd, vcd
 
 
+@pytest.mark.lab      # the FUSED launch is a lab kernel (tools/lab/csrc/hybrid_lab.hip)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("Hq,Hkv,chunks,dec_lens", [
     (8, 2, [(1000, 512)], [700, 33, 1500, 1, 257]),                       # Sarathi iteration: one chunk + running decodes
@@ -86,6 +87,7 @@ def test_fused_hybrid_launch_matches_the_oracle(Hq, Hkv, chunks, dec_lens, dtype
         assert torch.equal(kg.cpu(), kc_ref) and torch.equal(vg.cpu(), vc_ref), "appended rows differ"
 
 
+@pytest.mark.lab      # the FUSED launch is a lab kernel (tools/lab/csrc/hybrid_lab.hip)
 def test_fused_hybrid_workspace_survives_a_growing_decode_batch():
     """Back-to-back launches on ONE stream reuse one workspace.  A first launch with a few decode groups leaves fp32 split partials
     in it; a later launch with MORE groups (b * h_k going from 8 to 96 here) must not find its merge counters on top of those bytes
@@ -118,6 +120,7 @@ def test_fused_hybrid_workspace_survives_a_growing_decode_batch():
         assert torch.equal(kg.cpu(), kc_ref) and torch.equal(vg.cpu(), vc_ref)
 
 
+@pytest.mark.lab      # the FUSED launch is a lab kernel (tools/lab/csrc/hybrid_lab.hip)
 def test_fused_hybrid_argument_rules():
     from vattention_amd.flash_attn import flash_attn_with_kvcache, hybrid_attn
     dt = torch.float16

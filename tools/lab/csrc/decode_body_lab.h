@@ -1,7 +1,5 @@
-// decode_body.h — the split-KV decode workgroup (see decode_kernels.hip for the overview) as a device function plus the kernels
-// that map a grid onto it.  Included by decode_kernels.hip.  PRODUCT source: the measurement scaffolding of rounds 2-5 (in-launch merge
-// protocols, XCD-consecutive ranges, per-workgroup clock stamps, fair-share issue priority, weighted heads, alternative shapes' selectors)
-// lives in the lab copy, tools/lab/csrc/decode_body_lab.h, which only tools/lab/libvattn_lab.so compiles.
+// decode_body.h — the split-KV decode workgroup (see decode_kernels.hip for the overview) as a device function plus the kernel
+// that maps a grid onto it.  Included by decode_kernels.hip and hybrid_kernels.hip.
 #pragma once
 #include <type_traits>
 
@@ -25,14 +23,15 @@ constexpr int DC_BN = 32;     // keys per wave tile
 //     launches with FEWER workgroups than the chip has room for: batch 1-4 decode; two workgroups per CU).
 template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES, int PF = 1>
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
-                                            const int split, const int hk, const int gb, const int b, char* smem,
+                                            const int split, const int hk, const int gb, const int b, char* smem, const int merge_mode = 0,
                                             const int item = -1, const int item_tb = 0, const int item_te = 0,
                                             const int st_mode = 0, const int st_slot = 0, const int st_lk = 0, const unsigned st_block = 0,
-                                            const int tstride = 1) {
+                                            const int st_done = 0, const int st_total = 0, const int tstride = 1) {
     // st_mode != 0: a piece [item_tb, item_te) of the device-planned stream decomposition (decode_stream_kernel below).  Slot and visible
     // length come from the workgroup's plan (LDS) instead of two dependent global loads; st_mode 1 = the piece is the whole sequence: the
     // final rows are written; st_mode 2 = a partial, published as one record block at byte offset st_block of the workspace (16-byte
-    // stores; merged by the next launch).
+    // stores; merged by the next launch); st_mode 3 (lab) = the same with write-through stores (device scope: merged INSIDE the launch by
+    // a workgroup that may sit on another XCD, whose L2 is not coherent with this one).
     using X = Tr<T>;
     using V8 = typename X::v8;
     constexpr int KK = HD / 32;          // k-steps of S^T (16x16x32)
@@ -312,6 +311,18 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
 #pragma unroll
         for (int u = 0; u < PF; u++) load_tile(u, first + u * wstep < loop_end ? first + u * wstep : ntiles_total);
         for (int tile0 = first; tile0 < loop_end; tile0 += PF * wstep) {
+            if (st_total > 0) {
+                // (LAB, off in the product: measured neutral.)  FAIR SHARE of the CU among its resident workgroups.  The CU issues the vector-memory instructions of its OLDEST waves
+                // first: three workgroups of equal work, dispatched back to back, finish one after the other (B16 @ 32 k: ids 0-255 at
+                // 100 us, 256-511 at 149 us, 512-767 at 178 us, tools/decode_skew_probe.py) and the CU spends the last third of the launch
+                // with a third of its waves — too few bytes in flight.  Issue priority follows the share of the workgroup's range that
+                // is still ahead of it, in quarters: whoever is behind outranks whoever is ahead, age only breaks ties inside a quarter.
+                const int q4 = (4 * (st_total - st_done - (tile0 - tile_begin))) / st_total;      // wave-uniform
+                if (q4 >= 3) __builtin_amdgcn_s_setprio(3);
+                else if (q4 == 2) __builtin_amdgcn_s_setprio(2);
+                else if (q4 == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
 #pragma unroll
             for (int u = 0; u < PF; u++) {
                 const int tile = tile0 + u * wstep;
@@ -386,8 +397,13 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
                     u32x4 bits;
                     __builtin_memcpy(&bits, &acc, 16);
                     const float lv = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));
-                    __builtin_amdgcn_raw_buffer_store_b128(bits, wsr, (int)(st_block + (r16 * HD + d0) * 4u), 0, 0);
-                    if (d0 == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lv), wsr, (int)(st_block + (16u * NB * HD + r16) * 4u), 0, 0);
+                    if (kLab && st_mode == 3) {      // handed over inside the launch: device scope (write-through)
+                        __builtin_amdgcn_raw_buffer_store_b128(bits, wsr, (int)(st_block + (r16 * HD + d0) * 4u), 0, kDevScope);
+                        if (d0 == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lv), wsr, (int)(st_block + (16u * NB * HD + r16) * 4u), 0, kDevScope);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(bits, wsr, (int)(st_block + (r16 * HD + d0) * 4u), 0, 0);
+                        if (d0 == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lv), wsr, (int)(st_block + (16u * NB * HD + r16) * 4u), 0, 0);
+                    }
                 }
             }
             continue;
@@ -418,10 +434,90 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
                 float* lacc = oacc + (item >= 0 ? (int64_t)p.num_split_items : (int64_t)num_splits * p.b) * p.h * HD;
                 const int64_t row_idx = item >= 0 ? (int64_t)item * p.h + hh : ((int64_t)split * p.b + b) * p.h + hh;
                 const float lv = (lsum == 0.f) ? -INFINITY : (mxs + __log2f(lsum));   // log2 domain
-                oacc[row_idx * HD + d] = acc * inv;
-                if (d == 0) lacc[row_idx] = lv;
+                if (kLab && merge_mode == 2) {      // handed to the merging workgroup inside this launch: device-scope stores (attn_common.h)
+                    store_dev(oacc + row_idx * HD + d, acc * inv);
+                    if (d == 0) store_dev(lacc + row_idx, lv);
+                } else {
+                    oacc[row_idx * HD + d] = acc * inv;
+                    if (d == 0) lacc[row_idx] = lv;
+                }
             }
         }
+    }
+}
+
+// LSE-weighted merge of the num_splits partials of head blocks gb*NB .. gb*NB + NB-1 of (b, hk) by ONE workgroup (256 threads: 16
+// threads per head, 8 output columns each) — the in-launch form of combine_kernel, used by the fused hybrid launch and by
+// decode_kernel's single-launch merge (the workgroup that completes a group's last split calls it).
+template <typename T, int HD, int NB>
+__device__ __forceinline__ void decode_group_combine(const vattn_attn_params& p, const int num_splits, const int hk, const int gb, const int b,
+                                                     const bool dev = false) {
+    const int tid = threadIdx.x;
+    const int G = p.h / p.h_k;
+    constexpr int CPT = HD / 16;                        // columns per thread
+    const float* oacc = (const float*)p.workspace;
+    const int64_t sstride = (int64_t)p.b * p.h;
+    const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        const int rh = (gb * NB + nb) * 16 + (tid >> 4);
+        if (rh >= G) continue;
+        const int hh = hk * G + rh;
+        const int d0 = (tid & 15) * CPT;
+        const int64_t row = (int64_t)b * p.h + hh;
+        float mx = -INFINITY;
+        for (int s = 0; s < num_splits; s++) mx = fmaxf(mx, dev ? load_dev(lacc + (int64_t)s * sstride + row) : lacc[(int64_t)s * sstride + row]);
+        const float mxs = (mx == -INFINITY) ? 0.f : mx;
+        float acc[CPT];
+#pragma unroll
+        for (int e = 0; e < CPT; e++) acc[e] = 0.f;
+        float wsum = 0.f;
+        for (int s = 0; s < num_splits; s++) {
+            const float w = fast_exp2((dev ? load_dev(lacc + (int64_t)s * sstride + row) : lacc[(int64_t)s * sstride + row]) - mxs);
+            const float* src = oacc + ((int64_t)s * sstride + row) * HD + d0;
+            wsum += w;
+#pragma unroll
+            for (int e = 0; e < CPT; e += 4) {
+                f32x4 a;
+                if (dev) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a[u] = load_dev(src + e + u);
+                } else {
+                    a = *(const f32x4*)(src + e);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[e + u] += w * a[u];
+            }
+        }
+        const float inv = (wsum == 0.f) ? 0.f : 1.f / wsum;
+        T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)hh * p.o_head_stride + d0;
+#pragma unroll
+        for (int e = 0; e < CPT; e++) optr[e] = Tr<T>::cvt(acc[e] * inv);
+        if (p.softmax_lse && (tid & 15) == 0)
+            p.softmax_lse[(int64_t)b * p.h + hh] = (wsum == 0.f) ? INFINITY : (mxs + __log2f(wsum)) * 0.6931471805599453f;
+    }
+}
+
+// Single-launch merge: after its partial is written, a workgroup releases it (the barrier retires every wave's stores into this
+// XCD's L2; ONE wave's agent-scope fence writes them back), takes a ticket from the group's counter, and the holder of the last
+// ticket acquires and merges.  `done` counters are zero between launches (the merger resets its group's).
+template <typename T, int HD, int NB>
+__device__ __forceinline__ void decode_release_and_merge(const vattn_attn_params& p, const int num_splits, const int hk, const int gb, const int b,
+                                                         int* done_counter, int* s_ticket, const int mode = 1) {
+    // mode 1: ordinary partial stores ordered by agent-scope fences; mode 2: device-scope stores / loads, ordered by the barrier's
+    // s_waitcnt vmcnt(0) alone (attn_common.h, prefill_release_and_merge)
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid < 64) {
+        if (mode == 1) __threadfence();
+        if (tid == 0) *s_ticket = atomicAdd(done_counter, 1);
+    }
+    __syncthreads();
+    if (*s_ticket == num_splits - 1) {
+        if (mode == 1 && tid < 64) __threadfence();
+        __syncthreads();
+        decode_group_combine<T, HD, NB>(p, num_splits, hk, gb, b, mode == 2);
+        if (tid == 0) *done_counter = 0;
     }
 }
 
@@ -448,7 +544,28 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
 // STRIPED pieces (see decode_body).  Product: the split-KV launch of ONE sequence (profiles/r04_decode_striped_ab.txt: one 128 k sequence
 // on 28 / 4 heads 60.5 -> 58.5 us; chip-filling batches +-0, one kv head per GPU -3 %: those keep contiguous pieces).  LAB: variant bit 24
 // stripes every uniform decomposition, bit 25 keeps the single sequence contiguous (A/B: tools/decode_striped_ab.py).
-__device__ __forceinline__ bool decode_striped(const vattn_attn_params& p) { return p.b == 1; }
+__device__ __forceinline__ bool decode_striped_all(const vattn_attn_params& p) { return kLab && (p.variant & (1 << 24)) != 0; }
+__device__ __forceinline__ bool decode_striped(const vattn_attn_params& p) {
+    return decode_striped_all(p) || (p.b == 1 && !(kLab && (p.variant & (1 << 25)) != 0));
+}
+// LAB (variant bit 26, single-sequence split launch): split counts per kv head weighted by where the head's bytes live — the head whose
+// 256-byte block of every row has address bits [9:8] = 01 streams ~20 % slower at this occupancy (profiles/r04_decode_head_skew.txt) and
+// gets 5 shares where the others get 4.  `total` workgroups in a 1-D grid; returns this head's count and its first workgroup.
+__device__ __forceinline__ bool decode_head_is_slow(const vattn_attn_params& p, const int hk) {
+    if ((p.k_row_stride * 2) % 1024 != 0) return false;
+    return ((((unsigned long long)p.k_cache + (unsigned long long)hk * (unsigned long long)p.k_head_stride * 2ull) >> 8) & 3ull) == 1ull;
+}
+__device__ __forceinline__ int decode_weighted_splits(const vattn_attn_params& p, const int total, const int hk, int& first) {
+    int wsum = 0, wbefore = 0, wmine = 4;
+    for (int h = 0; h < p.h_k; h++) {
+        const int w = decode_head_is_slow(p, h) ? 5 : 4;
+        if (h < hk) wbefore += w;
+        if (h == hk) wmine = w;
+        wsum += w;
+    }
+    first = (int)((long long)total * wbefore / wsum);
+    return (int)((long long)total * (wbefore + wmine) / wsum) - first;
+}
 constexpr int DC_MAXB = 256;                         // sequences per launch the plan prologue handles (4 per lane of a wave)
 // A workgroup whose range crosses into another sequence pays a second prologue / epilogue (partial stores drained, Q fetched, the K/V
 // stream restarted): a few microseconds during which its neighbours on the CU keep streaming but IT falls behind — and a one-round
@@ -650,25 +767,78 @@ __device__ __forceinline__ void decode_stream_merge(const vattn_attn_params& p, 
     }
 }
 
-// nwg: workgroups per (kv head, group) = gridDim.x.  The partials are merged by decode_stream_combine_kernel in a second launch (merging
-// inside the launch, XCD-consecutive ranges, per-workgroup clock stamps, fair-share issue priority: tools/lab/csrc/decode_body_lab.h).
+// nwg: workgroups per (kv head, group) = gridDim.x.  counters: NULL (product): the partials are merged by decode_stream_combine_kernel in a
+// second launch; LAB: one zero-initialised int per (sequence, kv head, group), left zero by the launch (the merging workgroup resets its
+// counter): merge inside the launch.
 template <typename T, int HD, bool USE_TR, int NB>
-__global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_kernel(vattn_attn_params p, int gblocks, int fused_append) {
+__global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_kernel(vattn_attn_params p, int gblocks, int fused_append, int* counters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_ticket;                           // (lab: in-launch merge)
     __shared__ int s_plan[3 * DC_MAXB];                // stream mode: the plan, for the pieces after the first
     const int tid = threadIdx.x;
     // grid (workgroups per head, kv heads): consecutive workgroup ids — consecutive XCDs — stream consecutive ranges of ONE kv head.  [The
     // kv head as the fastest index (the heads of one range dispatched together) measured 5-7 % slower on every shape, profiles/r04_decode_stream.txt.]
     const int hk = blockIdx.y / gblocks, gb = blockIdx.y % gblocks;
     const int nwg = gridDim.x;
-    const int w = blockIdx.x;
+    int w = blockIdx.x;
     const int X = stream_switch_tiles(p);
     constexpr unsigned RB = StreamRec<NB, HD>::kFloats * 4u;
+    // LAB instrumentation (tools/decode_skew_probe.py, variant bit 22): the buffer behind softmax_lse receives, from its 32 KiB mark on,
+    // per workgroup the 100 MHz wall clock at entry, after the plan and at exit
+    unsigned long long* const ts = (kLab && (p.variant & (1 << 22)) && p.softmax_lse) ? (unsigned long long*)p.softmax_lse + 4096 : nullptr;
+    const unsigned wg_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (kLab && ts && tid == 0) {
+        ts[3 * wg_id] = wall_clock64();
+        // where the dispatcher put this workgroup: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13]) and XCC_ID, behind the stamps
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        ts[3 * (unsigned)(gridDim.x * gridDim.y) + wg_id] = ((unsigned long long)xcc << 32) | hw;
+    }
     StreamPlan pl;
     stream_plan_load(p, X, pl);
+    if (kLab && ts && tid == 0) ts[3 * wg_id + 1] = wall_clock64();
     const StreamGeom geo = stream_geom(pl.total, pl.maxt, p.b, nwg);
+    const bool striped = decode_striped_all(p) && geo.uniform && geo.S > 1;      // (lab; the product stripes the single-sequence launch only)
+    // LAB (variant bit 27): the ranges of ONE XCD are consecutive — physical workgroup x (XCD x % 8: the
+    // dispatcher deals consecutive workgroup ids round-robin over the XCDs) takes logical range (x % 8) * n8 + x / 8, n8 = ranges per XCD —
+    // so a sequence's pieces share an L2 unless the sequence straddles one of the seven seams.  With the in-launch merge (bit 20) such a
+    // sequence is handed over INSIDE that L2: plain (write-back) record stores, a ticket that is an L2 atomic (workgroup scope: no sc1,
+    // performed in this XCD's L2, not at the memory side), record loads that only skip the vL1D; a straddling sequence keeps the
+    // device-scope protocol.  Only the active ranges are dealt (a short tile space uses a third of the grid: see stream_geom).
+    int n8 = 0;
+    if (kLab && (p.variant & (1 << 27)) && (nwg & 7) == 0) {
+        const int nact = geo.uniform ? p.b * geo.S : (pl.total + geo.T - 1) / geo.T;
+        n8 = (nact + 7) >> 3;
+        w = ((int)blockIdx.x & 7) * n8 + ((int)blockIdx.x >> 3);
+        if (((int)blockIdx.x >> 3) >= n8 || w >= nact) return;
+    }
+    auto seq_is_xcd_local = [&](const int b, const int first_rec, const int cnt) -> bool {
+        const int fw = first_rec - b;
+        return n8 > 0 && fw / n8 == (fw + cnt - 1) / n8;
+    };
+    auto publish_and_merge = [&](const int b, const int first_rec, const int cnt) {      // LAB: in-launch merge
+        // publish: this workgroup's record stores have left the CU (write-through, or into the XCD's L2), then ONE ticket
+        const bool local = seq_is_xcd_local(b, first_rec, cnt);
+        int* const c = counters + ((int64_t)b * p.h_k + hk) * gblocks + gb;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_ticket = local ? __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicAdd(c, 1);
+        __syncthreads();
+        if (s_ticket == cnt - 1) {
+            decode_stream_merge<T, HD, NB>(p, first_rec, cnt, hk, gb, gblocks, b);
+            if (tid == 0) {
+                if (local) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     // the current piece (all wave-uniform): sequence, its slot and visible length, tiles [tb, te), the sequence's records
     int b, slot, lk, tb, te, first_rec, cnt;
+    int done = 0, total = 0;                            // tiles of this workgroup's range behind / in all of its pieces (fair-share priority)
+    // LAB ONLY (variant bit 23): fair-share issue priority, see decode_body.  It does what it was built for — the three workgroups of a CU
+    // finish within 20 us of each other instead of 80 — and changes the launch time by < 0.5 % on every shape (profiles/r04_decode_skew.txt):
+    // a CU with one or two workgroups left still draws its share of the bandwidth, so the staggered finish was never the loss.
+    const bool fair = kLab && (p.variant & (1 << 23)) != 0;
     int g0 = 0, g1 = 0;
     // stream mode: the first piece at or after sequence `from` that holds real tiles of this workgroup's range (plan read from LDS)
     auto next_piece = [&](const int from) -> bool {
@@ -694,17 +864,25 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
         if (b >= p.b) return;
         const int excl = b ? stream_plan_get(pl.incl, pl.sh, b - 1) : 0, incl = stream_plan_get(pl.incl, pl.sh, b);
         const int t = incl - excl - X, per = (t + geo.S - 1) / geo.S;
-        tb = sidx * per;
-        te = min(t, tb + per);
-        cnt = (t + per - 1) / per;
+        if (striped) {               // piece sidx = tiles sidx, sidx + S, ...: min(S, t) pieces hold tiles
+            tb = sidx;
+            te = t;
+            cnt = min(geo.S, t);
+        } else {
+            tb = sidx * per;
+            te = min(t, tb + per);
+            cnt = (t + per - 1) / per;
+        }
         if (te <= tb) return;
         first_rec = b * geo.S + b;
         slot = stream_plan_get(pl.slot, pl.sh, b);
         lk = stream_plan_get(pl.lk, pl.sh, b);
+        total = (fair && !striped) ? te - tb : 0;
     } else {
         g0 = w * geo.T;
         if (g0 >= pl.total) return;
         g1 = min(pl.total, g0 + geo.T);
+        total = fair ? g1 - g0 : 0;
         // the range may hold several sequences: the plan moves to LDS (every wave stores the SAME values and reads only after its own
         // stores: no barrier), so that its twelve registers are not carried through the key loops
         const int b0 = stream_plan_find(pl, g0);
@@ -722,8 +900,18 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     for (;;) {
         const unsigned blk = stream_table_bytes(p.b) + (((unsigned)(w + b) * p.h_k + hk) * gblocks + gb) * RB;
         if (tb == 0 && hk == 0 && gb == 0 && tid == 0) stream_publish_seq(p, b, first_rec, cnt);      // (the owner of the sequence's first piece)
-        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, tb, te, cnt == 1 ? 1 : 2, slot, lk, blk);
-        if (geo.uniform || !next_piece(b + 1)) return;
+        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, 0, tb, te,
+                                       cnt == 1 ? 1 : (kLab && counters && !seq_is_xcd_local(b, first_rec, cnt)) ? 3 : 2, slot, lk, blk,
+                                       done, total, striped ? geo.S : 1);
+        done += te - tb;
+        if (kLab && cnt > 1 && counters != nullptr) publish_and_merge(b, first_rec, cnt);      // product: the records are merged by decode_stream_combine_kernel
+        if (geo.uniform || !next_piece(b + 1)) {
+            if (kLab && ts) {
+                __syncthreads();
+                if (tid == 0) ts[3 * wg_id + 2] = wall_clock64();
+            }
+            return;
+        }
         __syncthreads();                                 // the previous piece's in-workgroup merge is done with the LDS
     }
 }
@@ -739,20 +927,34 @@ __global__ __launch_bounds__(256) void decode_stream_combine_kernel(vattn_attn_p
     decode_stream_merge<T, HD, NB, 16, 0>(p, first_rec, cnt, hk, gb, gblocks, b);      // (up to 16 records in ONE round trip)
 }
 
-// gblocks = head-block GROUPS per kv head (ceil(ceil(G/16) / NB)).  The partials of a split launch are merged by combine_kernel in a
-// second launch (the single-launch merges live in the lab copy).
+// gblocks = head-block GROUPS per kv head (ceil(ceil(G/16) / NB)).  `done`: NULL = partials are merged by combine_kernel in a second
+// launch; else one zero-initialised int per (sequence, kv head, group): single-launch merge.
 template <typename T, int HD, bool USE_TR, int NB, int W = DC_WAVES, int PF = 1>
-__global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB > 1) || PF > 1) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append) {
+__global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB > 1) || PF > 1) ? 2 : 3) void decode_kernel(vattn_attn_params p, int num_splits, int gblocks, int fused_append, int* done, int merge_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_ticket;
     int split, hk, gb, b;
     if (p.split_items != nullptr) {
         // length-balanced plan: blockIdx.x = work item (a piece of ONE sequence), blockIdx.y = (kv head, head-block group)
         const vattn_decode_item it = p.split_items[blockIdx.x];
-        decode_body<T, HD, USE_TR, NB, W, PF>(p, 2, gblocks, fused_append, it.index_in_seq, blockIdx.y / gblocks, blockIdx.y % gblocks, it.b, smem,
+        decode_body<T, HD, USE_TR, NB, W, PF>(p, 2, gblocks, fused_append, it.index_in_seq, blockIdx.y / gblocks, blockIdx.y % gblocks, it.b, smem, 0,
                                           (int)blockIdx.x, it.tile_begin, it.tile_end);
         return;
     }
-    if (gridDim.y == 1 && gridDim.z == 1 && gblocks > 1) {
+    int my_splits = num_splits;                        // pieces of THIS head's sequence (== num_splits except in the lab's weighted form)
+    if (kLab && merge_mode == 7) {
+        // LAB: heads get different numbers of workgroups (decode_weighted_splits); blockIdx.x = workgroup of the flattened (head, piece)
+        b = 0;
+        gb = 0;
+        hk = 0;
+        int first = 0;
+        for (int h = 0; h < p.h_k; h++) {
+            int f;
+            const int n = decode_weighted_splits(p, (int)gridDim.x, h, f);
+            if ((int)blockIdx.x >= f && (int)blockIdx.x < f + n) { hk = h; first = f; my_splits = n; }
+        }
+        split = (int)blockIdx.x - first;
+    } else if (gridDim.y == 1 && gridDim.z == 1 && gblocks > 1) {
         // G > 32 query heads per kv head (MQA models): the head-block groups of one (split, kv head, sequence) read the
         // SAME K/V rows.  1-D grid laid out so that those sibling workgroups get consecutive slots on ONE XCD (ids 8 apart):
         // the first reader pulls the rows from HBM, the others hit that XCD's L2
@@ -771,8 +973,10 @@ __global__ __launch_bounds__(64 * W, W > 4 ? 4 : (HD > 128 || (HD == 128 && NB >
         gb = blockIdx.y % gblocks;
         b = blockIdx.z;
     }
-    decode_body<T, HD, USE_TR, NB, W, PF>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, -1, 0, 0, 0, 0, 0, 0,
-                                          (decode_striped(p) && num_splits > 1) ? num_splits : 1);
+    decode_body<T, HD, USE_TR, NB, W, PF>(p, num_splits, gblocks, fused_append, split, hk, gb, b, smem, done ? merge_mode : 0, -1, 0, 0, 0, 0, 0, 0, 0, 0,
+                                          (decode_striped(p) && num_splits > 1) ? my_splits : 1);
+    if (kLab && W == DC_WAVES && done != nullptr && num_splits > 1)
+        decode_release_and_merge<T, HD, NB>(p, num_splits, hk, gb, b, done + ((int64_t)b * p.h_k + hk) * gblocks + gb, &s_ticket, merge_mode);
 }
 
 }  // namespace vattn_k

@@ -16,7 +16,7 @@ namespace vattn_k {
 // ============================================================================================
 
 }  // namespace vattn_k
-#include "decode_body.h"  // DC_WAVES, DC_BN, decode_body / decode_kernel
+#include "decode_body_lab.h"  // DC_WAVES, DC_BN, decode_body / decode_kernel
 namespace vattn_k {
 
 
@@ -25,7 +25,7 @@ namespace vattn_k {
 // partials with independent loads.  Serves the decode form (sq = 1) and the KV-split prefill form.
 // workspace: float o_part[splits][b][sq][h][HD]; float lse_part[splits][b][sq][h]  (log2 domain)
 template <typename T, int HD>
-__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits, int sq) {   // 128 threads: one per split weight, first HD also one per output column
+__global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int num_splits, int sq, int wtotal) {   // 128 threads: one per split weight, first HD also one per output column
     __shared__ float wsm[128];
     __shared__ float red[4];
     const int64_t row = blockIdx.x;                  // (b * sq + q) * h + head
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(128) void combine_kernel(vattn_attn_params p, int n
     const float* oacc = (const float*)p.workspace;
     const int64_t sstride = (int64_t)p.b * sq * p.h;
     const float* lacc = oacc + (int64_t)num_splits * sstride * HD;
+    if (kLab && wtotal > 0) {      // LAB (weighted heads): num_splits is the layout's stride; this head merges its own piece count
+        int f;
+        num_splits = decode_weighted_splits(p, wtotal, hh / (p.h / p.h_k), f);
+    }
     const float my = (tid < num_splits) ? lacc[(int64_t)tid * sstride + row] : -INFINITY;    // num_splits <= 128
     // up to kEarly partials per thread are asked for BEFORE the weights exist: their loads fly together with the LSE loads instead of
     // behind the two reductions (the kernel is two dependent memory latencies long, nothing else)
@@ -161,10 +165,34 @@ static inline int decode_groups(const vattn_attn_params* p) {
     const int nb = decode_nb(p);
     return (blocks + nb - 1) / nb;
 }
-// (the alternative workgroup shapes — 8 / 16 waves, two K/V register sets per wave — and the single-launch merges measured slower and live
-// in the lab copy, tools/lab/csrc/decode_kernels_lab.hip; profiles/r03_kbench_decode_shapes.txt, r02_kbench_decode_merge.txt)
+// Workgroup shape (decode_body.h: W waves per workgroup).  LAB ONLY — variant bit 16: 8 waves (two workgroups per CU); bit 17: 16 waves
+// (one): both measured slower than the 4-wave product shape (B16 @ 32 k: 0.192 ms vs 0.207 / 0.204, profiles/r03_kbench_decode_shapes.txt:
+// the pure-read probe's gain from wider workgroups does not carry over to a kernel whose waves each own a register-resident tile).
+static inline int decode_shape(const vattn_attn_params* p) {
+    if (!kLab || p->d != 128 || decode_nb(p) != 1) return 0;      // the alternative shapes exist for d = 128, one head block per workgroup
+    return (p->variant & 65536) ? 1 : (p->variant & 131072) ? 2 : 0;      // 1: 8 waves (512 slots), 2: 16 waves (256 slots)
+}
+// Two K/V register sets per wave (decode_body.h, PF = 2; two workgroups per CU).  LAB ONLY (variant bit 18): it helps the one shape
+// whose grid is smaller than the chip — B1 @ 32 k: 23.4 -> 21.4 us — and costs 1-8 % on grids that fill it (B16 @ 32 k: 0.191 -> 0.206 ms,
+// profiles/r03_kbench_decode_shapes.txt): a third of the resident waves for twice the bytes per wave is a bad trade once every CU is busy.
+static inline bool decode_pf2(const vattn_attn_params* p) {
+    if (!kLab || p->d != 128 || decode_nb(p) != 1) return false;
+    return (p->variant & 262144) != 0;
+}
 static inline long decode_slots(const vattn_attn_params* p) {      // resident workgroups
+    if (decode_shape(p) == 1) return 512;
+    if (decode_shape(p) == 2) return 256;
+    if (decode_pf2(p)) return 512;
     return (p->d == 128 && decode_nb(p) == 2) ? 512 : 768;
+}
+// Single-launch merge (the last workgroup of a group merges its partials) instead of a second launch of combine_kernel.  LAB ONLY
+// (variant bits 9 / 10): MEASURED SLOWER on MI355X — the release / acquire it needs are agent-scope fences, and on this multi-XCD part
+// each one writes back and invalidates the XCD's L2: B1 @ 32 k 23.7 -> 41.5 us, B16 @ 32 k 203 -> 243 us
+// (profiles/r02_kbench_decode_merge.txt).  The group counters live in a small library-owned device buffer per (device, stream),
+// zeroed when it is created; the kernel leaves them zero.
+static inline bool decode_inline_merge(const vattn_attn_params* p, int splits, int groups) {
+    (void)groups;
+    return splits > 1 && (p->variant & (512 | 1024)) != 0;      // bit 9: fence protocol, bit 10: device-scope accesses, no fence
 }
 // Device-planned stream decomposition (decode_body.h, decode_stream_kernel): the host only picks the number of workgroups per (kv head,
 // head-block group) — from the batch size and the cache VIEW's row count, which the reference's wrapper makes the batch's longest
@@ -175,9 +203,14 @@ static inline long decode_slots(const vattn_attn_params* p) {      // resident w
 int stream_nwg(const vattn_attn_params* p) {
     if (p->seqlen_q != 1 || p->split_items || p->num_splits > 0 || (p->variant & kVariantLegacyDecodePlan)) return 0;
     if (p->b > DC_MAXB || decode_groups(p) != 1) return 0;
+    if (kLab && (decode_shape(p) || decode_pf2(p) || (p->variant & (1 | 256)) || decode_inline_merge(p, 2, 1))) return 0;      // lab shapes / protocols keep the old grid
     const long slots = decode_nb(p) == 2 ? 512 : 768;      // resident workgroups of decode_stream_kernel (its launch bounds)
     const long gps = p->h_k;
-    if (p->num_splits < 0) return (int)std::min<long>(-(long)p->num_splits, 65535);
+    const bool xcd_ranges = kLab && (p->variant & (1 << 27)) != 0;      // lab (XCD-consecutive ranges, decode_stream_kernel): whole rounds of the 8 XCDs
+    if (p->num_splits < 0) {
+        const long forced = std::min<long>(-(long)p->num_splits, 65535);
+        return (int)(xcd_ranges ? std::min(65528L, (forced + 7) & ~7L) : forced);
+    }
     // ONE sequence has nothing to balance, and the two-block workgroups of wide GQA groups (16 < G <= 32) measure 16 % slower on this path
     // (mqa G32 B16 @ 16 k: 42.5 vs 36.5 us): both keep the grid heuristics
     if (p->b < 2 || decode_nb(p) == 2) return 0;
@@ -186,11 +219,38 @@ int stream_nwg(const vattn_attn_params* p) {
     // ~700 keys costs more in prologue and merge than it returns once the chip is full, short contexts still want every CU busy)
     const long per_seq = std::min(48L, std::max(1L, max_tiles / 4));
     const long nwg = std::min(std::max(1L, slots / gps), (long)p->b * per_seq);
+    if (xcd_ranges) return (int)std::max(8L, nwg & ~7L);
     return (int)nwg;
 }
 static size_t stream_workspace_bytes(const vattn_attn_params* p, int nwg) {
     const size_t rf = decode_nb(p) == 2 ? (size_t)(32 * p->d + 32) : (size_t)(16 * p->d + 32);
     return stream_table_bytes(p->b) + (size_t)(nwg + p->b) * p->h_k * rf * sizeof(float);      // (first record, count) per sequence, then the records
+}
+
+// LAB ONLY (variant bit 20; measured equal or slower than the second launch on every shape: ragged 256 sequences 0.223 vs 0.219 ms,
+// B16 @ 32 k 0.200 vs 0.198, B1 @ 32 k 24.3 vs 22.4 us — profiles/r04_decode_stream.txt: the publishing side drains its write-through
+// stores and waits for a device-scope ticket, one workgroup reads all pieces of a sequence).
+// Tickets of the in-launch merge: one int per (sequence, kv head), zero between launches (the merging workgroup resets its own).  One
+// buffer per (device, stream), created — and zeroed, stream-ordered — on first use; never while the stream is being captured into a
+// graph (the launch then takes the two-launch merge; a warm-up call before the capture creates the buffer).
+static int* stream_counters(hipStream_t st, size_t n_ints) {
+    struct Buf { int* p; size_t n; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    Buf& b = bufs[std::make_pair(dev, st)];
+    if (b.p && b.n >= n_ints) return b.p;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    const size_t n = std::max<size_t>(n_ints, 1 << 16);
+    int* np = nullptr;
+    if (hipMalloc((void**)&np, n * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemsetAsync(np, 0, n * sizeof(int), st) != hipSuccess) { (void)hipFree(np); return nullptr; }
+    b.p = np;      // (an older, smaller buffer may still be in use by queued launches: leaked on purpose, at most once per growth step)
+    b.n = n;
+    return np;
 }
 
 template <typename T, int HD, int NB> int launch_decode_stream(const vattn_attn_params* p, hipStream_t st, int nwg) {
@@ -199,40 +259,79 @@ template <typename T, int HD, int NB> int launch_decode_stream(const vattn_attn_
     const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);
-    hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB>), dim3((unsigned)nwg, (unsigned)p->h_k), dim3(64 * DC_WAVES), smem, st, *p, 1, fused_append);
-    hipLaunchKernelGGL((decode_stream_combine_kernel<T, HD, NB>), dim3((unsigned)p->b, (unsigned)p->h_k), dim3(256), 0, st, *p, 1);
+    int* counters = (kLab && (p->variant & kVariantInLaunchMerge)) ? stream_counters(st, (size_t)p->b * p->h_k) : nullptr;
+    hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB>), dim3((unsigned)nwg, (unsigned)p->h_k), dim3(64 * DC_WAVES), smem, st, *p, 1, fused_append, counters);
+    if (!counters) hipLaunchKernelGGL((decode_stream_combine_kernel<T, HD, NB>), dim3((unsigned)p->b, (unsigned)p->h_k), dim3(256), 0, st, *p, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;
 }
 
-template <typename T, int HD, int NB> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
-    constexpr int W = DC_WAVES;
-    if (const int nwg = stream_nwg(p)) return launch_decode_stream<T, HD, NB>(p, st, nwg);
+template <typename T, int HD, int NB, int W = DC_WAVES, int PF = 1> int launch_decode_nb(const vattn_attn_params* p, hipStream_t st) {
+    if constexpr (W == DC_WAVES && PF == 1) {
+        const int nwg = stream_nwg(p);
+        if (nwg > 0) return launch_decode_stream<T, HD, NB>(p, st, nwg);
+    }
+    const bool use_tr = (p->variant & 1) == 0 || W != DC_WAVES || PF != 1;
     const int groups = decode_groups(p);
     const bool planned = p->split_items != nullptr;
     if (planned && (!p->split_seq || p->num_split_items <= 0)) return fail(VATTN_K_ERR_INVALID, "split_items needs split_seq and num_split_items");
     const int splits = planned ? 2 : pick_splits(p, groups, decode_slots(p));
     if (splits > 1 && !p->workspace) return fail(VATTN_K_ERR_INVALID, "split-KV decode needs a workspace");
     dim3 grid(splits, p->h_k * groups, p->b), block(64 * W);
+    // LAB (variant bit 26): one sequence, kv heads get workgroups in proportion to how slowly their bytes stream (decode_weighted_splits):
+    // a 1-D grid of the same total; the partials' layout takes the largest head's count (5/4 of the even share, rounded up)
+    const bool weighted = kLab && (p->variant & (1 << 26)) && !(p->variant & (1 << 25)) && use_tr && p->b == 1 && groups == 1 && !planned && splits > 1 && W == DC_WAVES && PF == 1 && p->h_k > 1;
+    const int wtotal = weighted ? splits * p->h_k : 0;
+    const int layout_splits = weighted ? (splits * 5) / 4 + 2 : splits;
+    if (weighted) grid = dim3((unsigned)wtotal, 1, 1);
     if (planned) grid = dim3((unsigned)p->num_split_items, p->h_k * groups, 1);
     if (groups > 1 && !(p->variant & 64) && !planned) {            // sibling groups share an XCD (variant bit 6: plain 3-D grid, for A/B)
         const long w = (long)splits * p->h_k * p->b;
         grid = dim3((unsigned)(((w + 7) / 8) * 8 * groups));
     }
-    const size_t smem = (size_t)W * 16 * HD * 4 + W * 16 * 4 * 2;   // merge area >= V staging (W x 8 KiB)
+    const size_t smem = (size_t)W * 16 * HD * 4 + W * 16 * 4 * 2 + (W > DC_WAVES ? NB * (HD / 32) * 1024 : 0);   // merge area >= V staging (W x 8 KiB), then Q^T fragments
+    if (smem > 48 * 1024) {
+        static const bool once = [] {
+            (void)hipFuncSetAttribute((const void*)decode_kernel<T, HD, true, NB, W, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)W * 16 * HD * 4 + W * 16 * 4 * 2 + NB * (HD / 32) * 1024));
+            return true;
+        }();
+        (void)once;
+    }
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);        // seqlen_knew > 1: separate append launch
     const vattn_attn_params& q = *p;
-    hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, splits, groups, fused_append);
+    int* done = (W == DC_WAVES && PF == 1 && !planned && decode_inline_merge(p, splits, groups)) ? merge_counters(st, (size_t)p->b * p->h_k * groups) : nullptr;
+    const bool inline_merge = done != nullptr;
+    const int mm = weighted ? 7 : !inline_merge ? 0 : (p->variant & 1024) ? 2 : 1;
+    if constexpr (W != DC_WAVES || PF != 1) {
+        hipLaunchKernelGGL((decode_kernel<T, HD, true, NB, W, PF>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
+    } else {
+        bool plain = false;
+        if constexpr (kLab) {      // variant bit 0: V^T fragments by plain LDS reads
+            if (!use_tr) {
+                hipLaunchKernelGGL((decode_kernel<T, HD, false, NB>), grid, block, smem, st, q, splits, groups, fused_append, done, mm);
+                plain = true;
+            }
+        }
+        if (!plain) hipLaunchKernelGGL((decode_kernel<T, HD, true, NB>), grid, block, smem, st, q, layout_splits, groups, fused_append, done, mm);
+    }
     if (planned) hipLaunchKernelGGL((combine_items_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q);
-    else if (splits > 1) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, splits, 1);
+    else if (splits > 1 && !inline_merge) hipLaunchKernelGGL((combine_kernel<T, HD>), dim3(p->b * p->h), dim3(128), 0, st, q, layout_splits, 1, wtotal);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;
 }
 
 template <typename T, int HD> int launch_decode_t(const vattn_attn_params* p, hipStream_t st) {
+#ifdef VATTN_LAB
+    if constexpr (HD == 128) {
+        const int shape = decode_shape(p);
+        if (shape == 1) return launch_decode_nb<T, 128, 1, 8>(p, st);
+        if (shape == 2) return launch_decode_nb<T, 128, 1, 16>(p, st);
+        if (decode_pf2(p)) return launch_decode_nb<T, 128, 1, DC_WAVES, 2>(p, st);
+    }
+#endif
     return decode_nb(p) == 2 ? launch_decode_nb<T, HD, 2>(p, st) : launch_decode_nb<T, HD, 1>(p, st);
 }
 
@@ -349,7 +448,8 @@ size_t decode_workspace_bytes(const vattn_attn_params* p) {
     const int groups = decode_groups(p);
     const int splits = pick_splits(p, groups, decode_slots(p));
     if (splits <= 1) return 0;
-    return (size_t)splits * p->b * p->h * (p->d + 1) * sizeof(float);
+    const int layout_splits = (kLab && (p->variant & (1 << 26)) && p->b == 1) ? (splits * 5) / 4 + 2 : splits;      // (lab: weighted heads; a little more than needed when the form is not taken)
+    return (size_t)layout_splits * p->b * p->h * (p->d + 1) * sizeof(float);
 }
 
 }  // namespace vattn_k

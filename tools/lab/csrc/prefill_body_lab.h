@@ -1,11 +1,20 @@
 // prefill_body.h — the 8/4-wave x 32-row prefill workgroup (see prefill_kernels.hip for the overview) as a device function plus
-// the kernel that maps a grid onto it.  Included by prefill_kernels.hip.  PRODUCT source: the compile-time ablation switch, the in-launch
-// merge of key-range shares and the fused hybrid launch that calls the body from a persistent loop live in the lab copies
-// (tools/lab/csrc/prefill_body_lab.h, hybrid_lab.hip).  The product instantiates USE_TR = true, MSUM = false only.
+// the kernel that maps a grid onto it.  Included by prefill_kernels.hip and hybrid_kernels.hip.
 #pragma once
 #include "attn_common.h"
 
 namespace vattn_k {
+
+// Debug-only ablation switch for tools/kbench.py (cdna guide §5.4: "ablate before optimizing"); the product
+// build leaves it at 0.  1: exp2 replaced by a multiply; 2: V^T fragments not read from LDS; 3: K fragments
+// not read from LDS; 4: no global loads / LDS stores of the next tile; 5: no per-tile barrier; 6: no softmax VALU at all
+#ifndef VATTN_ABLATE
+#define VATTN_ABLATE 0
+#endif
+#ifndef VATTN_ABLATE_MASK
+#define VATTN_ABLATE_MASK (VATTN_ABLATE ? (1 << VATTN_ABLATE) : 0)
+#endif
+#define ABL(k) ((VATTN_ABLATE_MASK >> (k)) & 1)
 
 // WAVES waves per workgroup, each owning QC blocks of 32 query rows (BM = 32*QC*WAVES rows per workgroup).
 // QC = 2 halves the LDS fragment traffic per flop (each K / V^T fragment read feeds two MFMAs) at the price
@@ -15,7 +24,8 @@ namespace vattn_k {
 // The work of ONE workgroup — query block qb of head h of batch entry b, key-range share `split` of nsplit — as a device function:
 // prefill_kernel below maps blockIdx to it; hybrid_kernel (hybrid_kernels.hip) calls it from a persistent loop.
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const int b, const int h, const int qb, const int split, const int nsplit, char* smem) {
+__device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const int b, const int h, const int qb, const int split, const int nsplit, char* smem,
+                                             int* merge_counter = nullptr, int* s_ticket = nullptr, const int merge_mode = 0) {
     using X = Tr<T>;
     using V8 = typename X::v8;
     using S = PfSmem<HD>;
@@ -164,7 +174,7 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
 
     auto tile_body = [&](int t, uint4 (&kld)[PASSES], uint4 (&vld)[PASSES], const uint4 (&kwr)[PASSES], const uint4 (&vwr)[PASSES]) {
         const int buf = (t - tb) & 1;
-        stage_load(t + 2, kld, vld);     // two tiles ahead (past the last tile: all lanes out of range)
+        if (!ABL(4)) stage_load(t + 2, kld, vld);     // two tiles ahead (past the last tile: all lanes out of range)
 
         const int n0 = t * PF_BN;
         // wave-uniform tile classification
@@ -181,6 +191,7 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
             // accumulate latency of one chain is covered by the other chain's issue slot; the K fragments of
             // step kk+1 are read from LDS while the MFMAs of step kk run (explicit two-deep register ring)
             auto kfrag = [&](int kb, int kk) -> V8 {
+                if (ABL(3)) return qf[0][(kk + kb) % KK];
                 return *(const V8*)(ksm + (kb * 32 + l31) * S::kRowBytes + (((2 * kk + g) ^ (l31 & SWZ)) << 4));
             };
             V8 a_cur[2], a_nxt[2];
@@ -213,6 +224,7 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
             float alpha[QC];
 #pragma unroll
             for (int qc = 0; qc < QC; qc++) {
+                if (ABL(6)) { alpha[qc] = 1.f; continue; }
                 if (need_mask) {
                     const int my_q = qw0 + 32 * qc + l31;
                     const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;     // last visible key for this query
@@ -240,7 +252,7 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         float e;
-                        e = fast_exp2(__builtin_fmaf(s[kb][qc][r], sc, -msub));
+                        if (ABL(1)) e = s[kb][qc][r] * sc; else e = fast_exp2(__builtin_fmaf(s[kb][qc][r], sc, -msub));
                         s[kb][qc][r] = e;
                         if (!MSUM) psum += e;
                     }
@@ -280,7 +292,9 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
 #pragma unroll
                     for (int db = 0; db < DB; db++) {
                         V8 a;
-                        if constexpr (USE_TR) {
+                        if (ABL(2)) {
+                            a = qf[0][(db + u + 2 * kb) % KK];
+                        } else if constexpr (USE_TR) {
                             const int i16 = lane & 15, dh = (lane >> 4) & 1;
                             const char* a1 = vsm + db * S::kVSubBytes + (krow0 + 4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2;
                             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
@@ -299,8 +313,8 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
                     }
                 }
         }
-        stage_write(buf ^ 1, kwr, vwr);   // tile t+1 (issued one iteration ago) into the buffer last read in iteration t-1
-        __syncthreads();
+        if (!ABL(4)) stage_write(buf ^ 1, kwr, vwr);   // tile t+1 (issued one iteration ago) into the buffer last read in iteration t-1
+        if (!ABL(5) && !ABL(4)) __syncthreads();
     };
     for (int t = tb; t < nt; t += 2) {
         tile_body(t, kregA, vregA, kregB, vregB);
@@ -326,15 +340,21 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
                     f32x4 w;
 #pragma unroll
                     for (int e = 0; e < 4; e++) w[e] = o[db][qc][4 * tq + e] * inv;
-                    *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    if (kLab && merge_mode == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) store_dev(opart + 32 * db + 8 * tq + 4 * g + e, w[e]);
+                    } else {
+                        *(f32x4*)(opart + 32 * db + 8 * tq + 4 * g) = w;
+                    }
                 }
             if (g == 0) {
                 const float lv = (l_tot == 0.f || l_tot != l_tot) ? -INFINITY : (m_run[qc] * sc + __log2f(l_tot));
-                lpart[row] = lv;
+                if (kLab && merge_mode == 2) store_dev(lpart + row, lv);
+                else lpart[row] = lv;
             }
         } else if (my_q < Sq) {
             T* optr = (T*)p.out + (p.q_start ? 0 : (int64_t)b * p.o_batch_stride) + (q_first + my_q) * p.o_row_stride + (int64_t)h * p.o_head_stride;
-            if ((((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0)) {
+            if ((((p.o_row_stride | p.o_head_stride | p.o_batch_stride) & 7) == 0) && !ABL(7)) {
                 // 16-byte stores: lane l (g = 0) and lane l + 32 (g = 1) hold d..d+3 and d+4..d+7 of the SAME row for every
                 // 8-wide d group tq; one v_permlane32_swap per dword hands the g = 0 lane the whole even group and the g = 1
                 // lane the whole odd group -> 8 x 16 B per lane instead of 16 x 8 B (the store tail is issue-bound)
@@ -373,14 +393,20 @@ __device__ __forceinline__ void prefill_body(const vattn_attn_params& p, const i
             }
         }
     }
+    // single-launch merge of the key-range shares (attn_common.h): the workgroup that completes the block's last share merges them
+    if (kLab && nsplit > 1 && merge_counter != nullptr)
+        prefill_release_and_merge<T, HD>(p, nsplit, b, h, q_wg0, min(Sq, q_wg0 + BM), q_first, merge_counter, s_ticket, merge_mode);
 }
 
 template <typename T, int HD, bool USE_TR, int WAVES, int QC, bool MSUM>
-__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb, int nsplit) {
+__global__ __launch_bounds__(64 * WAVES, (QC == 2 || HD > 128) ? 1 : 2) void prefill_kernel(vattn_attn_params p, int order, int nqb, int nsplit, int* done, int merge_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_ticket;
     int b, h, qb, split;
     if (!wg_to_work(p, order, nqb, nsplit, b, h, qb, split)) return;
-    prefill_body<T, HD, USE_TR, WAVES, QC, MSUM>(p, b, h, qb, split, nsplit, smem);      // (key-range shares are merged by combine_rows_kernel)
+    // done: one zeroed counter per (sequence, head, query block) = single-launch merge of the key-range shares; NULL = combine_rows_kernel
+    prefill_body<T, HD, USE_TR, WAVES, QC, MSUM>(p, b, h, qb, split, nsplit, smem,
+                                                 done ? done + ((int64_t)b * p.h + h) * nqb + qb : nullptr, &s_ticket, merge_mode);
 }
 
 }  // namespace vattn_k

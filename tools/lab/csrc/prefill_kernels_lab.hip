@@ -21,9 +21,292 @@ namespace vattn_k {
 // ============================================================================================
 
 }  // namespace vattn_k
-#include "prefill_body.h"  // prefill_body / prefill_kernel
+#include "prefill_body_lab.h"  // prefill_body / prefill_kernel
 namespace vattn_k {
 
+
+#ifdef VATTN_LAB
+// --------------------------------------------------------------------------------------------
+// Interleaved, software-pipelined prefill (8 waves x 32 query rows, d = 128): S(t+1) = K(t+1).Q^T is accumulated while
+// the softmax of tile t is evaluated, then P(t).V(t); K runs one tile ahead of V in LDS (iteration t reads K[(t+1)&1] and
+// V[t&1] and stores K(t+2) -> K[t&1], V(t+1) -> V[(t+1)&1] before its single barrier).  The ISSUE ORDER is written out by
+// hand instead of left to the scheduler: the loop body is a sequence of 32 groups, each
+//     { one MFMA ; the LDS fragment read(s) for the MFMA two groups ahead ; a 3-6 instruction slice of VALU work }
+// closed by a scheduling barrier, so every MFMA is followed by independent VALU of the SAME wave.  Measured on gfx950
+// (tools/mfma_overlap_probe.cpp, tools/attn_skeleton_probe.cpp): VALU issued by the wave that owns the running MFMA
+// hides almost completely (16 MFMA + 64 VALU: +5 %), VALU issued by the OTHER wave of the SIMD costs the matrix pipe
+// about half its issue time.  VALU placement per tile (138 instructions for 32 MFMAs):
+//     QK(t+1) MFMAs 0-15 : exp2 / row-sum / f16 pack of P(t) values 0-19          (ten pairs, ~4.4 per MFMA)
+//     PV(t)   MFMAs 0-7  : P(t) values 20-31                                       (six pairs, ~5.3 per MFMA)
+//     PV(t)   MFMAs 8-15 : running max of S(t+1) (v_max3 chain), then m / alpha    (~3 per MFMA)
+// so the row max never sits on the critical path between two matrix phases.
+// --------------------------------------------------------------------------------------------
+#ifndef ILV_AHEAD
+#define ILV_AHEAD 2
+#endif
+template <typename T>
+__global__ __launch_bounds__(512, 2) void prefill_ilv_kernel(vattn_attn_params p, int order, int nqb) {
+    using X = Tr<T>;
+    using V8 = typename X::v8;
+    constexpr int HD = 128;
+    using S = PfSmem<HD>;
+    constexpr int WAVES = 8, NT = 64 * WAVES, BM = 32 * WAVES;
+    constexpr int KK = HD / 16, DB = HD / 32, CPR = HD / 8;
+    constexpr int PASSES = (PF_BN * CPR) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ksm0 = smem;                          // K[0], K[1]
+    char* const vsm0 = smem + 2 * S::kTileBytes;      // V[0], V[1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+    int b, h, qb, split_unused;
+    if (!wg_to_work(p, order, nqb, 1, b, h, qb, split_unused)) return;
+    const int hk = h / (p.h / p.h_k);
+    const int slot = __builtin_amdgcn_readfirstlane(p.cache_batch_idx ? p.cache_batch_idx[b] : b);
+    const int Lk = min(p.seqlen_k, __builtin_amdgcn_readfirstlane((p.cache_seqlens ? p.cache_seqlens[b] : p.seqlen_k) + p.seqlen_knew));   // never beyond the cache view
+    const int Sq = p.seqlen_q;
+    const bool causal = p.is_causal != 0;
+    const int off = Lk - Sq;
+    const int q_wg0 = qb * BM;
+    const int qw0 = q_wg0 + wave * 32;
+    const int my_q = qw0 + l31;
+
+    int n_end = Lk;
+    if (causal) n_end = min(Lk, q_wg0 + BM + off);
+    if (n_end < 0) n_end = 0;
+    const int nt = (n_end + PF_BN - 1) / PF_BN;
+    int t_live = nt;      // tiles [0, t_live) hold at least one visible (row, key) pair for THIS wave (wave-uniform)
+    if (causal) {
+        const int last_key = qw0 + 31 + off;
+        t_live = last_key < 0 ? 0 : min(nt, last_key / PF_BN + 1);
+    }
+
+    const T* kbase = (const T*)p.k_cache + (int64_t)slot * p.k_batch_stride + (int64_t)hk * p.k_head_stride;
+    const T* vbase = (const T*)p.v_cache + (int64_t)slot * p.v_batch_stride + (int64_t)hk * p.v_head_stride;
+    const T* qptr = (const T*)p.q + (int64_t)b * p.q_batch_stride + (int64_t)my_q * p.q_row_stride + (int64_t)h * p.q_head_stride;
+
+    V8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (my_q < Sq) v = *(const uint4*)(qptr + 16 * kk + 8 * g);
+        qf[kk] = as_v8<V8>(v);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // retire the Q loads here (see prefill_kernel)
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) asm volatile("" : "+v"(qf[kk]));
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; i++) o[i] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.softmax_scale * kLog2e;
+
+    const unsigned k_rs_bytes = (unsigned)p.k_row_stride * 2u, v_rs_bytes = (unsigned)p.v_row_stride * 2u;
+    unsigned koff[PASSES], voff[PASSES], klds[PASSES], vlds[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int idx = ps * NT + tid;
+        const int row = idx / CPR, c = idx % CPR;
+        koff[ps] = (unsigned)row * k_rs_bytes + (unsigned)c * 16u;
+        voff[ps] = (unsigned)row * v_rs_bytes + (unsigned)c * 16u;
+        klds[ps] = (unsigned)(row * S::kRowBytes + ((c ^ (row & 15)) << 4));                 // XOR-swizzled K image
+        vlds[ps] = (unsigned)((c >> 2) * S::kVSubBytes + row * 64 + ((c & 3) << 4));         // [d/32][key][32 d] V image
+    }
+    const T* kbase_u = uniform_ptr(kbase);
+    const T* vbase_u = uniform_ptr(vbase);
+    auto tile_rsrc = [&](const T* base, int64_t row_stride, unsigned rs_bytes, int t) {
+        int rem = Lk - t * PF_BN;
+        rem = rem < 0 ? 0 : (rem > PF_BN ? PF_BN : rem);
+        return make_rsrc(base + (int64_t)t * PF_BN * row_stride, (unsigned)rem * rs_bytes);
+    };
+    uint4 kreg[PASSES], vreg[PASSES];
+    auto load_k = [&](int t) {
+        const __amdgpu_buffer_rsrc_t r = tile_rsrc(kbase_u, p.k_row_stride, k_rs_bytes, t);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) kreg[ps] = buf_load16(r, koff[ps]);
+    };
+    auto load_v = [&](int t) {
+        const __amdgpu_buffer_rsrc_t r = tile_rsrc(vbase_u, p.v_row_stride, v_rs_bytes, t);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) vreg[ps] = buf_load16(r, voff[ps]);
+    };
+    auto store_k = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) *(uint4*)(ksm0 + buf * S::kTileBytes + klds[ps]) = kreg[ps];
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) *(uint4*)(vsm0 + buf * S::kTileBytes + vlds[ps]) = vreg[ps];
+    };
+    // K fragment of S^T MFMA i (k-step i>>1, key block i&1); V^T fragment of PV MFMA j (P group j>>2, d block j&3)
+    const unsigned kfrag_row = (unsigned)(l31 * S::kRowBytes);
+    auto kfrag = [&](const char* ksm, int i) -> V8 {
+        const int kk = i >> 1, kb = i & 1;
+        return *(const V8*)(ksm + kb * 32 * S::kRowBytes + kfrag_row + (((2 * kk + g) ^ (l31 & 15)) << 4));
+    };
+    const int i16 = lane & 15, dh = (lane >> 4) & 1;
+    const unsigned vfrag_lane = (unsigned)((4 * g + (i16 >> 2)) * 64 + (16 * dh + 4 * (i16 & 3)) * 2);
+    auto vfrag = [&](const char* vsm, int j) -> V8 {
+        const int pg = j >> 2, db = j & 3;
+        const int krow0 = (pg >> 1) * 32 + 16 * (pg & 1);
+        const char* a1 = vsm + db * S::kVSubBytes + krow0 * 64 + vfrag_lane;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a1 + 8 * 64));
+        return join_tr<V8>(lo, hi);
+    };
+    auto mask_tile = [&](int tt, f32x16& x0, f32x16& x1) {
+        const int n0 = tt * PF_BN;
+        if ((n0 + PF_BN > Lk) || (causal && (n0 + PF_BN - 1 > qw0 + off))) {
+            const int lim = causal ? min(Lk - 1, my_q + off) : Lk - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = n0 + 8 * (r >> 2) + 4 * g + (r & 3);
+                if (key > lim) x0[r] = -INFINITY;
+                if (key + 32 > lim) x1[r] = -INFINITY;
+            }
+        }
+    };
+
+    // ---- prologue: K(0), K(1), V(0) into LDS; S(0); its row max ----
+    load_k(0);
+    store_k(0);
+    load_k(1);
+    store_k(1);
+    load_v(0);
+    store_v(0);
+    __syncthreads();
+    f32x16 sc0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 sc1 = sc0;      // S(t): key blocks 0 and 1 of the current tile
+    float msub = 0.f, alpha = 1.f;   // softmax shift of the current tile, rescale factor it implies for O and l
+    if (t_live > 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * KK; i++) {
+            if (i & 1) sc1 = X::mfma32(kfrag(ksm0, i), qf[i >> 1], sc1);
+            else sc0 = X::mfma32(kfrag(ksm0, i), qf[i >> 1], sc0);
+        }
+        mask_tile(0, sc0, sc1);
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
+        mloc = fmaxf(mloc, swap_halves(mloc));
+        m_run = mloc;
+        msub = (m_run == -INFINITY) ? 0.f : m_run * sc;
+    }
+
+    for (int t = 0; t < nt; t++) {
+        load_k(t + 2);      // in flight across the whole iteration (out of range past the end: zeros, no access)
+        load_v(t + 1);
+        if (t < t_live) {
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // rare after the first tiles; exact
+#pragma unroll
+                for (int i = 0; i < DB; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+            }
+            const char* ksm = ksm0 + ((t + 1) & 1) * S::kTileBytes;
+            const char* vsm = vsm0 + (t & 1) * S::kTileBytes;
+            f32x16 sn0 = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 sn1 = sn0;
+            V8 pf[4];            // P(t) in the PV B-operand layout: group pg <-> keys of S^T registers 8u..8u+7 of key block kb, pg = 2kb+u
+            float psum = 0.f;
+            // P pair pr (0..15): key block pr>>3, S^T registers 2*(pr&7), +1  ->  pf[pr>>2] elements 2*(pr&3), +1
+            auto exp_pair = [&](int pr) {
+                const int kb = pr >> 3, r0 = 2 * (pr & 7);
+                const float e0 = fast_exp2(__builtin_fmaf(kb ? sc1[r0] : sc0[r0], sc, -msub));
+                const float e1 = fast_exp2(__builtin_fmaf(kb ? sc1[r0 + 1] : sc0[r0 + 1], sc, -msub));
+                psum += e0;
+                psum += e1;
+                pf[pr >> 2][2 * (pr & 3)] = X::cvt(e0);
+                pf[pr >> 2][2 * (pr & 3) + 1] = X::cvt(e1);
+            };
+            constexpr int AH = ILV_AHEAD;      // fragment reads run AH groups ahead of the MFMA that consumes them
+            V8 kf[2 * KK];
+#pragma unroll
+            for (int i = 0; i < AH; i++) kf[i] = kfrag(ksm, i);
+            __builtin_amdgcn_sched_barrier(0);
+            V8 vf[16];
+            // ---- S(t+1) = K(t+1).Q^T   ||   P(t) pairs 0-9 ----
+#pragma unroll
+            for (int i = 0; i < 2 * KK; i++) {
+                if (i + AH < 2 * KK) kf[i + AH] = kfrag(ksm, i + AH);
+                else vf[i + AH - 2 * KK] = vfrag(vsm, i + AH - 2 * KK);     // the last AH groups prefetch the first V^T fragments
+                if (i & 1) sn1 = X::mfma32(kf[i], qf[i >> 1], sn1);
+                else sn0 = X::mfma32(kf[i], qf[i >> 1], sn0);
+#pragma unroll
+                for (int pr = (i * 10 + 15) / 16; pr < ((i + 1) * 10 + 15) / 16; pr++) exp_pair(pr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- O^T += V^T(t).P(t)^T, first half   ||   P(t) pairs 10-15 ----
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                vf[j + AH] = vfrag(vsm, j + AH);
+                o[j & 3] = X::mfma32(vf[j], pf[j >> 2], o[j & 3]);
+#pragma unroll
+                for (int pr = 10 + (j * 6 + 7) / 8; pr < 10 + ((j + 1) * 6 + 7) / 8; pr++) exp_pair(pr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            l_run = l_run * alpha + psum;
+            // ---- second half   ||   row max of S(t+1) (raw: a diagonal / ragged next tile is redone below) ----
+            // NOTE no control flow between the groups of one iteration: hipcc sinks the VALU slices of a block into a
+            // later block when their results are only used there, across scheduling barriers
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 8; j < 16; j++) {
+                if (j + AH < 16) vf[j + AH] = vfrag(vsm, j + AH);
+                o[j & 3] = X::mfma32(vf[j], pf[j >> 2], o[j & 3]);
+                {
+                    const int q = j - 8;      // S(t+1) registers 2q, 2q+1 of both key blocks
+                    mx = fmaxf(fmaxf(mx, sn0[2 * q]), sn0[2 * q + 1]);
+                    mx = fmaxf(fmaxf(mx, sn1[2 * q]), sn1[2 * q + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool has_next = t + 1 < t_live;
+            const int n1 = (t + 1) * PF_BN;
+            if (has_next && ((n1 + PF_BN > Lk) || (causal && (n1 + PF_BN - 1 > qw0 + off)))) {     // wave-uniform, rare
+                mask_tile(t + 1, sn0, sn1);
+                mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaxf(sn0[r], sn1[r]));
+            }
+            mx = fmaxf(mx, swap_halves(mx));
+            const float m_new = has_next ? fmaxf(m_run, mx) : m_run;
+            msub = (m_new == -INFINITY) ? 0.f : m_new * sc;
+            alpha = fast_exp2(m_run * sc - msub);
+            m_run = m_new;
+            sc0 = sn0;
+            sc1 = sn1;
+        }
+        store_k(t & 1);            // K(t+2): the buffer held K(t), whose QK finished in iteration t-1 on every wave
+        store_v((t + 1) & 1);      // V(t+1): the buffer held V(t-1), last read in iteration t-1
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + swap_halves(l_run);
+    const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+    if (my_q < Sq) {
+        T* optr = (T*)p.out + (int64_t)b * p.o_batch_stride + (int64_t)my_q * p.o_row_stride + (int64_t)h * p.o_head_stride;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int tq = 0; tq < 4; tq++) {
+                typename X::v4 w;
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[e] = X::cvt(o[db][4 * tq + e] * inv);
+                *(typename X::v4*)(optr + 32 * db + 8 * tq + 4 * g) = w;
+            }
+        if (p.softmax_lse && g == 0) {
+            const float lse = (l_tot == 0.f) ? INFINITY : (m_run * p.softmax_scale + __logf(l_tot));
+            p.softmax_lse[((int64_t)b * p.h + h) * Sq + my_q] = lse;
+        }
+    }
+}
+
+#endif  // VATTN_LAB
 
 // Same merge for the KV-split prefill form, where there are b * sq * h output rows (tens of thousands) and at most 16
 // partials each: one WAVE per row (4 rows per 256-thread block), lane l < splits holds partial l's LSE, the weights are
@@ -145,7 +428,9 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
     // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
     if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6 || pl.tiling == 7))) pl.tiling = 1;
-    if (pl.tiling == 2 || pl.tiling == 6) pl.tiling = 1;     // lab-only kernels (tools/lab/csrc/prefill_kernels_lab.hip; validate() rejects them before this)
+    if (!kLab && (pl.tiling == 2 || pl.tiling == 6)) pl.tiling = 1;     // lab-only kernels (validate() rejects them before this)
+    if (pl.tiling == 6 && (p->q_lens || p->rotary_cos_sin)) pl.tiling = 1;      // the interleaved kernel has no batched-chunk / fused-RoPE form
+    if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
     // keys an average query block sees.  Without a host-side bound the cache VIEW's row count stands in for the lengths, exactly as in
     // FlashAttention's own heuristic (flash_api.cpp:258-323 sizes the split from seqlen_k = k_cache.size(1)); the kernels divide the keys a
     // block REALLY sees (device-side lengths), so an over-estimate costs balance, never correctness.  [Rounds 1-3 assumed seqlen_q here:
@@ -239,9 +524,20 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     return pl;
 }
 
-// (the single-launch merge of the key-range shares — variant bits 14 / 15 — measured slower and lives in the lab copy: profiles/r02_kbench_prefill_merge.txt)
-template <typename T, int HD, int WAVES, int QC> void launch_prefill(const vattn_attn_params* p, hipStream_t st, int nsplit) {
-    constexpr bool MSUM = false;
+// Counters of the single-launch merge of a KV-split prefill (one per (sequence, head, query block)), or NULL: two-launch form
+// (combine_rows_kernel).  Opt-in only.  Variant bit 14 = mode 1, ordered by agent-scope fences: they flush the XCD's L2, which the
+// query blocks' K/V prefix re-reads live on — TP8 8 k prompt 0.201 -> 0.274 ms, 512-token chunk @ 16 k 0.073 -> 0.151 ms
+// (profiles/r02_kbench_prefill_merge.txt).  Variant bit 15 = mode 2: partials through device-scope stores / loads, no fence.
+static inline int prefill_merge_mode(const vattn_attn_params* p, int nsplit) {
+    if (nsplit <= 1) return 0;
+    return (p->variant & 32768) ? 2 : (p->variant & 16384) ? 1 : 0;
+}
+static int* prefill_merge_counters(const vattn_attn_params* p, hipStream_t st, int nsplit, int nqb) {
+    if (!prefill_merge_mode(p, nsplit)) return nullptr;
+    return merge_counters(st, (size_t)p->b * p->h * nqb);
+}
+
+template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(const vattn_attn_params* p, hipStream_t st, bool use_tr, int nsplit) {
     constexpr int BM = 32 * QC * WAVES;
     const int nqb = (p->seqlen_q + BM - 1) / BM;
     int order;
@@ -258,17 +554,28 @@ template <typename T, int HD, int WAVES, int QC> void launch_prefill(const vattn
     const size_t smem = PfSmem<HD>::kTotal;
     static const bool attr_once = [] {   // 64 KiB of dynamic LDS per workgroup
         (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, true, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
+        if constexpr (kLab) (void)hipFuncSetAttribute((const void*)prefill_kernel<T, HD, false, WAVES, QC, MSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<HD>::kTotal);
         return true;
     }();
     (void)attr_once;
-    hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit);
-    if (nsplit > 1) {
+    int* done = prefill_merge_counters(p, st, nsplit, nqb);
+    const int mm = done ? prefill_merge_mode(p, nsplit) : 0;
+    bool plain = false;
+    if constexpr (kLab) {      // variant bit 0: V^T fragments by plain LDS reads instead of ds_read_b64_tr_b16
+        if (!use_tr) {
+            hipLaunchKernelGGL((prefill_kernel<T, HD, false, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
+            plain = true;
+        }
+    }
+    if (!plain) hipLaunchKernelGGL((prefill_kernel<T, HD, true, WAVES, QC, MSUM>), grid, block, smem, st, *p, order, nqb, nsplit, done, mm);
+    if (nsplit > 1 && !done) {
         const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
         hipLaunchKernelGGL((combine_rows_kernel<T, HD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, nsplit, p->seqlen_q, rows);
     }
 }
 
 template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, hipStream_t st) {
+    const bool use_tr = (p->variant & 1) == 0;
     if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
     if constexpr (HD == 128) {
         if (p->pf_items) {        // host-planned work list: prefill64 pieces longest first, then the merge of the split blocks
@@ -298,17 +605,38 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     bool launched = false;
     if constexpr (HD == 128) {
         if (pl.tiling == 7) {
-            launch_prefill64(p, st, pl.nsplit, nullptr, 0);
-            if (pl.nsplit > 1) {
+            int* done = prefill_merge_counters(p, st, pl.nsplit, (p->seqlen_q + 255) / 256);
+            launch_prefill64(p, st, pl.nsplit, done, done ? prefill_merge_mode(p, pl.nsplit) : 0);
+            if (pl.nsplit > 1 && !done) {
                 const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
                 hipLaunchKernelGGL((combine_rows_kernel<T, 128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, pl.nsplit, p->seqlen_q, rows);
             }
             launched = true;
         }
+#ifdef VATTN_LAB
+        else if (pl.tiling == 2) {
+            launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);
+            launched = true;
+        } else if (pl.tiling == 6) {
+            const int nqb = (p->seqlen_q + 255) / 256;
+            static const bool once6 = [] {
+                (void)hipFuncSetAttribute((const void*)prefill_ilv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, PfSmem<128>::kTotal);
+                return true;
+            }();
+            (void)once6;
+            int order;
+            const dim3 grid = prefill_grid(p, nqb, &order);
+            hipLaunchKernelGGL((prefill_ilv_kernel<T>), grid, dim3(512), PfSmem<128>::kTotal, st, *p, order, nqb);
+            launched = true;
+        }
+#endif
     }
     if (launched) {
-    } else if (pl.tiling == 4) launch_prefill<T, HD, 4, 1>(p, st, pl.nsplit);
-    else launch_prefill<T, HD, 8, 1>(p, st, pl.nsplit);
+    } else if (pl.tiling == 4) launch_prefill<T, HD, 4, 1, false>(p, st, use_tr, pl.nsplit);
+#ifdef VATTN_LAB
+    else if ((p->variant & 16) && HD == 128) launch_prefill<T, HD == 128 ? 128 : HD, 8, 1, HD == 128>(p, st, use_tr, pl.nsplit);      // denominator on the matrix pipe
+#endif
+    else launch_prefill<T, HD, 8, 1, false>(p, st, use_tr, pl.nsplit);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
     return VATTN_K_OK;

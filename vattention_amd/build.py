@@ -119,12 +119,13 @@ def build_lib(force=False):
     return out
 
 
-# The lab library compiles the product sources with -DVATTN_LAB — except where the laboratory has its OWN copy of a kernel
-# (tools/lab/csrc/): prefill64 since round 6 (the product's prefill64_kernels.hip carries one schedule and no measurement code; the lab
-# copy keeps every alternative schedule, ablation, stamp and price-list build behind `variant` bits).
+# The lab library (round 6): the kernels' LAB COPIES under tools/lab/csrc/ — every alternative schedule, operand path, in-launch merge
+# protocol, timing ablation, clock stamp and the fused hybrid launch, behind `variant` bits — plus the product sources that have no lab
+# side (the C entry points, the persistent prefill kernel, cache_flat).  The product sources carry none of that code any more.
 LAB_DIR_SRC = os.path.join(ROOT, "tools", "lab", "csrc")
-LAB_SOURCES = ("attn_api.hip", "prefill_kernels.hip", os.path.join(LAB_DIR_SRC, "prefill64_lab.hip"), "prefill64p_kernels.hip", "decode_kernels.hip", "cache_kernels.hip",
-               "hybrid_kernels.hip")
+LAB_SOURCES = ("attn_api.hip", os.path.join(LAB_DIR_SRC, "prefill_kernels_lab.hip"), os.path.join(LAB_DIR_SRC, "prefill64_lab.hip"), "prefill64p_kernels.hip",
+               os.path.join(LAB_DIR_SRC, "decode_kernels_lab.hip"), "cache_kernels.hip", os.path.join(LAB_DIR_SRC, "hybrid_lab.hip"))
+LAB_HEADERS = ("decode_body_lab.h", "prefill_body_lab.h")
 
 
 def build_lab(force=False):
@@ -136,8 +137,8 @@ def build_lab(force=False):
     os.makedirs(outdir, exist_ok=True)
     out = os.path.join(outdir, "libvattn_lab.so")
     srcs = [f if os.path.isabs(f) else os.path.join(CSRC, f) for f in LAB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill64_common.h"), os.path.join(CSRC, "prefill_body.h"), os.path.join(CSRC, "decode_body.h"),
-                   os.path.join(ROOT, "include", "vattn_kernels.h")]
+    deps = srcs + [os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "prefill64_common.h")] + [os.path.join(LAB_DIR_SRC, h) for h in LAB_HEADERS] + [
+        os.path.join(ROOT, "include", "vattn_kernels.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-DVATTN_LAB", "-Wno-inline-asm", "-I" + CSRC, *UNROLL_FLAGS]

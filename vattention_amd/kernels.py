@@ -117,6 +117,8 @@ def klib_lab():
     global _lab
     if _lab is None:
         import os
+        if os.environ.get("VATTN_NO_LAB") == "1":      # the product-only test run (tests/conftest.py, -m "gpu and not lab")
+            raise RuntimeError("a lab kernel was requested in a product-only run (VATTN_NO_LAB=1): this test belongs to the `lab` marker")
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lab", "libvattn_lab.so")
         if not os.path.exists(path):
             raise RuntimeError("lab kernels requested (variant bits outside the product set) but tools/lab/libvattn_lab.so is missing: "
