@@ -318,8 +318,10 @@ def main():
             res = c4_rank_share_leg(make_runner, mem_for_kv)
         elif a.leg == "hybrid_sarathi":
             res = hybrid_sarathi_leg(make_runner, mem_for_kv)
+        elif a.leg == "scale_series":
+            res = scale_series_leg(make_runner, mem_for_kv, 1)
         else:
-            raise SystemExit("--leg must be dynamic, dynamic_tp8_rank, c4_rank_share_128k, hybrid_sarathi or capacity")
+            raise SystemExit("--leg must be dynamic, dynamic_tp8_rank, c4_rank_share_128k, scale_series, hybrid_sarathi or capacity")
         _emit(json.dumps({a.leg: res}))
         return
     if a.qps:       # stand-alone open-loop replay (not a bench line)

@@ -425,7 +425,7 @@ def test_decode_stream_plan(Hq, Hkv, B, lo, hi, nwg, append):
     ref32 = flash_attn_with_kvcache_ref(q, kc2[:, :ml], vc2[:, :ml], kn, vn, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     dev = lambda t: t.to(DEV) if t is not None else None
     outs = {}
-    for variant in enabled(0, 1 << 20, 1 << 27, (1 << 27) | (1 << 20)):      # bit 27 (lab): the ranges of one XCD are consecutive; with bit 20 a sequence inside one XCD is handed over in its L2
+    for variant in enabled(0, 1 << 20, 1 << 27, (1 << 27) | (1 << 20), 1 << 21):      # bit 27 (lab): the ranges of one XCD are consecutive; with bit 20 a sequence inside one XCD is handed over in its L2
         kg, vg = kc.to(DEV), vc.to(DEV)
         for rep in range(2):
             out, lse = flash_attn_with_kvcache(dev(q), kg[:, :ml], vg[:, :ml], dev(kn), dev(vn), cache_seqlens=dev(cl), cache_batch_idx=dev(idx),
@@ -435,7 +435,7 @@ def test_decode_stream_plan(Hq, Hkv, B, lo, hi, nwg, append):
         assert torch.equal(kg.cpu(), kc1) and torch.equal(vg.cpu(), vc1)
         outs[variant] = (out.cpu(), lse.cpu())
     # (the two merges fold the records in chunks of 16 / 8: the same sum up to the order of a few fp32 multiply-adds)
-    for v in enabled(1 << 20, 1 << 27, (1 << 27) | (1 << 20)):
+    for v in enabled(1 << 20, 1 << 27, (1 << 27) | (1 << 20), 1 << 21):      # bit 21 (lab, round 6): a drawn queue of fixed 16-tile pieces
         assert (outs[0][0].float() - outs[v][0].float()).abs().max().item() <= 1e-3 and torch.allclose(outs[0][1], outs[v][1], atol=1e-4, rtol=1e-5), v
     if not append:      # an empty sequence attends to nothing: zeros, LSE = +inf as FlashAttention reports it
         for b, l in enumerate(lens):

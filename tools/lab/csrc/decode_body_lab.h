@@ -697,6 +697,16 @@ __device__ __forceinline__ int stream_plan_find(const StreamPlan& pl, const int 
     return (l << pl.sh) + __builtin_amdgcn_readlane(hit, l);
 }
 
+// (lab, drawn queue) the same from the copy of the plan in LDS (inclusive scan in s_plan[0 .. B)): binary search, wave-uniform
+__device__ __forceinline__ int stream_plan_find_lds(const int* s_plan, const int B, const int g) {
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (__builtin_amdgcn_readfirstlane(s_plan[mid]) > g) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ void stream_publish_seq(const vattn_attn_params& p, const int b, const int first_rec, const int cnt) {
     int* t = (int*)p.workspace + 2 * b;
     t[0] = first_rec;
@@ -771,9 +781,10 @@ __device__ __forceinline__ void decode_stream_merge(const vattn_attn_params& p, 
 // second launch; LAB: one zero-initialised int per (sequence, kv head, group), left zero by the launch (the merging workgroup resets its
 // counter): merge inside the launch.
 template <typename T, int HD, bool USE_TR, int NB>
-__global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_kernel(vattn_attn_params p, int gblocks, int fused_append, int* counters) {
+__global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_kernel(vattn_attn_params p, int gblocks, int fused_append, int* counters, int* qctr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;                           // (lab: in-launch merge)
+    __shared__ int s_next;                             // (lab, round 6: the next piece's ticket of the drawn queue)
     __shared__ int s_plan[3 * DC_MAXB];                // stream mode: the plan, for the pieces after the first
     const int tid = threadIdx.x;
     // grid (workgroups per head, kv heads): consecutive workgroup ids — consecutive XCDs — stream consecutive ranges of ONE kv head.  [The
@@ -797,7 +808,20 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     StreamPlan pl;
     stream_plan_load(p, X, pl);
     if (kLab && ts && tid == 0) ts[3 * wg_id + 1] = wall_clock64();
-    const StreamGeom geo = stream_geom(pl.total, pl.maxt, p.b, nwg);
+    StreamGeom geo = stream_geom(pl.total, pl.maxt, p.b, nwg);
+    // LAB (round 6, variant bit 21): a QUEUE OF FIXED SMALL PIECES.  The tile space is cut into pieces of P positions
+    // (split_reserved bits 8-15, default 16 = 512 keys); the resident workgroups start with piece blockIdx.x and DRAW further pieces from a
+    // device counter (one per kv head: qctr[blockIdx.y]; the ticket for the next piece is asked for when a piece starts and read when it
+    // ends), so a workgroup that runs ahead takes more pieces and the launch ends evenly — at the price of one record per piece.  Records,
+    // the per-sequence table and the merge launch are those of the stream decomposition with T = P and "nwg" = the number of pieces.
+    const bool queue = qctr != nullptr;
+    int npieces = 0;
+    if (queue) {
+        const int P = ((p.split_reserved >> 8) & 255) ? ((p.split_reserved >> 8) & 255) : 16;
+        geo.uniform = false;
+        geo.T = P;
+        npieces = (pl.total + P - 1) / P;
+    }
     const bool striped = decode_striped_all(p) && geo.uniform && geo.S > 1;      // (lab; the product stripes the single-sequence launch only)
     // LAB (variant bit 27): the ranges of ONE XCD are consecutive — physical workgroup x (XCD x % 8: the
     // dispatcher deals consecutive workgroup ids round-robin over the XCDs) takes logical range (x % 8) * n8 + x / 8, n8 = ranges per XCD —
@@ -857,6 +881,27 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
         }
         return false;
     };
+    // (lab, drawn queue) the ticket in flight names this workgroup's next range; a range is taken until one holds real tiles.  Tickets
+    // 0 .. npieces - 1 are drawn in all (one per range looked at) and whoever draws the last one puts the counter back to zero.
+    bool queue_has_ticket = false;
+    auto draw_piece = [&]() -> bool {
+        while (queue_has_ticket) {
+            __syncthreads();
+            const int v = s_next;
+            __syncthreads();
+            if (v == npieces - 1 && tid == 0) qctr[blockIdx.y] = 0;
+            w = nwg + v;
+            if (w >= npieces) {
+                queue_has_ticket = false;
+                return false;
+            }
+            g0 = w * geo.T;
+            g1 = min(pl.total, g0 + geo.T);
+            if (tid == 0) s_next = atomicAdd(qctr + blockIdx.y, 1);
+            if (next_piece(stream_plan_find_lds(s_plan, p.b, g0))) return true;
+        }
+        return false;
+    };
     if (geo.uniform) {
         // piece w % S of sequence w / S: each sequence divides ITS OWN tiles into S pieces; everything from the plan's registers
         b = w / geo.S;
@@ -883,6 +928,8 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
         if (g0 >= pl.total) return;
         g1 = min(pl.total, g0 + geo.T);
         total = fair ? g1 - g0 : 0;
+        if (queue && tid == 0) s_next = atomicAdd(qctr + blockIdx.y, 1);      // the ticket of this workgroup's SECOND piece, in flight under the first
+        queue_has_ticket = queue;
         // the range may hold several sequences: the plan moves to LDS (every wave stores the SAME values and reads only after its own
         // stores: no barrier), so that its twelve registers are not carried through the key loops
         const int b0 = stream_plan_find(pl, g0);
@@ -895,7 +942,7 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
                 s_plan[2 * DC_MAXB + i] = pl.lk[e];
             }
         }
-        if (!next_piece(b0)) return;
+        if (!next_piece(b0) && !draw_piece()) return;
     }
     for (;;) {
         const unsigned blk = stream_table_bytes(p.b) + (((unsigned)(w + b) * p.h_k + hk) * gblocks + gb) * RB;
@@ -906,6 +953,7 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
         done += te - tb;
         if (kLab && cnt > 1 && counters != nullptr) publish_and_merge(b, first_rec, cnt);      // product: the records are merged by decode_stream_combine_kernel
         if (geo.uniform || !next_piece(b + 1)) {
+            if (queue && draw_piece()) continue;
             if (kLab && ts) {
                 __syncthreads();
                 if (tid == 0) ts[3 * wg_id + 2] = wall_clock64();

@@ -222,9 +222,17 @@ int stream_nwg(const vattn_attn_params* p) {
     if (xcd_ranges) return (int)std::max(8L, nwg & ~7L);
     return (int)nwg;
 }
+// LAB (round 6, variant bit 21): the drawn queue of fixed pieces (decode_body_lab.h) has one record per piece of P positions
+static inline bool decode_queue(const vattn_attn_params* p) { return (p->variant & (1 << 21)) != 0; }
+static inline long decode_queue_piece(const vattn_attn_params* p) { return ((p->split_reserved >> 8) & 255) ? ((p->split_reserved >> 8) & 255) : 16; }
 static size_t stream_workspace_bytes(const vattn_attn_params* p, int nwg) {
     const size_t rf = decode_nb(p) == 2 ? (size_t)(32 * p->d + 32) : (size_t)(16 * p->d + 32);
-    return stream_table_bytes(p->b) + (size_t)(nwg + p->b) * p->h_k * rf * sizeof(float);      // (first record, count) per sequence, then the records
+    long recs = nwg;
+    if (decode_queue(p)) {      // at most ceil(B x (tiles of the view + switch allowance) / P) pieces
+        const long max_tiles = std::max(1L, ((long)p->seqlen_k + DC_BN - 1) / DC_BN) + 8;
+        recs = std::max<long>(nwg, ((long)p->b * max_tiles + decode_queue_piece(p) - 1) / decode_queue_piece(p) + 1);
+    }
+    return stream_table_bytes(p->b) + (size_t)(recs + p->b) * p->h_k * rf * sizeof(float);      // (first record, count) per sequence, then the records
 }
 
 // LAB ONLY (variant bit 20; measured equal or slower than the second launch on every shape: ragged 256 sequences 0.223 vs 0.219 ms,
@@ -260,7 +268,13 @@ template <typename T, int HD, int NB> int launch_decode_stream(const vattn_attn_
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);
     int* counters = (kLab && (p->variant & kVariantInLaunchMerge)) ? stream_counters(st, (size_t)p->b * p->h_k) : nullptr;
-    hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB>), dim3((unsigned)nwg, (unsigned)p->h_k), dim3(64 * DC_WAVES), smem, st, *p, 1, fused_append, counters);
+    // (lab, bit 21) the queue's counters: one per kv head behind the merge tickets' region, zero between launches (the last draw resets its own)
+    int* qctr = nullptr;
+    if (decode_queue(p) && !counters) {
+        int* base = stream_counters(st, (size_t)DC_MAXB * 64 + 64);
+        qctr = base ? base + (size_t)DC_MAXB * 64 : nullptr;
+    }
+    hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB>), dim3((unsigned)nwg, (unsigned)p->h_k), dim3(64 * DC_WAVES), smem, st, *p, 1, fused_append, counters, qctr);
     if (!counters) hipLaunchKernelGGL((decode_stream_combine_kernel<T, HD, NB>), dim3((unsigned)p->b, (unsigned)p->h_k), dim3(256), 0, st, *p, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
