@@ -204,6 +204,11 @@ const char* vattn_last_error(const vattn_t* m);
 int vattn_vmm_selfcheck(int device, uint32_t detail[3]);
 /* HIP VMM granularity probe for a device: 0 on success. */
 int vattn_hip_granularity(int device, uint64_t* min_gran, uint64_t* rec_gran);
+/* HIP runtime / driver versions (hipRuntimeGetVersion / hipDriverGetVersion) of the process.  The TLB-invalidation step of the unmap
+ * policy rests on observed driver behaviour, not on an API contract (csrc/hip_backend.cpp, profiles/r06_tlb_flush_probe.txt: nothing the
+ * VMM API itself offers carries the invalidation on ROCm 7.2); it is therefore PROVEN on the device by vattn_vmm_selfcheck at every
+ * vattn_create, whatever the version, and a failed proof names these versions in vattn_last_error.  0 on success. */
+int vattn_hip_versions(int* runtime_version, int* driver_version);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         "vattn_get_counts": (i32, [vp, C.POINTER(u64)]),
         "vattn_last_error": (C.c_char_p, [vp]),
         "vattn_hip_granularity": (i32, [i32, C.POINTER(u64), C.POINTER(u64)]),
+        "vattn_hip_versions": (i32, [C.POINTER(i32), C.POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

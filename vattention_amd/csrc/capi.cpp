@@ -8,6 +8,7 @@
 namespace vattn {
 int make_hip_backend(int device, vattn_backend_ops* ops);
 int hip_vmm_selfcheck(int device, const vattn_backend_ops* ops, uint32_t detail[3]);   // vmm_selfcheck.hip
+int hip_versions(int* rt, int* drv);                                                       // hip_backend.cpp
 }
 
 struct vattn_handle {
@@ -40,11 +41,14 @@ int vattn_create(const vattn_config* cfg, const vattn_backend_ops* backend, vatt
         auto it = verdict.find(cfg->device);
         if (it == verdict.end()) it = verdict.emplace(cfg->device, vattn::hip_vmm_selfcheck(cfg->device, &ops, nullptr)).first;
         if (it->second != 0) {
-            h->pm->set_error(it->second > 0
-                ? "HIP VMM self-check failed: a kernel still reads the OLD physical page after hipMemUnmap + hipMemMap at the same "
+            int rt = 0, drv = 0;
+            (void)vattn::hip_versions(&rt, &drv);
+            const std::string ver = " [HIP runtime " + std::to_string(rt) + ", driver " + std::to_string(drv) + "]";
+            h->pm->set_error((it->second > 0
+                ? std::string("HIP VMM self-check failed: a kernel still reads the OLD physical page after hipMemUnmap + hipMemMap at the same "
                   "virtual address, even after the TLB-invalidation step — refusing to start (reclaimed KV pages would leak between "
-                  "requests).  Verified on ROCm 7.2 / gfx950; set VATTN_FLAG_NO_VMM_SELFCHECK only to debug."
-                : "HIP VMM self-check could not run (driver error)");
+                  "requests).  The step was verified on ROCm 7.2 / gfx950 and is re-proven at every start; set VATTN_FLAG_NO_VMM_SELFCHECK only to debug.")
+                : std::string("HIP VMM self-check could not run (driver error)")) + ver);
             *out = h;
             return VATTN_ERR_DRIVER;
         }
@@ -95,6 +99,8 @@ int vattn_vmm_selfcheck(int device, uint32_t detail[3]) {
     if (vattn::make_hip_backend(device, &ops) != 0) return VATTN_ERR_DRIVER;
     return vattn::hip_vmm_selfcheck(device, &ops, detail);
 }
+
+int vattn_hip_versions(int* rt, int* drv) { return vattn::hip_versions(rt, drv) == 0 ? VATTN_OK : VATTN_ERR_DRIVER; }
 
 int vattn_hip_granularity(int device, uint64_t* mn, uint64_t* rec) {
     vattn_backend_ops ops;

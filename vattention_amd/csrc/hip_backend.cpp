@@ -124,6 +124,14 @@ static int h_tlb_flush(void* c) {
     return 0;
 }
 
+int hip_versions(int* rt, int* drv) {      // include/vattn.h vattn_hip_versions
+    int a = 0, b = 0;
+    if (hipRuntimeGetVersion(&a) != hipSuccess || hipDriverGetVersion(&b) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (rt) *rt = a;
+    if (drv) *drv = b;
+    return 0;
+}
+
 static int h_quiesce(void*) {
     hipError_t e = hipDeviceSynchronize();
     return e == hipSuccess ? 0 : hip_fail("hipDeviceSynchronize", e);
