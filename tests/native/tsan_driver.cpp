@@ -16,6 +16,7 @@ extern "C" void vattn_fake_counters(uint64_t*);
 namespace vattn {
 int make_hip_backend(int, vattn_backend_ops*) { return -1; }   // never used: a backend table is always passed
 int hip_vmm_selfcheck(int, const vattn_backend_ops*, uint32_t*) { return -1; }
+int hip_versions(int*, int*) { return -1; }
 }
 
 int main() {

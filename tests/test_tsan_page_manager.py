@@ -9,6 +9,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _skip_only_if_the_sanitizer_is_missing(stderr: str, what: str):
+    """a toolchain without the sanitizer runtime skips; a compile or link error in OUR sources fails (round 6: a missing stub once hid
+    both tests behind a skip)"""
+    if "undefined reference" in stderr or "error:" in stderr.replace("ld returned 1 exit status", ""):
+        if "tsan" not in stderr and "asan" not in stderr and "ubsan" not in stderr and "sanitizer" not in stderr.lower():
+            pytest.fail(what + " build failed in the package's own sources:\n" + stderr[-1500:])
+    pytest.skip(what + " build unavailable: " + stderr[-300:])
+
+
 def test_mapper_thread_is_race_free_under_tsan():
     src = [os.path.join(ROOT, "vattention_amd/csrc/page_manager.cpp"), os.path.join(ROOT, "vattention_amd/csrc/capi.cpp"),
            os.path.join(ROOT, "tests/native/fake_backend.cpp"), os.path.join(ROOT, "tests/native/tsan_driver.cpp")]
@@ -16,7 +25,7 @@ def test_mapper_thread_is_race_free_under_tsan():
         exe = os.path.join(d, "tsan_driver")
         r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", *src, "-o", exe], capture_output=True, text=True)
         if r.returncode != 0:
-            pytest.skip("ThreadSanitizer build unavailable: " + r.stderr[-300:])
+            _skip_only_if_the_sanitizer_is_missing(r.stderr, "ThreadSanitizer")
         env = dict(os.environ, TSAN_OPTIONS="exitcode=66 halt_on_error=0")
         run = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
         if "FATAL: ThreadSanitizer" in run.stderr and "unexpected memory mapping" in run.stderr:
@@ -37,7 +46,7 @@ def test_page_manager_is_clean_under_asan_and_ubsan():
         r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread", *src, "-o", exe],
                            capture_output=True, text=True)
         if r.returncode != 0:
-            pytest.skip("AddressSanitizer build unavailable: " + r.stderr[-300:])
+            _skip_only_if_the_sanitizer_is_missing(r.stderr, "AddressSanitizer")
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1 exitcode=67", UBSAN_OPTIONS="print_stacktrace=1")
         run = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
         if "LeakSanitizer has encountered a fatal error" in run.stderr or "LeakSanitizer does not work under ptrace" in run.stderr:
