@@ -220,6 +220,16 @@ def mfma_views(roofs: dict, clock_mhz, traffic) -> None:
             if traffic and traffic.get("mfma_busy_frac") is not None:
                 r["mfma_busy_frac"] = traffic["mfma_busy_frac"]
                 r["mfma_busy_source"] = traffic["source"] + " (separate --pmc pass over the same launch, not this run)"
+    # `kernel_us_per_launch`: the kernels' own mean duration (rocprofv3 kernel trace of the same workload, committed) beside the event time
+    # `ms_per_launch`, which also holds the launch boundaries — a 0.697 vs 0.717 decode reading can then be told apart as gap or kernel
+    for key, short in (("roofline_prefill", "prefill"), ("roofline_decode", "decode")):
+        r = roofs.get(key)
+        ku = ((traffic or {}).get("kernel_us") or {}).get(short)
+        if r and ku:
+            r["kernel_us_per_launch"] = ku
+            r["kernel_us_source"] = traffic["source"] + " (rocprofv3 --kernel-trace --stats of this workload, not this run; decode = stream kernel + merge kernel)"
+            if roofs.get("roofline", {}).get("kernel") == r.get("kernel"):
+                roofs["roofline"]["kernel_us_per_launch"] = ku
 
 
 _REAL_STDOUT = None
@@ -433,7 +443,9 @@ def main():
             if os.path.exists(pth) and world == 1 and valid:
                 tj = json.load(open(pth))
                 traffic = {"prefill": tj["prefill_yi6b_n32702"]["hbm_bytes_per_launch"], "decode": tj["decode_yi6b_b16_32k"]["hbm_bytes_per_launch"],
-                           "mfma_busy_frac": tj["prefill_yi6b_n32702"].get("mfma_busy_frac"), "source": "profiles/" + name}
+                           "mfma_busy_frac": tj["prefill_yi6b_n32702"].get("mfma_busy_frac"),
+                           "kernel_us": {"prefill": tj["prefill_yi6b_n32702"].get("kernel_us"), "decode": tj["decode_yi6b_b16_32k"].get("kernel_us")},
+                           "source": "profiles/" + name}
                 break
     except Exception:
         traffic = None

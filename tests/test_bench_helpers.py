@@ -31,7 +31,8 @@ def test_mfma_utilisation_three_ways():
     assert abs(r["roofline"]["frac_at_clock"] - r["roofline"]["achieved"] / (2500.0 * 1811.0 / 2400.0)) < 1e-4
     assert r["roofline"]["mfma_busy_frac"] == 0.655 and r["roofline_prefill"]["frac_at_clock"] == r["roofline"]["frac_at_clock"]
     d = bench.rooflines({"attn_decode": {"ms": 3.0, "timed": 10, "n": 10, "work": 10 * 1.2e9}})
-    bench.mfma_views(d, 1811.0, None)
+    bench.mfma_views(d, 1811.0, {"kernel_us": {"decode": 188.1, "prefill": None}, "source": "profiles/x.json"})
+    assert d["roofline_decode"]["kernel_us_per_launch"] == 188.1 and d["roofline"]["kernel_us_per_launch"] == 188.1
     assert "frac_at_clock" not in d["roofline"]            # an HBM-bound kernel's peak does not move with the shader clock
 
 
