@@ -37,6 +37,12 @@ Every line (every N, static or dynamic) carries:
                       (query row, visible key) pairs of the timed steps.
   `clock_mhz_mean` / `power_w_mean`  shader clock and board power sampled over the timed region by a side process
                       (vattention_amd/telemetry.py): a power-capped MI355X runs this kernel between ~1.5 and 2.4 GHz, boxes differ.
+  `roofline.frac_at_clock` / `.mfma_busy_frac` / `.kernel_us_per_launch` (round 6)  MFMA utilisation three ways — of the 2.5 PF spec peak (`frac`), of the
+                      peak at the sustained clock, and the matrix-pipe duty of the committed SQ pass — and the kernels' own durations from the
+                      committed rocprofv3 trace beside the event times (profiles/rNN_traffic.json, tools/traffic_json.py).
+  `legs.scale_series` ONE fixed workload at every N — Yi-34B (56 / 8 heads / N, 60 layers), one 131 072-token request in 16 k chunks — so that tokens/s
+                      across the N = 1 / 2 / 4 / 8 lines is a strong-scaling series (the lines' `value`s follow BASELINE.json's per-N configs);
+                      N > 1 adds `scaling_reference`: the same step once more WITHOUT the control-plane exchange (= --rank-of N on one GPU).
 N = 1 adds, outside the timed region: `cold_wave`, `full_trace_50req`, `dynamic` (configs[2] shape, closed loop, time-weighted KV
 utilisation), `dynamic_tp8_rank` (the TP8 rank shape: 256 sequences resident at full depth, deferred reclamation on / off),
 `c4_rank_share_128k` (ONE rank's share of configs[3]'s 128 k request: Yi-34B TP2 heads, 16 k chunks — the metric's 128 k half on one
