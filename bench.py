@@ -334,6 +334,10 @@ def main():
             res = c4_rank_share_leg(make_runner, mem_for_kv)
         elif a.leg == "hybrid_sarathi":
             res = hybrid_sarathi_leg(make_runner, mem_for_kv)
+        elif a.leg == "hybrid_sarathi_1k_chunks":
+            res = hybrid_sarathi_leg(make_runner, mem_for_kv, 1024)
+        elif a.leg == "hybrid_sarathi_512_chunks":
+            res = hybrid_sarathi_leg(make_runner, mem_for_kv, 512)
         elif a.leg == "scale_series":
             res = scale_series_leg(make_runner, mem_for_kv, 1)
         else:
@@ -556,6 +560,8 @@ def main():
         leg("c4_rank_share_128k", c4_rank_share_leg, make_runner, mem_for_kv)
         leg("scale_series", scale_series_leg, make_runner, mem_for_kv, 1)
         leg("hybrid_sarathi", hybrid_sarathi_leg, make_runner, mem_for_kv)
+        # the regime the reference's POD kernel targets: chunks that leave CUs free (1 024 tokens x 32 heads = 128 workgroups on 256 CUs)
+        leg("hybrid_sarathi_1k_chunks", hybrid_sarathi_leg, make_runner, mem_for_kv, 1024)
         leg("open_loop", open_loop_leg, make_runner, mem_for_kv, lengths256, 6.0, 256)
         leg("capacity", capacity_leg, dev, mem_for_kv)
 
@@ -676,6 +682,9 @@ def main():
         if extras.get("hybrid_sarathi"):
             dig["hybrid_sarathi"] = {k: extras["hybrid_sarathi"].get(k) for k in ("tokens_per_s_serial", "tokens_per_s_streams", "streams_over_serial", "hybrid_iterations",
                                                                                   "overlapped_iterations", "error")}
+        if extras.get("hybrid_sarathi_1k_chunks"):
+            dig["hybrid_sarathi_1k_chunks"] = {k: extras["hybrid_sarathi_1k_chunks"].get(k) for k in ("tokens_per_s_serial", "tokens_per_s_streams", "streams_over_serial",
+                                                                                                      "hybrid_iterations", "overlapped_iterations", "error")}
         if extras.get("open_loop"):
             dig["open_loop_qps6"] = {k: extras["open_loop"].get(k) for k in ("request_e2e_time_normalized_p50", "request_e2e_time_normalized_p99", "sync_map_ms_per_step_p99")}
         if extras.get("capacity"):
@@ -849,7 +858,7 @@ def c4_rank_share_leg(make_runner, mem_for_kv) -> dict:
         r.close()
 
 
-def hybrid_sarathi_leg(make_runner, mem_for_kv) -> dict:
+def hybrid_sarathi_leg(make_runner, mem_for_kv, chunk=4096) -> dict:
     """SURVEY §8 f1 on the reference's own scheduler shape (vattention_flashattention_pod_wrapper.py:121-203, pod_attn/tests/
     attn_sweep.py:82-97): Yi-6B, 64 requests of 8 192 tokens (P:D = 15: 7 680 prefill + 512 decode), Sarathi 4 k chunks — every prefill
     chunk rides with the decode batch of the sequences already running (up to 63).  The SAME trace twice: backend fa_vattn (prefill
@@ -857,11 +866,11 @@ def hybrid_sarathi_leg(make_runner, mem_for_kv) -> dict:
     a host-side estimate says so).  A fused prefill || decode launch does not exist in the product (three measured designs lose to
     the serial order)."""
     import torch
-    out = {"workload": "yi-6b TP=1, 64 requests x 8192 tokens (7680 prefill + 512 decode), Sarathi 4096-token chunks with piggy-backed decodes, 32 layers"}
+    out = {"workload": "yi-6b TP=1, 64 requests x 8192 tokens (7680 prefill + 512 decode), Sarathi %d-token chunks with piggy-backed decodes, 32 layers" % chunk}
     for name, backend in (("serial", "fa_vattn"), ("streams", "fa_streams")):
         r = make_runner("yi-6b", 1, 8192, 2 << 20, 64, backend, min(mem_for_kv, 40 << 30))
         try:
-            r.run_static_trace(2, 8192, 15.0, 4096)                      # warm-up
+            r.run_static_trace(2, 8192, 15.0, chunk)                     # warm-up
             torch.cuda.synchronize()
             r.stats.__init__()
             hyb = {"n": 0, "ov": 0}
@@ -876,7 +885,7 @@ def hybrid_sarathi_leg(make_runner, mem_for_kv) -> dict:
                     return v
                 wr._plan_overlap = counted
             t0 = time.perf_counter()
-            r.run_static_trace(64, 8192, 15.0, 4096)
+            r.run_static_trace(64, 8192, 15.0, chunk)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             tk = r.stats.prefill_tokens + r.stats.decode_tokens
