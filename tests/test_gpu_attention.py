@@ -822,3 +822,30 @@ def test_decode_call_is_hip_graph_capturable():
         torch.cuda.synchronize()
         assert torch.equal(out, ref), step
         assert torch.equal(kg, ke) and torch.equal(vg, ve)
+
+
+@pytest.mark.lab
+@pytest.mark.parametrize("sel,sub", [(1, 0), (5, 0), (6, 0), (7, 13), (7, 4)], ids=["vt_preread", "scalar_scale", "mov_fmac", "soffset_dma", "price_list_v_mov"])
+def test_prefill64_round6_lab_builds_are_bit_identical_to_the_product(sel, sub):
+    """The exact-arithmetic builds of round 6's issue-budget study (tools/lab/csrc/prefill64_lab.hip, variant bits 28-30 + the sub-selector in
+    split_reserved bits 16-23) run the product's arithmetic in the product's order: bit-identical outputs, on a causal chunk over a prefix and on a
+    ragged whole prompt.  (The product kernel carries the winners: V^T pre-read, scalar scale, DMA distances in the scalar offset.)"""
+    import ctypes as C
+    from tools.kbench import params
+    from vattention_amd import kernels as K
+    st = torch.cuda.current_stream().cuda_stream
+    for n, c, Hq, Hkv in ((3000, 500, 8, 2), (777, 1000, 4, 4)):
+        torch.manual_seed(n)
+        q = torch.randn(1, n, Hq, 128, device=DEV, dtype=torch.float16)
+        kc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        vc = torch.randn(1, c + n, Hkv, 128, device=DEV, dtype=torch.float16)
+        cl = torch.tensor([c + n], dtype=torch.int32, device=DEV)
+        outs = []
+        for v, s_ in ((14, 0), (14 | (sel << 28), sub)):
+            p, keep = params(q, kc, vc, cl, variant=v)
+            p.split_reserved |= s_ << 16
+            lib = K.klib_for(v)
+            assert lib.vattn_flash_attn_with_kvcache(C.byref(p), C.c_void_p(st)) == 0, K.last_error(lib)
+            torch.cuda.synchronize()
+            outs.append(keep[0].clone())
+        assert torch.equal(outs[0], outs[1]), "lab build %d.%d differs from the product: max |diff| %.3e" % (sel, sub, (outs[0].float() - outs[1].float()).abs().max().item())

@@ -140,8 +140,8 @@ def test_layer_ordered_mapping_with_models_that_pass_no_layer_id():
     kernel of the iteration: layers >= sync_layers of a new prompt would otherwise run over pages the mapper thread has not mapped
     yet (a GPU memory fault).  Many layers and many small pages so that the mapper is still busy when forward() is entered."""
     from vattention_amd import vattention
-    st = _runner_vs_oracle("fa_vattn", num_layers=12, page=64 << 10, prompts=[3900, 2500], decode_steps=2, pool_groups=100,
-                           pass_layer_id=False)
+    st = _runner_vs_oracle("fa_vattn", num_layers=12, page=64 << 10, prompts=[2900, 1700], decode_steps=2, pool_groups=100,
+                           pass_layer_id=False)      # (12 layers x 2 tensors x 46 + 27 pages of 64 KiB: the mapper is busy for milliseconds)
     assert st["layered_batches"] >= 2
     assert vattention._layered_pending is False
 

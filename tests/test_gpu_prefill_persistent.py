@@ -89,8 +89,11 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
-@pytest.mark.parametrize("name,Hq,Hkv,chunks", SHAPES, ids=[s[0] for s in SHAPES])
+# (the two largest shapes' oracle runs take 15-25 s each: bf16 rides on the three smaller ones, whose queues hold every seam kind)
+@pytest.mark.parametrize("name,Hq,Hkv,chunks,dtype", [(s[0], s[1], s[2], s[3], dt) for s in SHAPES for dt in (torch.float16, torch.bfloat16)
+                                                      if not (dt == torch.bfloat16 and s[0] in ("tp8_8k", "llama8b_3prompts"))],
+                         ids=["%s-%s" % (s[0], "f16" if dt == torch.float16 else "bf16") for s in SHAPES for dt in (torch.float16, torch.bfloat16)
+                              if not (dt == torch.bfloat16 and s[0] in ("tp8_8k", "llama8b_3prompts"))])
 def test_persistent_work_list_matches_the_oracle_and_the_per_piece_launch(name, Hq, Hkv, chunks, dtype):
     plans = [("persistent", dict(persistent=True)), ("drawn_t9", dict(persistent=True, force_tiles=9, drawn=True)),
              ("assigned_t9", dict(persistent=True, force_tiles=9, drawn=False)), ("drawn_t9_again", dict(persistent=True, force_tiles=9, drawn=True)),
