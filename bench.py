@@ -40,6 +40,11 @@ Every line (every N, static or dynamic) carries:
   `roofline.frac_at_clock` / `.mfma_busy_frac` / `.kernel_us_per_launch` (round 6)  MFMA utilisation three ways — of the 2.5 PF spec peak (`frac`), of the
                       peak at the sustained clock, and the matrix-pipe duty of the committed SQ pass — and the kernels' own durations from the
                       committed rocprofv3 trace beside the event times (profiles/rNN_traffic.json, tools/traffic_json.py).
+  `roofline.other.power_ceiling` (round 6, N = 1)  what the board's POWER budget leaves of the MFMA peak on random operands, measured on this box
+                      right after the timed region by tools/power_ceiling_probe (whole-chip instruction streams, no data flow, ~0.7 s each):
+                      `mfma_only_tflops` (back-to-back v_mfma_f32_32x32x16_f16) and `tile_step_stream_tflops` (the same with the prefill tile
+                      step's VALU mix and LDS fragment reads per MFMA); `prefill_over_mfma_only` / `prefill_over_tile_step_stream` = the prefill
+                      kernel's achieved rate over them.  The part clocks to its power cap: these, not 2.5 PF, bound a chip-filling kernel.
   `legs.scale_series` ONE fixed workload at every N — Yi-34B (56 / 8 heads / N, 60 layers), one 131 072-token request in 16 k chunks — so that tokens/s
                       across the N = 1 / 2 / 4 / 8 lines is a strong-scaling series (the lines' `value`s follow BASELINE.json's per-N configs);
                       N > 1 adds `scaling_reference`: the same step once more WITHOUT the control-plane exchange (= --rank-of N on one GPU).
@@ -98,6 +103,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dynamic", action="store_true", help="skip the legs outside the timed region (N = 1)")
+    ap.add_argument("--no-power-ceiling", action="store_true", help="skip tools/power_ceiling_probe after the timed region (N = 1)")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; makes the number INVALID)")
     ap.add_argument("--ctx", type=int, default=0, help="override context length (debug only; makes the number INVALID)")
     ap.add_argument("--requests", type=int, default=0, help="override requests per step (debug only; makes the number INVALID)")
@@ -188,6 +194,27 @@ def bookkeeping_baseline() -> dict:
         return m
     except Exception as e:      # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def power_ceiling(prefill_tflops, seconds=0.7) -> dict:
+    """roofline.other.power_ceiling: tools/power_ceiling_probe --quick on the (now idle) GPU — the MFMA rate the board sustains under its power
+    cap on pseudo-random operands, for back-to-back MFMAs and for the prefill tile step's instruction mix — and the prefill kernel's rate over them."""
+    exe = os.path.join(ROOT, "tools", "power_ceiling_probe")
+    if not os.path.exists(exe):
+        return {"error": "tools/power_ceiling_probe is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    try:
+        r = subprocess.run([exe, "--quick", str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001  (the bench line is printed either way)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    d["what"] = ("whole-chip streams of v_mfma_f32_32x32x16_f16 on pseudo-random operands, one wave per SIMD, no data flow: MFMAs only / with the prefill "
+                 "tile step's VALU mix and LDS fragment reads; the board clocks to its power cap")
+    d["mfma_only_frac_of_peak"] = round(d["mfma_only_tflops"] / 2500.0, 4)
+    d["tile_step_stream_frac_of_peak"] = round(d["tile_step_stream_tflops"] / 2500.0, 4)
+    if prefill_tflops:
+        d["prefill_over_mfma_only"] = round(prefill_tflops / d["mfma_only_tflops"], 4)
+        d["prefill_over_tile_step_stream"] = round(prefill_tflops / d["tile_step_stream_tflops"], 4)
+    return d
 
 
 def rooflines(detail: dict, traffic=None) -> dict:
@@ -639,6 +666,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if world == 1 and not a.no_power_ceiling and not a.leg and isinstance((out.get("roofline") or {}).get("other"), dict):
+            pf = out["roofline"]["other"].get("prefill") or {}
+            out["roofline"]["other"]["power_ceiling"] = power_ceiling(pf.get("achieved") if pf.get("unit") == "TFLOP/s" else None)
         if not a.no_cpu_baseline:
             # after the timed region and after the ranks have parted: the oracle on this workload's per-rank shape, host cores only
             keys = min(w["ctx"], 32768) if w["mode"] == "dynamic" else w["ctx"] - math.ceil(w["ctx"] / (1 + w["pd"]))

@@ -118,3 +118,27 @@ def test_replay_timer_stride_samples_every_layer_equally_often():
         timed = [n % L for n in range(L * L * k) if n % k == 0]
         counts = [timed.count(layer) for layer in range(L)]
         assert min(counts) == max(counts) > 0, (name, counts[:4])
+
+
+def test_power_ceiling_leg_reports_ratios_and_never_raises(monkeypatch, tmp_path):
+    """roofline.other.power_ceiling: the probe's two rates, their fractions of the 2.5 PF spec peak, and the prefill kernel's rate over them; a box
+    without the binary or without a device yields {"error": ...} (the bench line is printed either way)."""
+    import subprocess
+
+    class R:
+        stdout = '{"mfma_only_tflops": 1680.0, "tile_step_stream_tflops": 1360.0, "seconds_each": 0.70}\n'
+        stderr = ""
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: True)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    d = bench.power_ceiling(1167.4)
+    assert d["mfma_only_frac_of_peak"] == 0.672 and d["tile_step_stream_frac_of_peak"] == 0.544
+    assert d["prefill_over_mfma_only"] == round(1167.4 / 1680.0, 4) and d["prefill_over_tile_step_stream"] == round(1167.4 / 1360.0, 4)
+    assert "prefill_over_mfma_only" not in bench.power_ceiling(None)
+
+    class Bad:
+        stdout = "no device\n"
+        stderr = ""
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Bad())
+    assert "error" in bench.power_ceiling(1000.0)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: False)
+    assert "not built" in bench.power_ceiling(1000.0)["error"]

@@ -120,7 +120,7 @@ def test_decode_single_launch_merge_and_head_block_groups(B, G, Hkv, D, lens, dt
         assert torch.equal(outs[(512, splits)], outs[(1024, splits)]), "the two in-launch merge protocols differ only in how the partials travel"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12, 14, 782, 526], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved", "w4q2_dma_pipelined", "w4q2_dma_xor_image", "w4q2_dma_kpad"])
+@pytest.mark.parametrize("variant", [0, 1, 8, 4, 16, 12, 14, 6, 782, 526], ids=["w8q1_tr", "w8q1_plain", "w4q1_tr", "w4q2_tr", "w8q1_mfma_rowsum", "w8_interleaved", "w4q2_dma_pipelined", "w8q1_dma_pipelined", "w4q2_dma_xor_image", "w4q2_dma_kpad"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("n,c,Hq,Hkv", [
     (128, 0, 8, 2), (200, 0, 4, 1), (77, 333, 8, 4), (512, 1000, 4, 2), (130, 62, 2, 2), (64, 64, 4, 2),
@@ -502,7 +502,7 @@ def test_prefill_workgroup_orders(Hq, Hkv):
     ref64 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True)
     ref32 = flash_attn_with_kvcache_ref(q, kc, vc, cache_seqlens=cl, cache_batch_idx=idx, causal=True, math="f32")
     outs = []
-    for variant in enabled(32, 64, 0, 96, 12, 14, 14 | 32, 14 | 64):
+    for variant in enabled(32, 64, 0, 96, 12, 14, 14 | 32, 14 | 64, 6, 6 | 32, 6 | 64):
         out = flash_attn_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), cache_seqlens=cl.to(DEV), cache_batch_idx=idx.to(DEV),
                                       causal=True, _variant=variant)
         torch.cuda.synchronize()
@@ -556,7 +556,7 @@ def test_head_dim_64(Hq, Hkv, dtype):
         _check(out, r64, r32, dtype, "d64 prefill variant=%d" % variant)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 8, 1, 14, 782], ids=["default", "w8", "w4", "plain_reads", "w4q2_dma_pipelined", "w4q2_dma_xor_image"])
+@pytest.mark.parametrize("variant", [0, 2, 8, 1, 14, 6, 782], ids=["default", "w8", "w4", "plain_reads", "w4q2_dma_pipelined", "w8q1_dma_pipelined", "w4q2_dma_xor_image"])
 @pytest.mark.parametrize("causal", [True, False], ids=["causal", "full"])
 def test_prefill_kv_split(causal, variant):
     """KV-split prefill (the key range of a work item divided over workgroups, fp32 partials merged by combine_kernel):
@@ -615,7 +615,7 @@ def test_prefill_kv_split_heuristic_engages():
     assert (a.float() - b.float()).abs().max().item() <= 2e-3 and (a.float() - c1.float()).abs().max().item() <= 2e-3
 
 
-@pytest.mark.parametrize("variant,splits", [(0, 0), (2, 0), (8, 0), (0, 3), (2, 2), (14, 0), (14, 3), (782, 0), (782, 3)], ids=["default", "w8", "w4", "default_split3", "w8_split2", "dma64", "dma64_split3", "dma64xor", "dma64xor_split3"])
+@pytest.mark.parametrize("variant,splits", [(0, 0), (2, 0), (8, 0), (0, 3), (2, 2), (14, 0), (14, 3), (6, 0), (6, 3), (782, 0), (782, 3)], ids=["default", "w8", "w4", "default_split3", "w8_split2", "dma64", "dma64_split3", "dma32", "dma32_split3", "dma64xor", "dma64xor_split3"])
 def test_batched_variable_length_prefill(variant, splits):
     """One launch for the chunks of several sequences with different lengths (flash_attn_varlen_with_kvcache): every entry
     must equal the single-sequence call bit for bit and match the oracle; entries shorter than the grid's block count, an
@@ -704,7 +704,7 @@ def test_deferred_rescale_of_the_pipelined_kernel(dtype):
     ref64 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=cl, causal=True)
     ref32 = flash_attn_with_kvcache_ref(q, k.clone(), v.clone(), cache_seqlens=cl, causal=True, math="f32")
     outs = {}
-    for variant in enabled(14, 782, 0):
+    for variant in enabled(14, 782, 0, 6):
         out = flash_attn_with_kvcache(q.to(DEV), k.to(DEV), v.to(DEV), cache_seqlens=cl.to(DEV), causal=True, _variant=variant)
         torch.cuda.synchronize()
         _check(out, ref64, ref32, dtype, "deferred rescale variant %d" % variant)

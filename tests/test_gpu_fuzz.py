@@ -46,7 +46,7 @@ def test_fuzz_prefill(seed):
         causal = rng.random() < 0.8
         cls = [rng.choice([0, 1, 30, 64, 333, 600]) + (n if rng.random() < 0.85 else rng.randrange(1, n + 1)) for _ in range(B)]
         slots = rng.sample(range(B + 2), B)
-        variant = rng.choice([0, 0, 1, 2, 8, 9, 32, 64, 12 if D == 128 else 0, 4 if D == 128 else 0, 14 if D == 128 else 0, 782 if D == 128 else 2, 14 if D == 128 else 0, 526 if D == 128 else 8])
+        variant = rng.choice([0, 0, 1, 2, 8, 9, 32, 64, 12 if D == 128 else 0, 4 if D == 128 else 0, 14 if D == 128 else 0, 782 if D == 128 else 2, 14 if D == 128 else 0, 526 if D == 128 else 8, 6 if D == 128 else 0, 6 if D == 128 else 2])
         splits = rng.choice([0, 0, 0, 1, 2, 3, 7])
         if splits > 1:
             variant |= rng.choice([0, 0, 16384, 32768])      # the key-range shares merged inside the launch (both protocols)
@@ -87,7 +87,7 @@ def test_fuzz_batched_chunks(seed):
         slots = rng.sample(range(B + 1), B)
         i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
         out = flash_attn_varlen_with_kvcache(q.to(DEV), kc.to(DEV), vc.to(DEV), i32(starts), i32(lens), max(lens), i32(cls), i32(slots),
-                                             causal=True, num_splits=rng.choice([0, 0, 2, 5]), _variant=product_or_self(rng.choice([0, 2, 8, 64, 14, 782])),
+                                             causal=True, num_splits=rng.choice([0, 0, 2, 5]), _variant=product_or_self(rng.choice([0, 2, 8, 64, 14, 782, 6])),
                                              _max_seqlen_k=max(cls))
         torch.cuda.synchronize()
         for i in range(B):
@@ -150,7 +150,7 @@ def test_fuzz_prefill64_midsize(seed):
         cls = [p + (n if rng.random() < 0.8 else rng.randrange(1, n + 1)) for p in pre]
         ctx = max(cls) + 7
         causal = rng.random() < 0.85
-        variant = rng.choice([14, 14, 14, 782, 782])
+        variant = rng.choice([14, 14, 14, 782, 782, 6, 6, 6])
         splits = rng.choice([0, 0, 1, 2, 3])
         if splits > 1:
             variant |= rng.choice([0, 16384, 32768])

@@ -206,7 +206,7 @@ if __name__ == "__main__":
     torch.zeros(1, device=DEV)
     if "prefill" in what:
         for v in VARIANTS:
-            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3] + (", prefill64 build %d" % ((v >> 8) & 15) if (v >> 8) & 15 else ""), {0: "default plan", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups", 7: "4 waves x 64 rows, LDS-DMA ring, in-wave software pipeline (prefill64)"}[(v >> 1) & 7]))
+            print("-- prefill variant %d (order %s, tiling %s) --" % (v, ["XCD-grouped (default)", "block-major per head", "heaviest-first across heads", "XCD-grouped"][(v >> 5) & 3] + (", prefill64 build %d" % ((v >> 8) & 15) if (v >> 8) & 15 else ""), {0: "default plan", 1: "8 waves x 32 rows", 2: "4 waves x 64 rows", 3: "8 waves x 32 rows, LDS-DMA ring, in-wave software pipeline (prefill32)", 4: "4 waves x 32 rows", 6: "8 waves, hand-interleaved MFMA/VALU groups", 7: "4 waves x 64 rows, LDS-DMA ring, in-wave software pipeline (prefill64)"}[(v >> 1) & 7]))
             prefill(v)
     if "decode" in what:
         dvs = [variant]

@@ -427,7 +427,7 @@ PrefillPlan plan_prefill(const vattn_attn_params* p) {
     const bool auto_tiling = pl.tiling == 0;
     // 2 (64-row waves) and 6 (hand-interleaved, software-pipelined) exist for d = 128 only; 3 and 5 were the compiler-scheduled
     // pipelined and the phase-staggered kernels of round 1 (both slower, removed: profiles/r01_prefill_ablations.md)
-    if (pl.tiling == 3 || pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 6 || pl.tiling == 7))) pl.tiling = 1;
+    if (pl.tiling == 5 || (p->d != 128 && (pl.tiling == 2 || pl.tiling == 3 || pl.tiling == 6 || pl.tiling == 7))) pl.tiling = 1;      // 3: prefill32_lab.hip (round 6)
     if (!kLab && (pl.tiling == 2 || pl.tiling == 6)) pl.tiling = 1;     // lab-only kernels (validate() rejects them before this)
     if (pl.tiling == 6 && (p->q_lens || p->rotary_cos_sin)) pl.tiling = 1;      // the interleaved kernel has no batched-chunk / fused-RoPE form
     if (pl.tiling == 6) return pl;                                   // no split epilogue in that kernel
@@ -574,6 +574,8 @@ template <typename T, int HD, int WAVES, int QC, bool MSUM> void launch_prefill(
     }
 }
 
+void launch_prefill32(const vattn_attn_params* p, hipStream_t st, int nsplit);      // prefill32_lab.hip (d = 128): 8 waves x 32 rows on prefill64's data flow
+
 template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, hipStream_t st) {
     const bool use_tr = (p->variant & 1) == 0;
     if (p->k_new && p->seqlen_knew > 0) launch_append(p, st);
@@ -592,7 +594,8 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
                 // behind for the next one (the kernel's own reset by the last draw stays — it costs nothing)
                 persistent = ctr != nullptr && hipMemsetAsync(ctr, 0, 16 * sizeof(int), st) == hipSuccess;
             }
-            if (persistent) launch_prefill64p(p, st, ctr);
+            if (((p->variant >> 1) & 7) == 3) launch_prefill32(p, st, 1);        // LAB, explicit tiling 3: one prefill32 workgroup per listed piece
+            else if (persistent) launch_prefill64p(p, st, ctr);
             else launch_prefill64(p, st, 1, nullptr, 0);
             if (p->num_pf_blocks > 0) hipLaunchKernelGGL((combine_blocks_kernel<T, 128>), dim3((unsigned)p->num_pf_blocks * 64), dim3(256), 0, st, *p);
             hipError_t e = hipGetLastError();
@@ -614,7 +617,14 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
             launched = true;
         }
 #ifdef VATTN_LAB
-        else if (pl.tiling == 2) {
+        else if (pl.tiling == 3) {      // prefill64's data flow and tile step on 8 waves x 32 rows (prefill32_lab.hip)
+            launch_prefill32(p, st, pl.nsplit);
+            if (pl.nsplit > 1) {
+                const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
+                hipLaunchKernelGGL((combine_rows_kernel<T, 128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, pl.nsplit, p->seqlen_q, rows);
+            }
+            launched = true;
+        } else if (pl.tiling == 2) {
             launch_prefill<T, 128, 4, 2, false>(p, st, use_tr, pl.nsplit);
             launched = true;
         } else if (pl.tiling == 6) {

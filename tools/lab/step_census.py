@@ -26,7 +26,7 @@ def main():
     # kernel bodies: from "<name>:" to ".Lfunc_end"
     start = None
     for i, l in enumerate(lines):
-        if "prefill64" in l and want in l.split(":")[0] and re.match(r"^_Z\w+:", l):
+        if ("prefill64" in l or "prefill32" in l) and want in l.split(":")[0] and re.match(r"^_Z\w+:", l):
             start = i
             break
     if start is None:
@@ -78,7 +78,7 @@ main()
 def gaps(path, want):
     """per MFMA gap of the hot loop: instruction count and a first-order issue cost (4 cycles per instruction, v_exp 8, s_nop N: N+1 states)"""
     lines = open(path).read().splitlines()
-    start = next(i for i, l in enumerate(lines) if "prefill64" in l and want in l.split(":")[0] and re.match(r"^_Z\w+:", l))
+    start = next(i for i, l in enumerate(lines) if ("prefill64" in l or "prefill32" in l) and want in l.split(":")[0] and re.match(r"^_Z\w+:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end]
     labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}

@@ -123,7 +123,7 @@ def build_lib(force=False):
 # protocol, timing ablation, clock stamp and the fused hybrid launch, behind `variant` bits — plus the product sources that have no lab
 # side (the C entry points, the persistent prefill kernel, cache_flat).  The product sources carry none of that code any more.
 LAB_DIR_SRC = os.path.join(ROOT, "tools", "lab", "csrc")
-LAB_SOURCES = ("attn_api.hip", os.path.join(LAB_DIR_SRC, "prefill_kernels_lab.hip"), os.path.join(LAB_DIR_SRC, "prefill64_lab.hip"), "prefill64p_kernels.hip",
+LAB_SOURCES = ("attn_api.hip", os.path.join(LAB_DIR_SRC, "prefill_kernels_lab.hip"), os.path.join(LAB_DIR_SRC, "prefill64_lab.hip"), os.path.join(LAB_DIR_SRC, "prefill32_lab.hip"), "prefill64p_kernels.hip",
                os.path.join(LAB_DIR_SRC, "decode_kernels_lab.hip"), "cache_kernels.hip", os.path.join(LAB_DIR_SRC, "hybrid_lab.hip"))
 LAB_HEADERS = ("decode_body_lab.h", "prefill_body_lab.h")
 
@@ -206,9 +206,20 @@ def build_reference_pyref():
     return True
 
 
+def build_probe(force=False):
+    """tools/power_ceiling_probe: whole-chip MFMA streams for bench.py's `roofline.other.power_ceiling` (what the board's power budget leaves of
+    the MFMA peak on random operands).  Measurement infrastructure: a stand-alone binary, nothing of the product links it."""
+    out = os.path.join(ROOT, "tools", "power_ceiling_probe")
+    src = out + ".cpp"
+    if force or _newer(out, [src]):
+        _run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=" + ARCH, "-O3", "-Wno-unused-value", "-o", out, src])
+    return out
+
+
 def build_all(force=False):
     build_lib(force)
     build_lab(force)
+    build_probe(force)
     build_vtensor(force)
     build_fake_backend(force)
     build_reference_oracle()
