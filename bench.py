@@ -45,6 +45,8 @@ Every line (every N, static or dynamic) carries:
                       `mfma_only_tflops` (back-to-back v_mfma_f32_32x32x16_f16) and `tile_step_stream_tflops` (the same with the prefill tile
                       step's VALU mix and LDS fragment reads per MFMA); `prefill_over_mfma_only` / `prefill_over_tile_step_stream` = the prefill
                       kernel's achieved rate over them.  The part clocks to its power cap: these, not 2.5 PF, bound a chip-filling kernel.
+  `roofline.other.hbm_ceiling` (round 6, N = 1)  the same probe's read-only HBM stream (4 GiB, 16-byte loads, nothing written): `read_stream_gbs`, its
+                      fraction of the 8 TB/s spec peak, and `decode_over_read_stream` = the decode kernel's achieved rate over it.
   `legs.scale_series` ONE fixed workload at every N — Yi-34B (56 / 8 heads / N, 60 layers), one 131 072-token request in 16 k chunks — so that tokens/s
                       across the N = 1 / 2 / 4 / 8 lines is a strong-scaling series (the lines' `value`s follow BASELINE.json's per-N configs);
                       N > 1 adds `scaling_reference`: the same step once more WITHOUT the control-plane exchange (= --rank-of N on one GPU).
@@ -194,6 +196,19 @@ def bookkeeping_baseline() -> dict:
         return m
     except Exception as e:      # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def measured_ceilings(prefill_tflops, decode_gbs, seconds=0.7):
+    """(roofline.other.power_ceiling, roofline.other.hbm_ceiling) from ONE run of tools/power_ceiling_probe --quick"""
+    pc = power_ceiling(prefill_tflops, seconds)
+    h = pc.pop("hbm_read_stream_gbs", None)
+    if not h:
+        return pc, ({"error": pc["error"]} if "error" in pc else {"error": "the probe reported no HBM stream"})
+    hc = {"read_stream_gbs": h, "read_stream_frac_of_peak": round(h / 8000.0, 4),
+          "what": "read-only stream over 4 GiB (16x the MALL): 1 024 x 1 024 threads, four 16-byte loads in flight per lane, nothing written"}
+    if decode_gbs:
+        hc["decode_over_read_stream"] = round(decode_gbs / h, 4)
+    return pc, hc
 
 
 def power_ceiling(prefill_tflops, seconds=0.7) -> dict:
@@ -667,8 +682,15 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not a.no_power_ceiling and not a.leg and isinstance((out.get("roofline") or {}).get("other"), dict):
-            pf = out["roofline"]["other"].get("prefill") or {}
-            out["roofline"]["other"]["power_ceiling"] = power_ceiling(pf.get("achieved") if pf.get("unit") == "TFLOP/s" else None)
+            pf, dc = out["roofline"]["other"].get("prefill") or {}, out["roofline"]["other"].get("decode") or {}
+            pc, hc = measured_ceilings(pf.get("achieved") if pf.get("unit") == "TFLOP/s" else None, dc.get("achieved") if dc.get("unit") == "GB/s" else None)
+            out["roofline"]["other"]["power_ceiling"], out["roofline"]["other"]["hbm_ceiling"] = pc, hc
+            # the dominant kernel's rate over its measured ceiling, beside `frac` (of the spec peak)
+            over = pc.get("prefill_over_mfma_only") if out["roofline"].get("bound") == "mfma" else hc.get("decode_over_read_stream")
+            if over is not None:
+                out["roofline"]["frac_of_measured_ceiling"] = over
+                out["roofline"]["measured_ceiling"] = ("back-to-back MFMAs on random operands under the board's power cap (other.power_ceiling.mfma_only_tflops)"
+                                                       if out["roofline"].get("bound") == "mfma" else "read-only HBM stream (other.hbm_ceiling.read_stream_gbs)")
         if not a.no_cpu_baseline:
             # after the timed region and after the ranks have parted: the oracle on this workload's per-rank shape, host cores only
             keys = min(w["ctx"], 32768) if w["mode"] == "dynamic" else w["ctx"] - math.ceil(w["ctx"] / (1 + w["pd"]))

@@ -134,6 +134,10 @@ def test_power_ceiling_leg_reports_ratios_and_never_raises(monkeypatch, tmp_path
     assert d["mfma_only_frac_of_peak"] == 0.672 and d["tile_step_stream_frac_of_peak"] == 0.544
     assert d["prefill_over_mfma_only"] == round(1167.4 / 1680.0, 4) and d["prefill_over_tile_step_stream"] == round(1167.4 / 1360.0, 4)
     assert "prefill_over_mfma_only" not in bench.power_ceiling(None)
+    R.stdout = '{"mfma_only_tflops": 1680.0, "tile_step_stream_tflops": 1360.0, "seconds_each": 0.70, "hbm_read_stream_gbs": 6600.0}\n'
+    pc, hc = bench.measured_ceilings(1167.4, 5717.0)
+    assert "hbm_read_stream_gbs" not in pc and pc["prefill_over_tile_step_stream"] == round(1167.4 / 1360.0, 4)
+    assert hc["read_stream_gbs"] == 6600.0 and hc["read_stream_frac_of_peak"] == 0.825 and hc["decode_over_read_stream"] == round(5717.0 / 6600.0, 4)
 
     class Bad:
         stdout = "no device\n"
@@ -142,3 +146,5 @@ def test_power_ceiling_leg_reports_ratios_and_never_raises(monkeypatch, tmp_path
     assert "error" in bench.power_ceiling(1000.0)
     monkeypatch.setattr(bench.os.path, "exists", lambda p: False)
     assert "not built" in bench.power_ceiling(1000.0)["error"]
+    pc, hc = bench.measured_ceilings(1000.0, 5000.0)
+    assert "error" in pc and "error" in hc

@@ -1,4 +1,4 @@
-// Probe (round 6; bench.py's `roofline.other.power_ceiling`, tools/lab/power_ceiling.py): what does the POWER budget leave of the MFMA peak?  (gfx950)
+// Probe (round 6; bench.py's `roofline.other.power_ceiling` / `.hbm_ceiling`, tools/lab/power_ceiling.py): what does the POWER budget leave of the MFMA peak?  (gfx950)
 // prefill32_kernel takes 4 % fewer cycles than prefill64_kernel and 2-3 % more time: the part clocks to its power budget, so the ceiling of a
 // chip-filling MFMA kernel on random data is not 2.5 PFLOP/s (= 2.4 GHz x 256 CUs x 4 SIMDs x 32x32x16x2 / 32 cycles) but whatever clock the
 // board sustains under that load.  This probe measures that ceiling directly: whole-chip streams of v_mfma_f32_32x32x16_f16, one wave per SIMD,
@@ -8,7 +8,9 @@
 //   stream 2  ... plus its LDS fragment reads (1/2 ds_read_b128 + 1 ds_read_b64_tr_b16 per 2 MFMAs)
 // each with pseudo-random fragments and with zero fragments.  Output: TFLOP/s, ns per MFMA per SIMD, and the clock a 32-cycle MFMA implies for
 // stream 0 (streams 1 / 2 are issue-bound: their cycles per MFMA are not known a priori).
-// `--quick [seconds]`: the two random-data lines bench.py reports (MFMAs only; MFMAs + VALU mix + LDS reads), one JSON object on stdout.
+// Also (the decode kernel's ceiling, same idea): a read-only HBM stream — every workgroup sums a contiguous slice of a 4 GiB buffer with 16-byte
+// loads, four in flight per lane, 1 024 x 1 024 threads (the best shape of tools/hbm_read_probe.cpp's sweep, profiles/r01_hbm_read_probe.txt).
+// `--quick [seconds]`: what bench.py reports (MFMAs only; MFMAs + VALU mix + LDS reads; the HBM read stream), one JSON object on stdout.
 // build: vattention_amd/build.py build_probe() = hipcc --offload-arch=gfx950 -O3 -o tools/power_ceiling_probe tools/power_ceiling_probe.cpp
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -72,6 +74,38 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, unsigned 
     if (sum == 12345.678f) out[0] = sum + lds[lane];
 }
 
+__global__ __launch_bounds__(1024) void hbm_read(const uint4* __restrict__ src, float* out, size_t n16) {
+    const size_t per = n16 / gridDim.x;
+    const uint4* p = src + (size_t)blockIdx.x * per;
+    unsigned acc = 0;
+    for (size_t i = threadIdx.x; i + 3 * (size_t)blockDim.x < per; i += 4 * (size_t)blockDim.x) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = p[i + (size_t)u * blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = 1.f;
+}
+// GB/s of the read stream: mean of 20 back-to-back passes over 4 GiB (16x the 256 MiB MALL), after two warm-up passes
+static double hbm_read_stream(float* out) {
+    const size_t bytes = 4ull << 30;
+    uint4* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return 0.0;
+    (void)hipMemset(d, 1, bytes);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL(hbm_read, dim3(1024), dim3(1024), 0, 0, d, out, bytes / 16);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL(hbm_read, dim3(1024), dim3(1024), 0, 0, d, out, bytes / 16);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipFree(d);
+    return 20.0 * bytes / ms / 1e6;
+}
+
 static double g_seconds = 1.0;
 static bool g_quiet = false;
 template <int STREAM> double run(const char* what, int zero, float* out) {
@@ -114,7 +148,8 @@ int main(int argc, char** argv) {
         g_seconds = argc > 2 ? atof(argv[2]) : 0.7;
         g_quiet = true;
         const double a = run<0>("", 0, out), b = run<2>("", 0, out);
-        printf("{\"mfma_only_tflops\": %.1f, \"tile_step_stream_tflops\": %.1f, \"seconds_each\": %.2f}\n", a, b, g_seconds);
+        const double h = hbm_read_stream(out);
+        printf("{\"mfma_only_tflops\": %.1f, \"tile_step_stream_tflops\": %.1f, \"seconds_each\": %.2f, \"hbm_read_stream_gbs\": %.1f}\n", a, b, g_seconds, h);
         return 0;
     }
     printf("# whole chip (256 workgroups x 4 waves, one wave per SIMD), v_mfma_f32_32x32x16_f16, ~1 s sustained per line\n");
@@ -124,6 +159,10 @@ int main(int argc, char** argv) {
         run<2>("MFMAs + VALU mix + LDS reads", 0, out);
         run<0>("MFMAs only", 1, out);
         run<1>("MFMAs + the tile step's VALU mix", 1, out);
+    }
+    for (int rep = 0; rep < 2; rep++) {
+        const double h = hbm_read_stream(out);
+        printf("HBM read stream (4 GiB, 1024 x 1024 threads, 4 x 16 B in flight per lane)  %8.1f GB/s  (%.3f of 8000)\n", h, h / 8000.0);
     }
     return 0;
 }
