@@ -264,7 +264,10 @@ int prefill_worklist(const vattn_attn_params* p, const int32_t* q_lens, const in
                      vattn_prefill_item* blocks, int cap_blocks, int32_t* counts, int32_t* wg_first = nullptr, int max_wg = 0, int persist_mode = 0);   // prefill_kernels.hip; persist_mode 0 none, 1 host-assigned queues, 2 drawn queues
 void launch_prefill64p(const vattn_attn_params* p, hipStream_t st, int* ctr);      // prefill64p_kernels.hip: persistent workgroups over a work list (ctr: drawn queues)
 int* queue_counters(hipStream_t st);      // attn_api.hip: 8 zeroed ints per (device, stream) for the drawn queues, NULL while the stream is being captured before they exist
-void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode);   // prefill64_kernels.hip (d = 128); done: counters of the single-launch merge or NULL
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit);      // prefill64_kernels.hip (d = 128)
+#ifdef VATTN_LAB
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode);   // tools/lab/csrc/prefill64_lab.hip; done: counters of the single-launch merge or NULL
+#endif
 int* merge_counters(hipStream_t st, size_t n_ints);                      // attn_api.hip: zeroed per-(device, stream) counters, NULL while capturing
 int launch_decode_form(const vattn_attn_params* p, hipStream_t st);     // decode_kernels.hip (seqlen_q == 1)
 size_t decode_workspace_bytes(const vattn_attn_params* p);

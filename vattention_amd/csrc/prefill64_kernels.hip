@@ -597,11 +597,8 @@ template <typename T> static void launch64_t(const vattn_attn_params* p, hipStre
     hipLaunchKernelGGL((prefill64_kernel<T>), grid, dim3(256), kSmem64 + 16, st, *p, order, nqb, nsplit);
 }
 
-// ONE build per dtype.  `done` / `merge_mode` belong to the lab copy's in-launch merge (tools/lab/csrc/prefill64_lab.hip); the product's callers
-// pass none and the key-range shares are merged by combine_rows_kernel / combine_blocks_kernel in a second launch.
-void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit, int* done, int merge_mode) {
-    (void)done;
-    (void)merge_mode;
+// ONE build per dtype; key-range shares are merged by combine_rows_kernel / combine_blocks_kernel in a second launch (prefill_kernels.hip).
+void launch_prefill64(const vattn_attn_params* p, hipStream_t st, int nsplit) {
     if (p->dtype == VATTN_DTYPE_BF16) launch64_t<__bf16>(p, st, nsplit);
     else launch64_t<_Float16>(p, st, nsplit);
 }

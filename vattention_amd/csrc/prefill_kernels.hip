@@ -286,7 +286,7 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
                 persistent = ctr != nullptr && hipMemsetAsync(ctr, 0, 16 * sizeof(int), st) == hipSuccess;
             }
             if (persistent) launch_prefill64p(p, st, ctr);
-            else launch_prefill64(p, st, 1, nullptr, 0);
+            else launch_prefill64(p, st, 1);
             if (p->num_pf_blocks > 0) hipLaunchKernelGGL((combine_blocks_kernel<T, 128>), dim3((unsigned)p->num_pf_blocks * 64), dim3(256), 0, st, *p);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
@@ -298,7 +298,7 @@ template <typename T, int HD> int launch_prefill_t(const vattn_attn_params* p, h
     bool launched = false;
     if constexpr (HD == 128) {
         if (pl.tiling == 7) {
-            launch_prefill64(p, st, pl.nsplit, nullptr, 0);
+            launch_prefill64(p, st, pl.nsplit);
             if (pl.nsplit > 1) {
                 const int64_t rows = (int64_t)p->b * p->seqlen_q * p->h;
                 hipLaunchKernelGGL((combine_rows_kernel<T, 128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, *p, pl.nsplit, p->seqlen_q, rows);
