@@ -27,6 +27,16 @@
 
 namespace vattn_k {
 
+// LAB (round 6, closed): l(agpr, 4 equal registers) += the lane's OWN four P values — v_mfma_f32_4x4x4 (16 blocks of 4 lanes, K = 4) with A = ones
+// gives D[i][j] = sum_k B[k][j], and lane (block, j) holds exactly B[0..3][j]: row sums on the matrix pipe
+template <typename T> __device__ __forceinline__ void rowsum4(f32x4& l, typename Tr<T>::v4 ones, typename Tr<T>::v4 b);
+template <> __device__ __forceinline__ void rowsum4<_Float16>(f32x4& l, Tr<_Float16>::v4 ones, Tr<_Float16>::v4 b) {
+    asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(b));
+}
+template <> __device__ __forceinline__ void rowsum4<__bf16>(f32x4& l, Tr<__bf16>::v4 ones, Tr<__bf16>::v4 b) {
+    asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(b));
+}
+
 
 // ABL bits 0-5: timing ablations for tools/kbench.py (results are WRONG when any is set): bit 0 no LDS-DMA in the steady state,
 // bit 1 no exp2 / row sums, bit 2 no row max, bit 3 no per-tile wait + barrier, bit 4 fragment reads only for the first MFMAs of
@@ -534,10 +544,10 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(vattn_attn_params p, 
             // row sums of key slice ks (its P fragments were packed at least two groups ago): four 4x4x4 MFMAs per slice, behind the
             // first fillers of a group so that they do not queue straight behind the group's own MFMA
             if constexpr (MSUM) {      // groups 0, 2 of a slice: query block 0 (low, high half of its fragment); 4, 6: block 1
-                if ((j & 7) == 0) M::rowsum4(lsum[0], ones4, __builtin_shufflevector(pf[ks & 1][0], pf[ks & 1][0], 0, 1, 2, 3));
-                if ((j & 7) == 2) M::rowsum4(lsum[0], ones4, __builtin_shufflevector(pf[ks & 1][0], pf[ks & 1][0], 4, 5, 6, 7));
-                if ((j & 7) == 4) M::rowsum4(lsum[1], ones4, __builtin_shufflevector(pf[ks & 1][1], pf[ks & 1][1], 0, 1, 2, 3));
-                if ((j & 7) == 6) M::rowsum4(lsum[1], ones4, __builtin_shufflevector(pf[ks & 1][1], pf[ks & 1][1], 4, 5, 6, 7));
+                if ((j & 7) == 0) rowsum4<T>(lsum[0], ones4, __builtin_shufflevector(pf[ks & 1][0], pf[ks & 1][0], 0, 1, 2, 3));
+                if ((j & 7) == 2) rowsum4<T>(lsum[0], ones4, __builtin_shufflevector(pf[ks & 1][0], pf[ks & 1][0], 4, 5, 6, 7));
+                if ((j & 7) == 4) rowsum4<T>(lsum[1], ones4, __builtin_shufflevector(pf[ks & 1][1], pf[ks & 1][1], 0, 1, 2, 3));
+                if ((j & 7) == 6) rowsum4<T>(lsum[1], ones4, __builtin_shufflevector(pf[ks & 1][1], pf[ks & 1][1], 4, 5, 6, 7));
             }
             // P fragments of key slice ks+1 are packed while slice ks is multiplied (4 cvt_pk per group, groups 4 and 6 of a slice)
             if (!(ABL & 32)) {

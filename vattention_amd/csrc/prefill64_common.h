@@ -73,7 +73,7 @@ __device__ __forceinline__ u32x4 tile_rsrc(const void* base, unsigned bytes) {
 // hipcc does not pad hazards around inline asm: callers keep MFMA results away from VALU readers by program order (an 8-pass
 // MFMA result is readable >= 12 states later) and use the _NOP forms when an A/B/C operand was just written by the VALU.
 template <typename T> struct Mfma;
-#define VATTN_MFMA_STRUCT(TYPE, MNEM, MNEM4)                                                                                             \
+#define VATTN_MFMA_STRUCT(TYPE, MNEM)                                                                                                    \
     template <> struct Mfma<TYPE> {                                                                                                \
         using V8 = typename Tr<TYPE>::v8;                                                                                          \
         /* S(vgpr) = A(vgpr) x B(agpr) + 0: the first MFMA of a chain */                                                           \
@@ -91,18 +91,13 @@ template <typename T> struct Mfma;
         static __device__ __forceinline__ void qk_acc_a(f32x16& d, V8 a, V8 b) {                                                   \
             asm volatile(MNEM " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));                                                       \
         }                                                                                                                          \
-        /* l(agpr, 4 equal registers) += the lane's OWN four P values: v_mfma_f32_4x4x4 (16 blocks of 4 lanes, K = 4) with A = ones gives    \
-           D[i][j] = sum_k B[k][j], and lane (block, j) holds exactly B[0..3][j] (round 6: row sums on the matrix pipe) */                  \
-        static __device__ __forceinline__ void rowsum4(f32x4& l, typename Tr<TYPE>::v4 ones, typename Tr<TYPE>::v4 b) {            \
-            asm volatile(MNEM4 " %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(b));                                                   \
-        }                                                                                                                          \
         /* O(agpr) += A(vgpr) x B(vgpr) */                                                                                         \
         static __device__ __forceinline__ void pv(f32x16& o, V8 a, V8 b) {                                                         \
             asm volatile(MNEM " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                                       \
         }                                                                                                                          \
     };
-VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16", "v_mfma_f32_4x4x4_16b_f16")
-VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_4x4x4_16b_bf16")
+VATTN_MFMA_STRUCT(_Float16, "v_mfma_f32_32x32x16_f16")
+VATTN_MFMA_STRUCT(__bf16, "v_mfma_f32_32x32x16_bf16")
 #undef VATTN_MFMA_STRUCT
 // one scalar f32 add that the SLP vectoriser cannot pack into v_pk_add_f32 (packed f32 VALU beside MFMAs costs more than two
 // plain adds, MI355X_MICROARCH "price of one filler")
