@@ -22,7 +22,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int STREAM>
+// REUSE (stream 0 only; `--operand-reuse`): which operand lines toggle between consecutive MFMAs — 0: A and B both change every MFMA;
+// 1: A stays for two MFMAs, B alternates between two fragments (the kernel's phase A: one K fragment against the two Q^T blocks; phase B alike);
+// 2: B stays for four MFMAs, A changes every MFMA; 3: A and B both stay for four MFMAs (only the accumulator changes)
+template <int STREAM, int REUSE = 0>
 __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, unsigned seed, int zero) {
     extern __shared__ char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -51,7 +54,10 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, unsigned 
 #pragma unroll
         for (int g = 0; g < 64; g++) {
             // the accumulators stay small: B alternates sign through the rotation (fragments are +-2), sums random-walk
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a[g & 7]), "v"(b[(g * 5 + (g >> 3)) & 7]));
+            if (REUSE == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a[g & 7]), "v"(b[(g * 5 + (g >> 3)) & 7]));
+            if (REUSE == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a[(g >> 1) & 7]), "v"(b[(g & 1) + 2 * ((g >> 4) & 3)]));
+            if (REUSE == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a[g & 7]), "v"(b[(g >> 2) & 7]));
+            if (REUSE == 3) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a[(g >> 2) & 7]), "v"(b[((g >> 2) * 3) & 7]));
             if (STREAM >= 1) {
                 if ((g & 1) == 0) {
                     asm volatile("v_fma_f32 %0, %2, %3, %3\n\tv_fma_f32 %1, %2, %3, %3" : "=v"(x[0]), "=v"(x[1]) : "v"(k[0]), "v"(c));
@@ -108,8 +114,8 @@ static double hbm_read_stream(float* out) {
 
 static double g_seconds = 1.0;
 static bool g_quiet = false;
-template <int STREAM> double run(const char* what, int zero, float* out) {
-    auto kfn = probe<STREAM>;
+template <int STREAM, int REUSE = 0> double run(const char* what, int zero, float* out) {
+    auto kfn = probe<STREAM, REUSE>;
     hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
     const int grid = 256, iters = 20000;      // 64 x 20 000 MFMAs per wave: ~40-60 ms per launch
     hipEvent_t e0, e1;
@@ -150,6 +156,16 @@ int main(int argc, char** argv) {
         const double a = run<0>("", 0, out), b = run<2>("", 0, out);
         const double h = hbm_read_stream(out);
         printf("{\"mfma_only_tflops\": %.1f, \"tile_step_stream_tflops\": %.1f, \"seconds_each\": %.2f, \"hbm_read_stream_gbs\": %.1f}\n", a, b, g_seconds, h);
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "--operand-reuse")) {
+        printf("# MFMAs only, whole chip, random operands: which operand lines toggle between consecutive MFMAs\n");
+        for (int rep = 0; rep < 2; rep++) {
+            run<0, 0>("A and B change every MFMA", 0, out);
+            run<0, 1>("A stays for 2, B alternates", 0, out);
+            run<0, 2>("B stays for 4, A changes", 0, out);
+            run<0, 3>("A and B stay for 4", 0, out);
+        }
         return 0;
     }
     printf("# whole chip (256 workgroups x 4 waves, one wave per SIMD), v_mfma_f32_32x32x16_f16, ~1 s sustained per line\n");
