@@ -42,7 +42,11 @@ UNROLL_FLAGS = ["-mllvm", "-pragma-unroll-threshold=1000000"]
 # prefill64_kernel counts its own `vmcnt` around LDS-DMA issued by inline asm: a register spill (scratch access, compiler-inserted
 # waits the hand-placed ones do not know about) silently breaks it, and the kernel sits at the SGPR / VGPR limits.  Its translation unit
 # is therefore compiled with the resource-usage remarks on, and the build FAILS when any instantiation of a guarded kernel spills.
-NO_SPILL_KERNELS = {"prefill64_kernels.hip": "prefill64_kernel", "prefill64p_kernels.hip": "prefill64p_kernel"}
+NO_SPILL_KERNELS = {"prefill64_kernels.hip": "prefill64_kernel", "prefill64p_kernels.hip": "prefill64p_kernel", "decode_kernels.hip": "decode_"}
+# ... except: the bf16 build of decode_stream_kernel (d = 128, one head block) that takes the fused-RoPE path at run time — bf16 rotates through fp32,
+# 12 registers more than three workgroups per CU leave; calls without rotation get the build without that path (decode_kernels.hip,
+# launch_decode_stream).  A scratch segment costs ~9 us per launch (profiles/r06_decode_bf16_scratch.txt): no other kernel may grow one unnoticed.
+SPILL_ALLOWED = ("decode_stream_kernelIDF16bLi128ELb1ELi1ELin1E",)
 
 
 # prefill64p_kernel receives its queue tickets in v255 asynchronously (an atomic issued by inline asm, read a tile step later): no other
@@ -89,14 +93,14 @@ def _compile(hipcc, flags, src, obj):
             seen += guard in name
         elif name and guard in name and ("ScratchSize" in line or "VGPRs Spill" in line):      # (SGPRs spilled to vector LANES touch no memory)
             value = int(line.split("]:")[-1].split("[")[0].strip() if "ScratchSize" in line else line.split("Spill:")[1].split()[0])
-            if value:
+            if value and not any(a in name for a in SPILL_ALLOWED):
                 bad.append("%s: %s" % (name, line.split("remark:")[1].split("[-R")[0].strip()))
     if not seen:
         raise RuntimeError("no resource remarks for %s in %s: the spill guard saw nothing" % (guard, src))
     if os.path.basename(src) in RESERVED_VGPR:
         _check_reserved_vgpr(hipcc, flags, src, *RESERVED_VGPR[os.path.basename(src)])
     if bad:
-        raise RuntimeError("register spills in a kernel that counts its own vmcnt:\n  " + "\n  ".join(bad))
+        raise RuntimeError("register spills / a scratch segment in a kernel that must have none (hand-counted vmcnt; + 9 us per launch):\n  " + "\n  ".join(bad))
 
 
 def build_lib(force=False):

@@ -23,7 +23,9 @@ constexpr int DC_BN = 32;     // keys per wave tile
 // PF: K/V register sets per wave = tiles a wave keeps in flight (1: the product shape for chip-filling grids, three workgroups per CU; 2:
 //     a second set, requested a whole tile earlier — a lone wave then pulls twice the bytes per round trip, which is what bounds
 //     launches with FEWER workgroups than the chip has room for: batch 1-4 decode; two workgroups per CU).
-template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES, int PF = 1>
+// ROPE: -1 = the fused-RoPE path is compiled in and taken when p.rotary_cos_sin is set; 0 = compiled out (the bf16 build of decode_stream_kernel
+// for calls without rotation: its fp32 rotation is 12 registers more than three workgroups per CU leave, see launch_decode_stream); 1 = unconditional
+template <typename T, int HD, bool USE_TR, int NB = 1, int W = DC_WAVES, int PF = 1, int ROPE = -1>
 __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const int num_splits, const int gblocks, const int fused_append,
                                             const int split, const int hk, const int gb, const int b, char* smem,
                                             const int item = -1, const int item_tb = 0, const int item_te = 0,
@@ -96,7 +98,7 @@ __device__ __forceinline__ void decode_body(const vattn_attn_params& p, const in
     }
     // fused RoPE (include/vattn_kernels.h): the query token sits at position Lk - 1; slot (g4, j) of k-step kk is element
     // d = 32*kk + 8*g4 + j, so element d and its partner d + HD/2 live in the SAME lane (k-steps kk and kk + KK/2)
-    const bool rope = p.rotary_cos_sin != nullptr;
+    const bool rope = ROPE < 0 ? p.rotary_cos_sin != nullptr : ROPE == 1;
     if (rope) {
 #pragma unroll
         for (int kk = 0; kk < KK / 2; kk++) {
@@ -652,7 +654,7 @@ __device__ __forceinline__ void decode_stream_merge(const vattn_attn_params& p, 
 
 // nwg: workgroups per (kv head, group) = gridDim.x.  The partials are merged by decode_stream_combine_kernel in a second launch (merging
 // inside the launch, XCD-consecutive ranges, per-workgroup clock stamps, fair-share issue priority: tools/lab/csrc/decode_body_lab.h).
-template <typename T, int HD, bool USE_TR, int NB>
+template <typename T, int HD, bool USE_TR, int NB, int ROPE = -1>
 __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_kernel(vattn_attn_params p, int gblocks, int fused_append) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_plan[3 * DC_MAXB];                // stream mode: the plan, for the pieces after the first
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(64 * DC_WAVES, NB > 1 ? 2 : 3) void decode_stream_k
     for (;;) {
         const unsigned blk = stream_table_bytes(p.b) + (((unsigned)(w + b) * p.h_k + hk) * gblocks + gb) * RB;
         if (tb == 0 && hk == 0 && gb == 0 && tid == 0) stream_publish_seq(p, b, first_rec, cnt);      // (the owner of the sequence's first piece)
-        decode_body<T, HD, USE_TR, NB>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, tb, te, cnt == 1 ? 1 : 2, slot, lk, blk);
+        decode_body<T, HD, USE_TR, NB, DC_WAVES, 1, ROPE>(p, 2, gblocks, fused_append, 0, hk, gb, b, smem, 0, tb, te, cnt == 1 ? 1 : 2, slot, lk, blk);
         if (geo.uniform || !next_piece(b + 1)) return;
         __syncthreads();                                 // the previous piece's in-workgroup merge is done with the LDS
     }

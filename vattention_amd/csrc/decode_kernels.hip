@@ -199,7 +199,15 @@ template <typename T, int HD, int NB> int launch_decode_stream(const vattn_attn_
     const size_t smem = (size_t)DC_WAVES * 16 * HD * 4 + DC_WAVES * 16 * 4 * 2;
     const int fused_append = (p->k_new && p->seqlen_knew == 1) ? 1 : 0;
     if (p->k_new && !fused_append) launch_append(p, st);
-    hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB>), dim3((unsigned)nwg, (unsigned)p->h_k), dim3(64 * DC_WAVES), smem, st, *p, 1, fused_append);
+    const dim3 grid((unsigned)nwg, (unsigned)p->h_k), block(64 * DC_WAVES);
+    if constexpr (__is_same(T, __bf16)) {
+        // bf16 rotates through fp32 (no packed arithmetic): with the fused-RoPE path compiled in, decode_stream_kernel<bf16, 128, one head block> is
+        // 12 registers over the 168 of three workgroups per CU and gets a scratch segment — 9 us per launch even when no rotation is asked for
+        // (profiles/r06_decode_bf16_scratch.txt).  Two builds: without the path (what the reference's wrapper calls: no spill), and the one that
+        // takes it at run time (the path compiled in UNCONDITIONALLY spills more: 46 registers instead of 12).
+        if (p->rotary_cos_sin) hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB, -1>), grid, block, smem, st, *p, 1, fused_append);
+        else hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB, 0>), grid, block, smem, st, *p, 1, fused_append);
+    } else hipLaunchKernelGGL((decode_stream_kernel<T, HD, true, NB>), grid, block, smem, st, *p, 1, fused_append);
     hipLaunchKernelGGL((decode_stream_combine_kernel<T, HD, NB>), dim3((unsigned)p->b, (unsigned)p->h_k), dim3(256), 0, st, *p, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATTN_K_ERR_LAUNCH, hipGetErrorString(e));
